@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the NPVP Stage-2 predictor training step on MI355X (BASELINE.json metric:
+"predictor train frames/sec at 1/2/4/8 MI355X; MFMA util %").
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one optimisation step of the predictor-only flavour of the reference's
+training_step_no_gan: frozen-encoder feature grids in HBM -> predictor fwd (S: context +
+target encoder passes, prior/posterior, decoder) -> feature-L1 + KL -> backward -> decoder-only
+grad-norm clip -> AdamW -> cosine-warm-restart lr, with the reference's dropout 0.1 / drop-path 0.1
+active.  Default workload = BASELINE.json configs[1]: KTH 64x64 NPVP-S, B=32 clips per GPU, To=Tp=10
+(weak scaling: every rank gets its own 32 clips; gradients all-reduced over RCCL).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = forward GEMM gemm_f32_kernel<1,1>,
+timed live with HIP event pairs around every launch inside the timed region) and, at N=1,
+`cpu_baseline` (the CPU oracle restatement of the same step on a bounded sample, host cores stated).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+WORKLOADS = {   # name -> (config file, variant, per-GPU clips, To, Tp)
+    "c1": ("config_KTH_VFP_NPVP-S.yaml", "KTH 64x64 NPVP-S", 32, 10, 10),
+    "c2": ("config_BAIR_VFP_NPVP-D.yaml", "BAIR 64x64 NPVP-D", 64, 2, 28),
+    "c2p": ("config_BAIR_VFP_NPVP-D.yaml", "BAIR 64x64 NPVP-D (T=20)", 64, 2, 18),
+    "c0": ("config_SMMNIST_VFP_NPVP-S.yaml", "SM-MNIST 64x64 NPVP-S", 4, 5, 15),
+    "c3": ("config_Cityscapes_VFP_NPVP-S.yaml", "Cityscapes 128x128 NPVP-S (per-GPU shard)", 8, 2, 12),
+    "c4": ("config_KITTI_VFP_NPVP-D.yaml", "KITTI 128x128 NPVP-D (per-GPU shard)", 8, 4, 16),
+}
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def forward_macs_per_clip(To, Tp, stochastic):
+    """Algorithmic MACs of one Predictor.forward per clip (SURVEY 8d formula; train = 3x forward)."""
+    C, hid, ff = 512, 2048, 1024
+
+    def E(T):
+        return 4 * C * C + 2 * 16 * C + (2 * C * hid + 9 * hid) + 4 * C * C + 2 * T * C + 2 * C * ff
+
+    def D(To_, Tp_):
+        return E(Tp_) + (2 * C * hid + 9 * hid) + 2 * C * C + 2 * To_ * C + 2 * C * C * To_ / Tp_
+
+    evt = 9 * 512 + 9 * 512 * 256 + 256 * 256 + 256 * 512 * (2 if stochastic else 1)
+    macs = 64 * (To * 4 * E(To) + (Tp * 4 * E(Tp) if stochastic else 0) + Tp * 8 * D(To, Tp))
+    macs += 64 * evt * (2 if stochastic else 1) + 64 * (To + Tp) * 393984
+    return macs
+
+
+def cpu_baseline(cfg_file, To, Tp, clips=2, steps=2):
+    """The reference CPU path = the oracle restatement (pinned to the reference by tests/golden), timed on the
+    host cores on a bounded sample of the same workload: `clips` clips of the same To/Tp, full depth."""
+    import oracle
+    from npvp_amd.trainer import load_config
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = load_config(os.path.join(ROOT, "configs", cfg_file), clips, To, Tp)
+    P = cfg["Predictor"]
+    m = oracle.build_predictor_from_cfg(oracle.Predictor, P, To, Tp)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=P["predictor_lr"])
+    past, fut = oracle.synth_features((clips, To, 512, 8, 8), 3047), oracle.synth_features((clips, Tp, 512, 8, 8), 3048)
+    oracle.predictor_train_step(m, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"])      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle.predictor_train_step(m, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"])
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": clips * (To + Tp) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{clips} clips x (To={To},Tp={Tp}), full-depth predictor train step, 1 warm-up + {steps} timed "
+                      f"steps of the CPU oracle (torch {torch.__version__}, {dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    args = ap.parse_args()
+
+    import npvp_amd
+    from npvp_amd import dp, ops
+    from npvp_amd.trainer import load_config, cosine_warm_restarts_lr
+
+    rank, world, local = dp.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg_file, name, B, To, Tp = WORKLOADS[args.workload]
+    cfg = load_config(os.path.join(ROOT, "configs", cfg_file), B, To, Tp)
+    P = cfg["Predictor"]
+    torch.manual_seed(cfg["Env"]["rand_seed"])
+    model = npvp_amd.build_predictor_from_cfg(npvp_amd.Predictor, P, To, Tp).to(dev)       # dropout/drop-path 0.1 defaults
+    if world > 1:
+        dp.broadcast_module(model)
+        dp.convert_sync_batchnorm(model)
+    model.train()
+    opt = npvp_amd.FlatAdamW(model, lr=P["predictor_lr"], clip_module=model.transformer, max_grad_norm=P["max_grad_norm"])
+    gsync = dp.GradSync(opt.buf) if world > 1 else None
+    ops.rng.manual_seed(cfg["Env"]["rand_seed"] + rank, dev)
+
+    g = torch.Generator().manual_seed(cfg["Env"]["rand_seed"] + rank)
+    past = torch.relu(torch.randn(B, To, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
+    fut = torch.relu(torch.randn(B, Tp, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
+    iters_per_epoch = 100
+
+    def step(i):
+        opt.set_lr(cosine_warm_restarts_lr(P["predictor_lr"], P["scheduler_eta_min"], P["scheduler_T0"], i / iters_per_epoch))
+        return npvp_amd.predictor_train_step(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"],
+                                             sync=False, grad_sync=gsync)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_probe:
+        ops.GemmProbe.arm(1, 1)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.GemmProbe.disarm()
+    loss = float(out["loss"])
+    assert loss == loss, "loss is NaN"
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    ms = 1000.0 * dt / args.steps
+    frames = world * B * (To + Tp)
+    flops_step = 3 * 2 * forward_macs_per_clip(To, Tp, P["stochastic"]) * B          # per GPU, fwd+bwd
+
+    roof = None
+    if not args.no_probe:
+        n, pms, pfl = ops.GemmProbe.summary()
+        if n:
+            ach = pfl / (pms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<true,true> (forward GEMMs, v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(1000.0 * pms / n, 2),
+                    "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
+
+    if rank == 0:
+        res = {"metric": "predictor train frames/sec", "value": round(frames / (ms * 1e-3), 2), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{name} predictor-only train step (features in HBM), {B} clips/GPU, To={To}, "
+                                      f"Tp={Tp}, dropout=drop_path=0.1, AdamW+clip",
+                          "global_batch": world * B, "frames_per_clip": To + Tp, "parallelism": f"dp{world}",
+                          "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg_file, To, Tp)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

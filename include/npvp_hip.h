@@ -1,0 +1,130 @@
+/* libnpvp_hip.so - C ABI of the MI355X (gfx950) kernels behind NPVP's Stage-2 predictor
+ * hot path.  The reference has NO native boundary for this path: it is pure Python that
+ * reaches ATen through torch.nn modules ("zero CUDA kernels, zero C++").  The
+ * entry points below are what a reference-side binding replaces those torch calls with;
+ * each one names the reference call sites whose arithmetic it takes over.  INTEGRATION.md
+ * shows the ctypes stub a maintainer adds to ref/models/VidHRFormer.py.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers + sizes, fp32, row-major, no torch types; every pointer is DEVICE memory
+ *     owned and allocated by the caller (including workspaces and saved-for-backward tensors);
+ *   - the library never allocates, frees, synchronises or keeps global mutable state; all work
+ *     is enqueued on `stream` (a hipStream_t), so calls are graph-capturable and re-entrant;
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 workspace);
+ *     npvp_last_error() gives the thread-local message; nothing throws;
+ *   - canonical activation layout: x[F][P][C], F = N*T frames (f = n*T + t), P = H*W, C contiguous;
+ *   - dropout / drop-path masks are a counter hash of (*seed, salt, element key): `seed` is a
+ *     device uint64 (so a captured graph sees a new value per replay), `salt` identifies the call
+ *     site; backward entry points replay the forward mask from the same (seed, salt).
+ */
+#ifndef NPVP_HIP_H
+#define NPVP_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* npvp_stream_t; /* hipStream_t */
+
+int npvp_version(void);
+const char* npvp_last_error(void);
+
+/* ---- GEMM (every nn.Linear / 1x1 Conv2d / MHA in- and out-projection and their backward:
+ * ref/models/VidHRFormer.py:71-72,111,184-185,225 (token FFN), :345,364,380,387 (MlpDWBN fc1/fc2),
+ * torch.nn.MultiheadAttention in_proj/out_proj at :70,180,192,270; NRMLP linears
+ * ref/models/submodules.py:275,288,295).
+ *   C[M,N] = epilogue(alpha * op(A)[M,K] op(B)[K,N])
+ *   a_kc=1: A is [M][K]; a_kc=0: A is [K][M].   b_kc=1: B is [N][K]; b_kc=0: B is [K][N].
+ *   epilogue order: +bias[N] -> aux_out (pre-activation copy) -> act -> dropout -> +residual
+ *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 multiply by GELU'(aux_in), 4 multiply by [aux_in > 0]
+ *   drop_mode 0: per element; 1: per row group key=(row/drop_g1)%drop_g2 (DropPath)
+ * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
+ * When the tile count is small and K large (weight gradients) the reduction is split over
+ * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
+long long npvp_gemm_workspace_bytes(int M, int N, int K);
+int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B, long long ldb,
+                  float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
+                  const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
+                  const unsigned long long* seed, unsigned int salt, float alpha, void* workspace, long long ws_bytes,
+                  npvp_stream_t stream);
+
+/* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
+ * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.
+ * mean/rstd [rows] are saved for backward (nullable in fwd). */
+int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, long long rows,
+                       int C, float eps, int relu, npvp_stream_t stream);
+long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C);
+int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
+                       const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
+                       void* workspace, long long ws_bytes, npvp_stream_t stream);
+
+/* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
+ * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL
+ * (the `+ query_evt` of ref/models/VidHRFormer.py:211,236), beta/gamma [T][per_frame] (gamma NULL for
+ * fuse_method 'Add').  mean/rstd [N*T] are outputs.  bwd: du = d(x+add); dyxh (nullable) = dy*uhat. */
+int npvp_frame_stats(const float* x, const float* add, float* mean, float* rstd, int frames, int T, int per_frame,
+                     float eps, npvp_stream_t stream);
+int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y, float* mean,
+                     float* rstd, int N, int T, int per_frame, float eps, npvp_stream_t stream);
+int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
+                     const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
+                     long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
+
+/* ---- MlpDWBN inner stages (ref/models/VidHRFormer.py:374-392) on the channels-last hidden tensor
+ * h [frames][per_frame = H*W*Ch]:  out = res + droppath_n( drop( GELU( LayerNorm((Ch,H,W))(h) ) ) )
+ * with the per-element affine w,b given channels-last [H*W][Ch]; mean/rstd from npvp_frame_stats. */
+int npvp_frameln_act_fwd(const float* h, const float* mean, const float* rstd, const float* w, const float* b,
+                         const float* res, float* out, int frames, int per_frame, float drop_p, unsigned int salt,
+                         float dp_p, unsigned int dp_salt, int frames_per_sample, const unsigned long long* seed,
+                         npvp_stream_t stream);
+long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame);
+int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                         const float* b, float* dh, float* dw, float* db, int frames, int per_frame, float drop_p,
+                         unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
+                         const unsigned long long* seed, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* depthwise 3x3, zero pad 1 (ref/models/VidHRFormer.py:351-358); wt is tap-major [9][Ch]; flip=1 gives the
+ * input gradient.  wgrad writes one contiguous [10][Ch] buffer: 9 taps then the bias gradient. */
+int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W, int Ch,
+                   int flip, npvp_stream_t stream);
+long long npvp_dwconv3x3_wgrad_workspace_bytes(int frames, int Ch);
+int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dwt_db, int frames, int H, int W, int Ch,
+                         void* workspace, long long ws_bytes, npvp_stream_t stream);
+
+/* ---- attention cores (the bmm/softmax/dropout/bmm inside torch.nn.MultiheadAttention as called at
+ * ref/models/VidHRFormer.py:104-107 (encoder temporal, masked), :221 (decoder temporal), :239 (enc-dec),
+ * :298-300 (spatial window; window gather = ref :447-475 as index math)).
+ *   mode 0 spatial: dim0 = N*T frames, groups = frames x windows, L = S = ws*ws
+ *   mode 1 temporal: dim0 = N, groups = N x P pixels, L = Tq, S = Tk (rows (n*T + t)*P + p)
+ *   mask_mode 1 = encoder quirk ref :100-102.  q NOT pre-scaled; head_dim must be 64; L,S <= 32. */
+int npvp_attn_fwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v, float* o,
+                  long long ld_o, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads, int head_dim,
+                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+int npvp_attn_bwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v,
+                  const float* go, long long ld_o, float* dq, long long ld_dq, float* dk, long long ld_dk, float* dv,
+                  long long ld_dv, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads, int head_dim,
+                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+
+/* ---- layout / reductions / masks */
+int npvp_drop_apply(const float* x, float* out, long long rows, int ncols, float p, int mode, int g1, int g2,
+                    const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+int npvp_transpose(const float* in, float* out, int batch, int R, int C, npvp_stream_t stream); /* [B][R][C]->[B][C][R] */
+int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
+int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
+
+/* out[n] = sum_r x[r][n]: bias gradients of every Linear / Conv2d on the path */
+long long npvp_colsum_workspace_bytes(long long rows, int N);
+int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, void* workspace, long long ws_bytes,
+                npvp_stream_t stream);
+
+/* ---- optimiser step of training_step_no_gan (ref/models/Predictor.py:135-136,197): clip_grad_norm_
+ * over a flat gradient range, then torch.optim.AdamW semantics on flat buffers.  hyper = {lr, step}
+ * and clip = {norm, coef} live in device memory. */
+int npvp_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, void* workspace, long long ws_bytes,
+                        npvp_stream_t stream);
+int npvp_adamw_step(float* p, float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
+                    float eps, float weight_decay, const float* clip, long long clip_begin, long long clip_end,
+                    int write_back_grad, npvp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,17 @@
+"""npvp_amd - MI355X-native (gfx950) implementation of NPVP's Stage-2 predictor hot path.
+
+`from npvp_amd import Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, ...` mirrors
+`from models import ...` of the reference.  All arithmetic on the path runs in the hand-written HIP
+kernels of libnpvp_hip.so (npvp_amd/csrc, C ABI in include/npvp_hip.h); importing the package works
+anywhere, but calling an op without the built library or without a GPU raises - there is no fallback.
+"""
+from .models import (Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, VidHRFormerBlockEnc, VidHRFormerBlockDecNAR,
+                     SpatialLocalMultiheadAttention, MlpDWBN, MultiheadAttention, CoorGenerator, NRMLP, PosFeatFuser,
+                     EventEncoder, L1Loss, Div_KL, DropPath)
+from .trainer import FlatAdamW, predictor_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg
+from . import ops
+
+__all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
+           "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
+           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "FlatAdamW", "predictor_train_step",
+           "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops"]

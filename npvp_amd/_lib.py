@@ -1,0 +1,69 @@
+"""ctypes binding of libnpvp_hip.so (include/npvp_hip.h).  There is NO fallback: if the
+shared object is missing or a call fails, a RuntimeError is raised - the product path never
+computes on the CPU or through torch ops in place of a HIP kernel."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnpvp_hip.so")
+
+c_int, c_ll, c_f, c_u, c_p = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint, ctypes.c_void_p
+
+# name -> (restype, argtypes)  - mirrors include/npvp_hip.h one to one
+SIGNATURES = {
+    "npvp_version": (c_int, []),
+    "npvp_last_error": (ctypes.c_char_p, []),
+    "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
+    "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
+                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_p, c_ll, c_p]),
+    "npvp_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_f, c_int, c_p]),
+    "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),
+    "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_frame_stats": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
+    "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
+    "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p]),
+    "npvp_frameln_act_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
+    "npvp_frameln_act_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
+                                     c_p, c_p, c_ll, c_p]),
+    "npvp_dwconv3x3": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "npvp_dwconv3x3_wgrad_workspace_bytes": (c_ll, [c_int, c_int]),
+    "npvp_dwconv3x3_wgrad": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_attn_fwd": (c_int, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_int, c_f, c_p, c_u, c_p]),
+    "npvp_attn_bwd": (c_int, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_int, c_int,
+                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f, c_p, c_u, c_p]),
+    "npvp_drop_apply": (c_int, [c_p, c_p, c_ll, c_int, c_f, c_int, c_int, c_int, c_p, c_u, c_p]),
+    "npvp_transpose": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
+    "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
+    "npvp_broadcast_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
+    "npvp_colsum_workspace_bytes": (c_ll, [c_ll, c_int]),
+    "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_p, c_ll, c_p]),
+    "npvp_grad_norm_clip": (c_int, [c_p, c_ll, c_f, c_p, c_p, c_ll, c_p]),
+    "npvp_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_ll, c_p, c_f, c_f, c_f, c_f, c_p, c_ll, c_ll, c_int, c_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing - the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `python npvp_amd/build.py`). "
+                "npvp_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().npvp_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

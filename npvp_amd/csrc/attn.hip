@@ -1,0 +1,377 @@
+// Attention cores of the predictor: softmax(q k^T / sqrt(d) + mask) v
+// per (group, head), fwd and bwd, over the canonical (B*T, H*W, C) layout with the
+// reference's permutes turned into index math:
+//   mode 0  spatial local window (ref/models/VidHRFormer.py:274-307,447-475): group = (frame, window),
+//           members = the ws*ws tokens of the window.
+//   mode 1  temporal / encoder-decoder (ref/models/VidHRFormer.py:94-107,217-221,229-239): group =
+//           (sample, pixel), members = the T time-steps (stride H*W*ld between them); Tq != Tk for
+//           the enc-dec case; mask_mode 1 = the encoder's "no query but the last sees the last
+//           time-step" mask (:100-102).
+// q/k/v/o carry their own row stride so that the q and k projections can live in one
+// [rows, 2C] buffer.  Sequence lengths are <= 32 and d = 64, so the core is LDS/latency bound,
+// not MFMA work: one wavefront per (group, head), q/k/v tiles staged in LDS with coalesced
+// 256-B row segments, softmax in registers, attention dropout replayed in backward from a
+// counter hash.  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
+#include "common.h"
+
+namespace npvp {
+
+constexpr int HD = 64;      // head dim
+constexpr int LDT = 68;     // LDS row stride of a [rows][64] tile (16-B aligned, bank-skewed)
+constexpr int LDP = 33;     // LDS row stride of the [L][S] probability tile
+
+struct AttnParams {
+  const float* q; const float* k; const float* v; const float* go;   // go = dO (bwd only)
+  float* o;                                                          // fwd out
+  float* dq; float* dk; float* dv;                                   // bwd out
+  long long ld_q, ld_k, ld_v, ld_o;                                  // row strides (floats); d* use the same
+  long long ld_dq, ld_dk, ld_dv;
+  int mode, heads, L, S;
+  int P, W, ws, nww, nwin;        // mode 0 geometry (P = H*W)
+  int Tq, Tk;                     // mode 1
+  int mask_mode;
+  float scale;
+  unsigned int drop_thresh; float drop_inv_keep; unsigned int salt;
+  const unsigned long long* seed;
+  long long total;                // groups * heads
+  int wpb, per_wave_floats;
+};
+
+__device__ __forceinline__ long long attn_row(const AttnParams& p, long long g, int m, int Tn) {
+  if (p.mode == 0) {
+    const long long f = g / p.nwin;
+    const int win = (int)(g - f * p.nwin);
+    const int qh = win / p.nww, qw = win - qh * p.nww;
+    const int ph = m / p.ws, pw = m - ph * p.ws;
+    return f * p.P + (long long)(qh * p.ws + ph) * p.W + qw * p.ws + pw;
+  }
+  const long long n = g / p.P;
+  const int px = (int)(g - n * p.P);
+  return (n * Tn + m) * p.P + px;
+}
+
+__device__ __forceinline__ void load_tile(float* dst, const float* src, long long ld, const AttnParams& p, long long g,
+                                          int nrows, int Tn, int head, int lane) {
+  for (int idx = lane; idx < nrows * 16; idx += 64) {
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    st4(dst + r * LDT + c4, ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + c4));
+  }
+}
+__device__ __forceinline__ void store_tile(const float* src, float* dst, long long ld, const AttnParams& p, long long g,
+                                           int nrows, int Tn, int head, int lane) {
+  for (int idx = lane; idx < nrows * 16; idx += 64) {
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + c4, ld4(src + r * LDT + c4));
+  }
+}
+
+__device__ __forceinline__ float dot64(const float4* a, const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const float4 t = ld4(b + c4 * 4);
+    s += a[c4].x * t.x + a[c4].y * t.y + a[c4].z * t.z + a[c4].w * t.w;
+  }
+  return s;
+}
+
+template <int PARTS>
+__device__ __forceinline__ float parts_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  if (PARTS == 4) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+template <int PARTS>
+__device__ __forceinline__ float parts_sum(float v) {
+  v += __shfl_xor(v, 32, 64);
+  if (PARTS == 4) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+// PARTS = 4: rows on lanes 0..15 (L,S <= 16), 4 lanes share a row; PARTS = 2: rows on lanes 0..31.
+template <int PARTS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LP = 64 / PARTS, CW = 64 / PARTS, JPL = 32 / PARTS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long wid = (long long)blockIdx.x * p.wpb + wave;
+  const bool active = wid < p.total;
+  if (!active) wid = p.total - 1;          // keep every wave in step for the barriers; stores are skipped
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  float* Qs = smem + (long long)wave * p.per_wave_floats;
+  float* Ks = Qs + L * LDT;
+  float* Vs = Ks + S * LDT;
+  float* Ps = Vs + S * LDT;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+
+  load_tile(Qs, p.q, p.ld_q, p, g, L, Tq, head, lane);
+  load_tile(Ks, p.k, p.ld_k, p, g, S, Tk, head, lane);
+  load_tile(Vs, p.v, p.ld_v, p, g, S, Tk, head, lane);
+  __syncthreads();
+
+  const int i = lane % LP, part = lane / LP;
+  const int ic = i < L ? i : L - 1;
+  float4 qv[16];
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) qv[c4] = ld4(Qs + ic * LDT + c4 * 4);
+
+  float sc[JPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    const int j = part + jj * PARTS;
+    float s = -INFINITY;
+    if (j < S) {
+      s = dot64(qv, Ks + j * LDT) * p.scale;
+      if (p.mask_mode == 1 && j == S - 1 && ic < L - 1) s = -INFINITY;
+    }
+    sc[jj] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = parts_max<PARTS>(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    sc[jj] = (sc[jj] == -INFINITY) ? 0.f : __expf(sc[jj] - mx);
+    sum += sc[jj];
+  }
+  sum = parts_sum<PARTS>(sum);
+  const float inv = 1.f / sum;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    const int j = part + jj * PARTS;
+    if (j < S && i < L) {
+      float pr = sc[jj] * inv;
+      if (p.drop_thresh)
+        pr *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + i) * S + j, p.drop_thresh, p.drop_inv_keep);
+      Ps[i * LDP + j] = pr;
+    }
+  }
+  __syncthreads();
+
+  float4 acc[CW / 4];
+#pragma unroll
+  for (int c4 = 0; c4 < CW / 4; ++c4) acc[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < S; ++j) {
+    const float pj = Ps[ic * LDP + j];
+    const float* vr = Vs + j * LDT + part * CW;
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) {
+      const float4 t = ld4(vr + c4 * 4);
+      acc[c4].x += pj * t.x; acc[c4].y += pj * t.y; acc[c4].z += pj * t.z; acc[c4].w += pj * t.w;
+    }
+  }
+  // stage O in the Q tile (every lane has its q row in registers since the first barrier)
+  if (i < L) {
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) st4(Qs + i * LDT + part * CW + c4 * 4, acc[c4]);
+  }
+  __syncthreads();
+  if (active) store_tile(Qs, p.o, p.ld_o, p, g, L, Tq, head, lane);
+}
+
+template <int PARTS>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LP = 64 / PARTS, CW = 64 / PARTS, JPL = 32 / PARTS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long wid = (long long)blockIdx.x * p.wpb + wave;
+  const bool active = wid < p.total;
+  if (!active) wid = p.total - 1;
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  float* Qs = smem + (long long)wave * p.per_wave_floats;
+  float* Ks = Qs + L * LDT;
+  float* Vs = Ks + S * LDT;
+  float* Gs = Vs + S * LDT;          // dO
+  float* Ps = Gs + L * LDT;          // dropped probabilities (what multiplied V in forward)
+  float* Ds = Ps + L * LDP;          // dS * scale
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+
+  load_tile(Qs, p.q, p.ld_q, p, g, L, Tq, head, lane);
+  load_tile(Ks, p.k, p.ld_k, p, g, S, Tk, head, lane);
+  load_tile(Vs, p.v, p.ld_v, p, g, S, Tk, head, lane);
+  load_tile(Gs, p.go, p.ld_o, p, g, L, Tq, head, lane);
+  __syncthreads();
+
+  const int i = lane % LP, part = lane / LP;
+  const int ic = i < L ? i : L - 1;
+  float sc[JPL], dp[JPL];
+  {
+    float4 qv[16], gv[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) { qv[c4] = ld4(Qs + ic * LDT + c4 * 4); gv[c4] = ld4(Gs + ic * LDT + c4 * 4); }
+#pragma unroll
+    for (int jj = 0; jj < JPL; ++jj) {
+      const int j = part + jj * PARTS;
+      float s = -INFINITY, d = 0.f;
+      if (j < S) {
+        s = dot64(qv, Ks + j * LDT) * p.scale;
+        if (p.mask_mode == 1 && j == S - 1 && ic < L - 1) s = -INFINITY;
+        d = dot64(gv, Vs + j * LDT);
+      }
+      sc[jj] = s; dp[jj] = d;
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) mx = fmaxf(mx, sc[jj]);
+  mx = parts_max<PARTS>(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    sc[jj] = (sc[jj] == -INFINITY) ? 0.f : __expf(sc[jj] - mx);
+    sum += sc[jj];
+  }
+  sum = parts_sum<PARTS>(sum);
+  const float inv = 1.f / sum;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  float rs = 0.f;            // sum_j dP_ij * p_ij
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    const int j = part + jj * PARTS;
+    const float pr = sc[jj] * inv;
+    float m = 1.f;
+    if (p.drop_thresh && j < S)
+      m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + ic) * S + j, p.drop_thresh, p.drop_inv_keep);
+    dp[jj] *= m;             // dP = dP_dropped * mask_scale
+    sc[jj] = pr;
+    rs += dp[jj] * pr;
+    if (j < S && i < L) Ps[i * LDP + j] = pr * m;
+  }
+  rs = parts_sum<PARTS>(rs);
+#pragma unroll
+  for (int jj = 0; jj < JPL; ++jj) {
+    const int j = part + jj * PARTS;
+    if (j < S && i < L) Ds[i * LDP + j] = sc[jj] * (dp[jj] - rs) * p.scale;
+  }
+  __syncthreads();
+
+  float4 aq[CW / 4], ak[CW / 4], av[CW / 4];
+#pragma unroll
+  for (int c4 = 0; c4 < CW / 4; ++c4) {
+    aq[c4] = make_float4(0.f, 0.f, 0.f, 0.f); ak[c4] = aq[c4]; av[c4] = aq[c4];
+  }
+  // dQ[i] = sum_j dS[i][j] K[j]
+  for (int j = 0; j < S; ++j) {
+    const float d = Ds[ic * LDP + j];
+    const float* kr = Ks + j * LDT + part * CW;
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) {
+      const float4 t = ld4(kr + c4 * 4);
+      aq[c4].x += d * t.x; aq[c4].y += d * t.y; aq[c4].z += d * t.z; aq[c4].w += d * t.w;
+    }
+  }
+  // dK[j] = sum_i dS[i][j] Q[i];  dV[j] = sum_i Pd[i][j] dO[i]   (this lane's row index is a key index here)
+  const int jc = i < S ? i : S - 1;
+  for (int ii = 0; ii < L; ++ii) {
+    const float d = Ds[ii * LDP + jc], pd = Ps[ii * LDP + jc];
+    const float* qr = Qs + ii * LDT + part * CW;
+    const float* gr = Gs + ii * LDT + part * CW;
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) {
+      const float4 t = ld4(qr + c4 * 4), u = ld4(gr + c4 * 4);
+      ak[c4].x += d * t.x; ak[c4].y += d * t.y; ak[c4].z += d * t.z; ak[c4].w += d * t.w;
+      av[c4].x += pd * u.x; av[c4].y += pd * u.y; av[c4].z += pd * u.z; av[c4].w += pd * u.w;
+    }
+  }
+  __syncthreads();           // all reads of Qs/Ks/Vs/Gs are done: reuse them as output staging
+  if (i < L) {
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) st4(Qs + i * LDT + part * CW + c4 * 4, aq[c4]);
+  }
+  if (i < S) {
+#pragma unroll
+    for (int c4 = 0; c4 < CW / 4; ++c4) {
+      st4(Ks + i * LDT + part * CW + c4 * 4, ak[c4]);
+      st4(Vs + i * LDT + part * CW + c4 * 4, av[c4]);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    store_tile(Qs, p.dq, p.ld_dq, p, g, L, Tq, head, lane);
+    store_tile(Ks, p.dk, p.ld_dk, p, g, S, Tk, head, lane);
+    store_tile(Vs, p.dv, p.ld_dv, p, g, S, Tk, head, lane);
+  }
+}
+
+static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
+                      int Tk, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, bool bwd) {
+  if (head_dim != HD) { npvp_set_error("attn: head_dim must be 64"); return NPVP_ERR_ARG; }
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !seed)) { npvp_set_error("attn: bad dropout arguments"); return NPVP_ERR_ARG; }
+  p.mode = mode; p.heads = heads; p.P = P; p.W = W; p.ws = ws; p.Tq = Tq; p.Tk = Tk; p.mask_mode = mask_mode;
+  long long groups;
+  if (mode == 0) {
+    if (ws <= 0 || W % ws != 0 || P % W != 0 || (P / W) % ws != 0) { npvp_set_error("attn: window must tile the grid"); return NPVP_ERR_ARG; }
+    p.nww = W / ws; p.nwin = p.nww * ((P / W) / ws); p.L = p.S = ws * ws;
+    groups = (long long)frames_or_N * p.nwin;
+  } else {
+    p.nww = p.nwin = 1; p.L = Tq; p.S = Tk;
+    groups = (long long)frames_or_N * P;
+  }
+  if (p.L < 1 || p.S < 1 || p.L > 32 || p.S > 32) { npvp_set_error("attn: sequence length must be in [1,32]"); return NPVP_ERR_ARG; }
+  p.scale = 0.125f;   // 1/sqrt(64)
+  p.drop_thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  p.salt = salt; p.seed = seed;
+  p.total = groups * heads;
+  int pw = (p.L + 2 * p.S) * LDT + p.L * LDP;
+  if (bwd) pw += p.L * LDT + p.L * LDP;
+  pw = (pw + 3) & ~3;
+  p.per_wave_floats = pw;
+  int wpb = (64 * 1024) / (pw * 4);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) { npvp_set_error("attn: LDS budget exceeded"); return NPVP_ERR_ARG; }
+  p.wpb = wpb;
+  return NPVP_OK;
+}
+
+}  // namespace npvp
+
+using namespace npvp;
+
+// mode 0: dim0 = frames (N*T); mode 1: dim0 = N.  See include/npvp_hip.h.
+extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v,
+                             float* o, long long ld_o, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads,
+                             int head_dim, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt,
+                             hipStream_t stream) {
+  AttnParams p = {};
+  const int rc = attn_setup(p, mode, heads, head_dim, dim0, P, W, ws, Tq, Tk, mask_mode, drop_p, seed, salt, false);
+  if (rc) return rc;
+  NPVP_CHECK_ARG(dim0 > 0, "attn: empty batch");
+  NPVP_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0, "attn: row strides must be multiples of 4");
+  p.q = q; p.k = k; p.v = v; p.o = o; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o;
+  const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
+  const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
+  const int L = p.L > p.S ? p.L : p.S;
+  if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v,
+                             const float* go, long long ld_o, float* dq, long long ld_dq, float* dk, long long ld_dk,
+                             float* dv, long long ld_dv, int mode, int dim0, int P, int W, int ws, int Tq, int Tk,
+                             int heads, int head_dim, int mask_mode, float drop_p, const unsigned long long* seed,
+                             unsigned int salt, hipStream_t stream) {
+  AttnParams p = {};
+  const int rc = attn_setup(p, mode, heads, head_dim, dim0, P, W, ws, Tq, Tk, mask_mode, drop_p, seed, salt, true);
+  if (rc) return rc;
+  NPVP_CHECK_ARG(dim0 > 0, "attn_bwd: empty batch");
+  NPVP_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0 && ld_dq % 4 == 0 && ld_dk % 4 == 0 &&
+                     ld_dv % 4 == 0, "attn_bwd: row strides must be multiples of 4");
+  p.q = q; p.k = k; p.v = v; p.go = go; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o; p.ld_dq = ld_dq; p.ld_dk = ld_dk; p.ld_dv = ld_dv;
+  const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
+  const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
+  const int L = p.L > p.S ? p.L : p.S;
+  if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}

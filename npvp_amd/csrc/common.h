@@ -1,0 +1,125 @@
+// Shared device helpers for the NPVP gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NPVP_OK 0
+#define NPVP_ERR_ARG (-1)
+#define NPVP_ERR_LAUNCH (-2)
+#define NPVP_ERR_WORKSPACE (-3)
+
+// host side: record the last error string (thread local), see api.hip
+extern "C" void npvp_set_error(const char* msg);
+
+#define NPVP_CHECK_ARG(cond, msg)                    \
+  do {                                               \
+    if (!(cond)) {                                   \
+      npvp_set_error(msg);                           \
+      return NPVP_ERR_ARG;                           \
+    }                                                \
+  } while (0)
+
+#define NPVP_CHECK_LAUNCH()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) {                         \
+      npvp_set_error(hipGetErrorString(e__));        \
+      return NPVP_ERR_LAUNCH;                        \
+    }                                                \
+  } while (0)
+
+namespace npvp {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x = NW*64 threads; `red` is NW floats of LDS.
+// Every thread gets the total.  Contains two barriers.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();                      // protect `red` from a previous use
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+// exact-erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based RNG for dropout masks: stateless, so backward replays the mask of
+// forward from (seed, salt, element index).  `seed` lives in device memory so that
+// a captured HIP graph sees a fresh value on every replay.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu;
+  h ^= h >> 13; h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t salt, uint64_t idx) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  uint32_t h = mix32(lo ^ s0);
+  h = mix32(h + 0x9e3779b9u * (salt + 1u) + hi);
+  h = mix32(h ^ s1 ^ (salt * 0x7f4a7c15u));
+  return h;
+}
+// keep-scale for inverted dropout: 1/(1-p) if kept, 0 if dropped
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t salt, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return rng_u32(seed, salt, idx) >= thresh ? inv_keep : 0.f;
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  // P(u32 < thresh) = p
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// Where a dropout / drop-path mask is keyed.
+//   mode 0: per element          key = row * ncols + col       (nn.Dropout)
+//   mode 1: per row group        key = (row / g1) % g2         (DropPath, ref/models/VidHRFormer.py:513-525:
+//           per sample g1 = T*P, g2 = N; the enc-dec site drops whole time-steps (:239): g1 = P, g2 = T)
+struct DropSpec {
+  unsigned int thresh; float inv_keep; unsigned int salt; int mode; int g1; int g2;
+};
+__device__ __forceinline__ float drop_spec_scale(const DropSpec& d, uint64_t seed, long long row, int col, int ncols) {
+  const uint64_t key = d.mode == 0 ? (uint64_t)row * (uint64_t)ncols + (uint64_t)col : (uint64_t)((row / d.g1) % d.g2);
+  return rng_u32(seed, d.salt, key) >= d.thresh ? d.inv_keep : 0.f;
+}
+inline DropSpec make_drop_spec(float p, unsigned int salt, int mode, int g1, int g2) {
+  DropSpec d;
+  d.thresh = p > 0.f ? drop_threshold(p) : 0u;
+  d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  d.salt = salt; d.mode = mode; d.g1 = g1 > 0 ? g1 : 1; d.g2 = g2 > 0 ? g2 : 1;
+  return d;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// out[c] = sum_b in[b*stride + c], c < ncols (defined in norm.hip)
+int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream);
+
+}  // namespace npvp

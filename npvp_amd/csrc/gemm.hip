@@ -1,0 +1,267 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered
+// fma chain) with fused bias / GELU / ReLU / dropout / residual / activation-gradient
+// epilogues.  This is the kernel that carries >99 % of the predictor's FLOPs
+// (SURVEY 2b K3-K7): every nn.Linear, 1x1 conv and attention in/out projection of
+// ref/models/VidHRFormer.py:71-72,184-185,270,345,364 and their backward passes.
+//
+//   C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
+//
+// Operand storage (no transposes are ever materialised):
+//   a_kc = 1 : A stored [M][K] (k contiguous)     a_kc = 0 : A stored [K][M]
+//   b_kc = 1 : B stored [N][K] (k contiguous)     b_kc = 0 : B stored [K][N]
+//   forward  y = x W^T          : a_kc=1, b_kc=1
+//   dgrad    dx = dy W          : a_kc=1, b_kc=0
+//   wgrad    dW = dy^T x        : a_kc=0, b_kc=0   (K = token rows, split-K)
+//
+// Tiling: 128x128x32 block, 256 threads = 4 waves (2x2), each wave a 64x64 tile as
+// 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  Operands are staged global -> VGPR
+// (float4, prefetched one K-step ahead) -> LDS in K-major [k][row] layout so each
+// MFMA operand is ONE conflict-free ds_read_b32 per lane (lane l reads row l&31 of
+// k-row l>>5).  LDS is double buffered: one barrier per K-step.  blockIdx is remapped
+// so that the 8 XCDs each walk a contiguous run of tiles (B = the weight stays in the
+// XCD's L2; each A row-panel is fetched by one XCD).
+#include "common.h"
+
+namespace npvp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, GEMM_THREADS = 256;
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  const float* bias;       // [N] or null
+  const float* residual;   // [M][ldr] or null (added last)
+  float* aux_out;          // [M][ldc] pre-activation copy (after bias) or null
+  const float* aux_in;     // [M][ldc] for act 3/4 (activation gradients)
+  const unsigned long long* seed;  // device seed for dropout or null
+  long long lda, ldb, ldc, ldr;
+  int M, N, K;             // K = this launch's reduction length per split
+  int act;                 // 0 none 1 gelu 2 relu 3 *gelu'(aux_in) 4 *relu'(aux_in)
+  DropSpec drop;
+  int tiles_m, tiles_n;
+  int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
+  float alpha;
+};
+
+// ---- operand staging: one 128 x 32 (rows x k) tile -----------------------------------
+template <bool KC> struct Stager;
+
+template <> struct Stager<true> {   // source [rows][K], k contiguous
+  static constexpr int LD = 129;
+  float4 r[4];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
+    const int t = threadIdx.x;
+    const int kc = (t & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + (t >> 3) + 32 * i;
+      r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+    const int t = threadIdx.x;
+    const int kc = (t & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 3) + 32 * i;
+      s[(kc + 0) * LD + row] = r[i].x;
+      s[(kc + 1) * LD + row] = r[i].y;
+      s[(kc + 2) * LD + row] = r[i].z;
+      s[(kc + 3) * LD + row] = r[i].w;
+    }
+  }
+};
+
+template <> struct Stager<false> {  // source [K][rows], rows contiguous
+  static constexpr int LD = 132;
+  float4 r[4];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
+    const int t = threadIdx.x;
+    const int rc = (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = (t >> 5) + 8 * i;
+      r[i] = (row0 + rc < nrows) ? ld4(src + (long long)(k0 + k) * ld + row0 + rc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+    const int t = threadIdx.x;
+    const int rc = (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = (t >> 5) + 8 * i;
+      st4(s + k * LD + rc, r[i]);
+    }
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p) {
+  constexpr int LDA = Stager<AKC>::LD, LDB = Stager<BKC>::LD;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  // XCD-aware, bijective tile remap (cdna guide T1)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = nid / p.tiles_n, tile_n = nid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.y;
+
+  // split-K: this block reduces k in [z*K, (z+1)*K)
+  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
+  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+  Stager<AKC> sa; Stager<BKC> sb;
+  const int nk = p.K / BK;
+  sa.load(A, p.lda, m0, p.M, 0);
+  sb.load(B, p.ldb, n0, p.N, 0);
+  sa.store(As[0]); sb.store(Bs[0]);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK);
+      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK);
+    }
+    const float* as = As[cur] + h * LDA + wm * 64 + r;
+    const float* bs = Bs[cur] + h * LDB + wn * 64 + r;
+    // operands of k-pair kk+2 are read from LDS before the four MFMAs of k-pair kk issue,
+    // so the ~64-cycle ds_read latency hides under 256 cycles of matrix work
+    float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 2 < BK) {
+        na0 = as[(kk + 2) * LDA]; na1 = as[(kk + 2) * LDA + 32];
+        nb0 = bs[(kk + 2) * LDB]; nb1 = bs[(kk + 2) * LDB + 32];
+      }
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    if (kt + 1 < nk) { sa.store(As[cur ^ 1]); sb.store(Bs[cur ^ 1]); }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+  const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
+  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
+      const int col = n0 + wn * 64 + tn * 32 + r;
+      if (col >= p.N) continue;
+      const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        const long long idx = (long long)row * p.ldc + col;
+        float v = acc[g];
+        if (p.splits > 1) { Cz[idx] = v; continue; }
+        v = v * p.alpha + bv;
+        if (p.aux_out) p.aux_out[idx] = v;
+        if (p.act == 1) v = gelu_f(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
+        else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
+        if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
+        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+        Cz[idx] = v;
+      }
+    }
+  }
+}
+
+// sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
+                                     long long ldc, int splits, float alpha) {
+  const long long total4 = (long long)M * N / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int zz = 0; zz < splits; ++zz) {
+      const float4 v = ld4(ws + (long long)zz * M * N + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+    st4(out + (long long)m * ldc + n, s);
+  }
+}
+
+static int pick_splits(int M, int N, int K) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles >= 256 || K < 2048) return 1;
+  int s = (1024 + tiles - 1) / tiles;          // aim for ~4 blocks per CU
+  const int maxs = K / (BK * 8);               // at least 8 K-steps per split
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  while (s > 1 && (K % (s * BK)) != 0) --s;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace npvp
+
+using namespace npvp;
+
+extern "C" long long npvp_gemm_workspace_bytes(int M, int N, int K) {
+  const int s = pick_splits(M, N, K);
+  return s > 1 ? (long long)s * M * N * 4 : 0;
+}
+
+// See include/npvp_hip.h for the contract.
+extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B,
+                             long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
+                             float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
+                             int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
+                             void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+  NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
+  NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
+  NPVP_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
+  NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm: A/B must be 16-byte aligned");
+  NPVP_CHECK_ARG(!(a_kc == 0 && b_kc == 1), "gemm: (a_kc=0,b_kc=1) is not used by the path");
+  NPVP_CHECK_ARG((act != 3 && act != 4) || aux_in, "gemm: act 3/4 need aux_in");
+  NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p out of range");
+  NPVP_CHECK_ARG(drop_p == 0.f || seed, "gemm: dropout needs a device seed");
+
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux_out = aux_out; p.aux_in = aux_in;
+  p.seed = seed; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
+  p.drop = make_drop_spec(drop_p, salt, drop_mode, drop_g1, drop_g2);
+  p.alpha = alpha;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  int splits = pick_splits(M, N, K);
+  const bool plain = !bias && act == 0 && !aux_out && !residual && drop_p == 0.f;
+  if (splits > 1 && (!plain || ws_bytes < (long long)splits * M * N * 4 || !workspace || (N % 4) != 0)) splits = 1;
+  p.splits = splits;
+  if (splits > 1) { p.K = K / splits; p.C = (float*)workspace; p.ldc = N; }
+
+  dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+  NPVP_CHECK_LAUNCH();
+  if (splits > 1) {
+    const long long total4 = (long long)M * N / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
+                       splits, alpha);
+    NPVP_CHECK_LAUNCH();
+  }
+  return NPVP_OK;
+}

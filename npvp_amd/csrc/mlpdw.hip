@@ -1,0 +1,111 @@
+// Depthwise 3x3 convolution of MlpDWBN (ref/models/VidHRFormer.py:351-358, nn.Conv2d(groups=Ch,
+// padding=1), cross-correlation) over the channels-last hidden tensor [F, H*W, Ch], fwd, input
+// gradient (same kernel, taps flipped) and weight/bias gradient.  HBM bound: one read + one write of
+// the hidden tensor (the 9 neighbour taps hit L1/L2).  Weights are tap-major [9][Ch] so that a lane's
+// 4 channels are one float4.
+#include "common.h"
+
+namespace npvp {
+
+__global__ void dwconv3x3_kernel(const float* __restrict__ a, const float* __restrict__ wt, const float* __restrict__ bias,
+                                 float* __restrict__ out, int H, int W, int Ch, long long total4, int flip) {
+  const int c4n = Ch / 4, P = H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long long fp = i / c4n;
+    const int p = (int)(fp % P);
+    const long long f = fp / P;
+    const int h = p / W, w = p - h * W;
+    float4 acc = bias ? ld4(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* af = a + f * P * Ch + c;
+#pragma unroll
+    for (int ky = -1; ky <= 1; ++ky) {
+      const int hh = h + ky;
+      if (hh < 0 || hh >= H) continue;
+#pragma unroll
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int ww = w + kx;
+        if (ww < 0 || ww >= W) continue;
+        const int tap = (ky + 1) * 3 + (kx + 1);
+        const float4 wv = ld4(wt + (flip ? 8 - tap : tap) * Ch + c);
+        const float4 v = ld4(af + (long long)(hh * W + ww) * Ch);
+        acc.x += wv.x * v.x; acc.y += wv.y * v.y; acc.z += wv.z * v.z; acc.w += wv.w * v.w;
+      }
+    }
+    st4(out + fp * Ch + c, acc);
+  }
+}
+
+// part[chunk][tap 0..8 | bias][Ch]:  dW[tap][c] = sum_{f,p} dout[f,p,c] * a[f, p + tap, c];  db[c] = sum dout
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dout,
+                                                              float* __restrict__ part, int H, int W, int Ch, int frames,
+                                                              int frames_per_chunk) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= Ch) return;
+  const int P = H * W;
+  float4 aw[9], ab = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) aw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int f0 = blockIdx.y * frames_per_chunk, f1 = min(frames, f0 + frames_per_chunk);
+  for (long long f = f0; f < f1; ++f) {
+    const float* af = a + f * P * Ch + c;
+    const float* df = dout + f * P * Ch + c;
+    for (int h = 0; h < H; ++h) {
+      for (int w = 0; w < W; ++w) {
+        const float4 d = ld4(df + (long long)(h * W + w) * Ch);
+        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+#pragma unroll
+        for (int ky = -1; ky <= 1; ++ky) {
+          const int hh = h + ky;
+          if (hh < 0 || hh >= H) continue;
+#pragma unroll
+          for (int kx = -1; kx <= 1; ++kx) {
+            const int ww = w + kx;
+            if (ww < 0 || ww >= W) continue;
+            const float4 v = ld4(af + (long long)(hh * W + ww) * Ch);
+            float4& t = aw[(ky + 1) * 3 + (kx + 1)];
+            t.x += d.x * v.x; t.y += d.y * v.y; t.z += d.z * v.z; t.w += d.w * v.w;
+          }
+        }
+      }
+    }
+  }
+  float* o = part + (long long)blockIdx.y * 10 * Ch;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) st4(o + t * Ch + c, aw[t]);
+  st4(o + 9 * Ch + c, ab);
+}
+
+static int dw_chunks(int frames) { return frames < 256 ? frames : 256; }
+
+}  // namespace npvp
+
+using namespace npvp;
+
+extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W,
+                              int Ch, int flip, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv: bad shape");
+  const long long total4 = (long long)frames * H * W * Ch / 4;
+  long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" long long npvp_dwconv3x3_wgrad_workspace_bytes(int frames, int Ch) {
+  return (long long)dw_chunks(frames) * 10 * Ch * 4;
+}
+
+// dwt [9][Ch], db [Ch] must be CONTIGUOUS as one [10][Ch] buffer: db = dwt + 9*Ch
+extern "C" int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dwt_db, int frames, int H, int W, int Ch,
+                                    void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv_wgrad: bad shape");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), "dwconv_wgrad: workspace too small");
+  const int chunks = dw_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 255) / 256, nchunks), dim3(256), 0, stream, a, dout,
+                     (float*)workspace, H, W, Ch, frames, fpc);
+  NPVP_CHECK_LAUNCH();
+  const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream);
+  if (rc) { npvp_set_error("dwconv_wgrad: reduce launch failed"); return rc; }
+  return NPVP_OK;
+}

@@ -1,0 +1,517 @@
+// HBM-bound normalisation kernels of the predictor:
+//   * token LayerNorm(C) fwd/bwd, one wavefront per row, registers only
+//     (ref/models/VidHRFormer.py:65-66,69,77,175-195; shared final norm :47-48,150-151, + relu_ :159)
+//   * per-frame statistics (GroupNorm(1,C) of PosFeatFuser, ref/models/submodules.py:427,446, and
+//     LayerNorm((Ch,H,W)) of MlpDWBN, ref/models/VidHRFormer.py:348,361,367)
+//   * PosFeatFuser apply  y = xhat*(1+gamma)+beta with the decoder's `+query_evt` folded in
+//     (ref/models/submodules.py:449-452, ref/models/VidHRFormer.py:211,236)
+//   * frame-LN + per-element affine + GELU + dropout (+ residual, drop-path) apply
+// and their backward passes.  Algorithmic bytes: one read + one write of the activation per
+// pass (8 B/element); statistics passes re-read a frame that is L2 resident.
+#include "common.h"
+
+namespace npvp {
+
+// ------------------------------------------------------------------ token LayerNorm
+template <int NV>   // C = NV*256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long long rows,
+                                                     float eps, int relu) {
+  constexpr int C = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = ld4(x + row * C + (i * 64 + lane) * 4);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mu = wave_sum(s) * (1.f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+    q += a * a + bb * bb + c * c + d * d;
+  }
+  const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    const float4 ww = ld4(w + c0), bb = ld4(b + c0);
+    float4 o;
+    o.x = (v[i].x - mu) * rs * ww.x + bb.x;
+    o.y = (v[i].y - mu) * rs * ww.y + bb.y;
+    o.z = (v[i].z - mu) * rs * ww.z + bb.z;
+    o.w = (v[i].w - mu) * rs * ww.w + bb.w;
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(y + row * C + c0, o);
+  }
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+}
+
+// backward: dx per row; per-block partial dw/db in `partial[blockIdx][2][C]`
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ dx, float* __restrict__ partial, long long rows,
+                                                     int relu) {
+  constexpr int C = NV * 256;
+  __shared__ float red[4][2 * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ww[NV], bb[NV], aw[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    ww[i] = ld4(w + c0);
+    bb[i] = ld4(b + c0);
+    aw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      const float4 xv = ld4(x + row * C + c0);
+      float4 d = ld4(dy + row * C + c0);
+      xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+      if (relu) {
+        if (xh[i].x * ww[i].x + bb[i].x <= 0.f) d.x = 0.f;
+        if (xh[i].y * ww[i].y + bb[i].y <= 0.f) d.y = 0.f;
+        if (xh[i].z * ww[i].z + bb[i].z <= 0.f) d.z = 0.f;
+        if (xh[i].w * ww[i].w + bb[i].w <= 0.f) d.w = 0.f;
+      }
+      aw[i].x += d.x * xh[i].x; aw[i].y += d.y * xh[i].y; aw[i].z += d.z * xh[i].z; aw[i].w += d.w * xh[i].w;
+      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      g[i].x = d.x * ww[i].x; g[i].y = d.y * ww[i].y; g[i].z = d.z * ww[i].z; g[i].w = d.w * ww[i].w;
+      s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+      s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+    }
+    s1 = wave_sum(s1) * (1.f / C);
+    s2 = wave_sum(s2) * (1.f / C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      float4 o;
+      o.x = rs * (g[i].x - s1 - xh[i].x * s2);
+      o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+      o.z = rs * (g[i].z - s1 - xh[i].z * s2);
+      o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+      st4(dx + row * C + c0, o);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    st4(&red[wave][c0], aw[i]);
+    st4(&red[wave][C + c0], ab[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    partial[(long long)blockIdx.x * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// out[c] = sum_b in[b][c]   (small second stage of the column reductions)
+__global__ void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int nb, int stride, int ncols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += in[(long long)b * stride + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------ per-frame statistics
+// One 512-thread block per frame; frame f = n*T + t; u = x[f] (+ add[n]).  Two-pass
+// (mean, then centred second moment): the frame (128 KiB .. 512 KiB) is L2 resident.
+__global__ __launch_bounds__(512) void frame_stats_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int T,
+                                                          int per_frame, float eps) {
+  __shared__ float red[8];
+  const int f = blockIdx.x;
+  const float* xp = x + (long long)f * per_frame;
+  const float* ap = add ? add + (long long)(f / T) * per_frame : nullptr;
+  float s = 0.f;
+  for (int e = threadIdx.x * 4; e < per_frame; e += 512 * 4) {
+    float4 v = ld4(xp + e);
+    if (ap) { const float4 a = ld4(ap + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mu = block_sum<8>(s, red) / per_frame;
+  float q = 0.f;
+  for (int e = threadIdx.x * 4; e < per_frame; e += 512 * 4) {
+    float4 v = ld4(xp + e);
+    if (ap) { const float4 a = ld4(ap + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu;
+    q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+  }
+  const float var = block_sum<8>(q, red) / per_frame;
+  if (threadIdx.x == 0) { mean[f] = mu; rstd[f] = rsqrtf(var + eps); }
+}
+
+// ------------------------------------------------------------------ PosFeatFuser apply
+// y[f,e] = (x[f,e] + add[n,e] - mean[f]) * rstd[f] * (1 + gamma[t,e]) + beta[t,e]
+__global__ void posfuse_apply_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                     const float* __restrict__ beta, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     float* __restrict__ y, int T, int per_frame, long long total4) {
+  const int pf4 = per_frame / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long f = i / pf4;
+    const int e = (int)(i - f * pf4) * 4;
+    const int n = (int)(f / T), t = (int)(f - (long long)n * T);
+    float4 v = ld4(x + f * per_frame + e);
+    if (add) { const float4 a = ld4(add + (long long)n * per_frame + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    const float mu = mean[f], rs = rstd[f];
+    const float4 bt = ld4(beta + (long long)t * per_frame + e);
+    float4 o;
+    o.x = (v.x - mu) * rs; o.y = (v.y - mu) * rs; o.z = (v.z - mu) * rs; o.w = (v.w - mu) * rs;
+    if (gamma) {
+      const float4 g = ld4(gamma + (long long)t * per_frame + e);
+      o.x *= 1.f + g.x; o.y *= 1.f + g.y; o.z *= 1.f + g.z; o.w *= 1.f + g.w;
+    }
+    o.x += bt.x; o.y += bt.y; o.z += bt.z; o.w += bt.w;
+    st4(y + f * per_frame + e, o);
+  }
+}
+
+// backward statistics: s1[f] = mean(g), s2[f] = mean(g * uhat), g = dy * (1 + gamma)
+__global__ __launch_bounds__(512) void posfuse_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ add,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ s1o,
+                                                                float* __restrict__ s2o, int T, int per_frame) {
+  __shared__ float red[8];
+  const int f = blockIdx.x, n = f / T, t = f - n * T;
+  const float mu = mean[f], rs = rstd[f];
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x * 4; e < per_frame; e += 512 * 4) {
+    float4 v = ld4(x + (long long)f * per_frame + e);
+    if (add) { const float4 a = ld4(add + (long long)n * per_frame + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    float4 g = ld4(dy + (long long)f * per_frame + e);
+    if (gamma) {
+      const float4 gm = ld4(gamma + (long long)t * per_frame + e);
+      g.x *= 1.f + gm.x; g.y *= 1.f + gm.y; g.z *= 1.f + gm.z; g.w *= 1.f + gm.w;
+    }
+    s1 += g.x + g.y + g.z + g.w;
+    s2 += g.x * (v.x - mu) * rs + g.y * (v.y - mu) * rs + g.z * (v.z - mu) * rs + g.w * (v.w - mu) * rs;
+  }
+  s1 = block_sum<8>(s1, red) / per_frame;
+  s2 = block_sum<8>(s2, red) / per_frame;
+  if (threadIdx.x == 0) { s1o[f] = s1; s2o[f] = s2; }
+}
+
+// du = rstd * (g - s1 - uhat*s2); optionally dyxh = dy * uhat (for d gamma)
+__global__ void posfuse_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         const float* __restrict__ add, const float* __restrict__ gamma,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ s1, const float* __restrict__ s2,
+                                         float* __restrict__ du, float* __restrict__ dyxh, int T, int per_frame,
+                                         long long total4) {
+  const int pf4 = per_frame / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long f = i / pf4;
+    const int e = (int)(i - f * pf4) * 4;
+    const int n = (int)(f / T), t = (int)(f - (long long)n * T);
+    float4 v = ld4(x + f * per_frame + e);
+    if (add) { const float4 a = ld4(add + (long long)n * per_frame + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    const float mu = mean[f], rs = rstd[f], a1 = s1[f], a2 = s2[f];
+    float4 uh;
+    uh.x = (v.x - mu) * rs; uh.y = (v.y - mu) * rs; uh.z = (v.z - mu) * rs; uh.w = (v.w - mu) * rs;
+    const float4 d = ld4(dy + f * per_frame + e);
+    float4 g = d;
+    if (gamma) {
+      const float4 gm = ld4(gamma + (long long)t * per_frame + e);
+      g.x *= 1.f + gm.x; g.y *= 1.f + gm.y; g.z *= 1.f + gm.z; g.w *= 1.f + gm.w;
+    }
+    float4 o;
+    o.x = rs * (g.x - a1 - uh.x * a2); o.y = rs * (g.y - a1 - uh.y * a2);
+    o.z = rs * (g.z - a1 - uh.z * a2); o.w = rs * (g.w - a1 - uh.w * a2);
+    st4(du + f * per_frame + e, o);
+    if (dyxh) st4(dyxh + f * per_frame + e, make_float4(d.x * uh.x, d.y * uh.y, d.z * uh.z, d.w * uh.w));
+  }
+}
+
+// ------------------------------------------------------------------ frame-LN + affine + GELU (+dropout, residual, drop-path)
+// out = res + dp[n] * drop( gelu( (h-mean)*rstd*w[e] + b[e] ) )
+struct FlnParams {
+  const float* h; const float* mean; const float* rstd; const float* w; const float* b;
+  const float* res;                 // nullable residual, same shape as h
+  const unsigned long long* seed;
+  unsigned int drop_thresh; float drop_inv_keep; unsigned int salt;       // elementwise dropout
+  unsigned int dp_thresh; float dp_inv_keep; unsigned int dp_salt; int frames_per_sample;   // per-sample drop-path
+  int per_frame; long long total4;
+};
+
+__device__ __forceinline__ float fln_scale(const FlnParams& p, unsigned long long seed, long long f, long long gidx) {
+  float sc = 1.f;
+  if (p.drop_thresh) sc *= drop_scale(seed, p.salt, (unsigned long long)gidx, p.drop_thresh, p.drop_inv_keep);
+  if (p.dp_thresh) sc *= drop_scale(seed, p.dp_salt, (unsigned long long)(f / p.frames_per_sample), p.dp_thresh, p.dp_inv_keep);
+  return sc;
+}
+
+__global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out) {
+  const int pf4 = p.per_frame / 4;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long f = i / pf4;
+    const int e = (int)(i - f * pf4) * 4;
+    const float mu = p.mean[f], rs = p.rstd[f];
+    const float4 v = ld4(p.h + f * p.per_frame + e), ww = ld4(p.w + e), bb = ld4(p.b + e);
+    const long long g0 = f * p.per_frame + e;
+    float4 o;
+    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, f, g0 + 0);
+    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, f, g0 + 1);
+    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, f, g0 + 2);
+    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, f, g0 + 3);
+    if (p.res) { const float4 r = ld4(p.res + g0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    st4(out + g0, o);
+  }
+}
+
+// dy_ln = dout * scale * gelu'(y);  g = dy_ln * w;  s1 = mean(g), s2 = mean(g*hhat)
+__global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p, const float* __restrict__ dout,
+                                                                    float* __restrict__ s1o, float* __restrict__ s2o) {
+  __shared__ float red[8];
+  const long long f = blockIdx.x;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  const float mu = p.mean[f], rs = p.rstd[f];
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x * 4; e < p.per_frame; e += 512 * 4) {
+    const long long g0 = f * p.per_frame + e;
+    const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e), d = ld4(dout + g0);
+    const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
+    const float gx = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x) * ww.x;
+    const float gy = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y) * ww.y;
+    const float gz = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z) * ww.z;
+    const float gw = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w) * ww.w;
+    s1 += gx + gy + gz + gw;
+    s2 += gx * hx + gy * hy + gz * hz + gw * hw;
+  }
+  s1 = block_sum<8>(s1, red) / p.per_frame;
+  s2 = block_sum<8>(s2, red) / p.per_frame;
+  if (threadIdx.x == 0) { s1o[f] = s1; s2o[f] = s2; }
+}
+
+__global__ void frameln_act_bwd_apply_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ s1,
+                                             const float* __restrict__ s2, float* __restrict__ dh) {
+  const int pf4 = p.per_frame / 4;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long f = i / pf4;
+    const int e = (int)(i - f * pf4) * 4;
+    const long long g0 = f * p.per_frame + e;
+    const float mu = p.mean[f], rs = p.rstd[f], a1 = s1[f], a2 = s2[f];
+    const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e), d = ld4(dout + g0);
+    const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
+    const float gx = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x) * ww.x;
+    const float gy = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y) * ww.y;
+    const float gz = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z) * ww.z;
+    const float gw = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w) * ww.w;
+    float4 o;
+    o.x = rs * (gx - a1 - hx * a2); o.y = rs * (gy - a1 - hy * a2);
+    o.z = rs * (gz - a1 - hz * a2); o.w = rs * (gw - a1 - hw * a2);
+    st4(dh + g0, o);
+  }
+}
+
+// dw[e] = sum_f dy_ln*hhat, db[e] = sum_f dy_ln.  grid.x covers e (float4), grid.y = frame chunks whose
+// partial sums go to part[chunk][2][per_frame] (summed by sum_rows_kernel).
+__global__ void frameln_act_bwd_params_kernel(FlnParams p, const float* __restrict__ dout, float* __restrict__ part,
+                                              int frames, int frames_per_chunk) {
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (e >= p.per_frame) return;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  const float4 ww = ld4(p.w + e), bb = ld4(p.b + e);
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int f0 = blockIdx.y * frames_per_chunk;
+  const int f1 = min(frames, f0 + frames_per_chunk);
+  for (long long f = f0; f < f1; ++f) {
+    const long long g0 = f * p.per_frame + e;
+    const float mu = p.mean[f], rs = p.rstd[f];
+    const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
+    const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
+    const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
+    const float dy_ = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
+    const float dz_ = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
+    const float dw_ = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
+    aw.x += dx_ * hx; aw.y += dy_ * hy; aw.z += dz_ * hz; aw.w += dw_ * hw;
+    ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
+  }
+  float* o = part + (long long)blockIdx.y * 2 * p.per_frame;
+  st4(o + e, aw);
+  st4(o + p.per_frame + e, ab);
+}
+
+int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 255) / 256), dim3(256), 0, stream, in, out, nb, stride, ncols);
+  return hipGetLastError() == hipSuccess ? NPVP_OK : NPVP_ERR_LAUNCH;
+}
+
+static inline int ew_blocks(long long total, int threads) {
+  long long b = (total + threads - 1) / threads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static void fill_fln(FlnParams& p, const float* h, const float* mean, const float* rstd, const float* w, const float* b,
+                     const float* res, int frames, int per_frame, float drop_p, unsigned int salt, float dp_p,
+                     unsigned int dp_salt, int frames_per_sample, const unsigned long long* seed) {
+  p.h = h; p.mean = mean; p.rstd = rstd; p.w = w; p.b = b; p.res = res; p.seed = seed;
+  p.drop_thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  p.salt = salt;
+  p.dp_thresh = dp_p > 0.f ? drop_threshold(dp_p) : 0u;
+  p.dp_inv_keep = dp_p > 0.f ? 1.f / (1.f - dp_p) : 1.f;
+  p.dp_salt = dp_salt; p.frames_per_sample = frames_per_sample > 0 ? frames_per_sample : 1;
+  p.per_frame = per_frame; p.total4 = (long long)frames * per_frame / 4;
+}
+
+}  // namespace npvp
+
+using namespace npvp;
+
+extern "C" int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                                  long long rows, int C, float eps, int relu, hipStream_t stream) {
+  NPVP_CHECK_ARG(rows > 0, "layernorm: no rows");
+  NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm: C must be 256, 512, 768 or 1024");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
+  }
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+static int ln_bwd_blocks(long long rows) {
+  long long b = (rows + 3) / 4;
+  return (int)(b > 512 ? 512 : b);
+}
+
+extern "C" long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C) {
+  return (long long)ln_bwd_blocks(rows) * 2 * C * 4;
+}
+
+extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
+                                  const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
+                                  void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(rows > 0, "layernorm_bwd: no rows");
+  NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm_bwd: C must be 256, 512, 768 or 1024");
+  const int nb = ln_bwd_blocks(rows);
+  NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)nb * 2 * C * 4, "layernorm_bwd: workspace too small");
+  float* part = (float*)workspace;
+  dim3 grid(nb), block(256);
+  switch (C / 256) {
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
+  }
+  NPVP_CHECK_LAUNCH();
+  // partial rows are [dw(C) | db(C)]
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, nb, 2 * C, C);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part + C, db, nb, 2 * C, C);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_frame_stats(const float* x, const float* add, float* mean, float* rstd, int frames, int T,
+                                int per_frame, float eps, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && T > 0 && frames % T == 0, "frame_stats: frames must be a multiple of T");
+  NPVP_CHECK_ARG(per_frame % 4 == 0, "frame_stats: per_frame must be a multiple of 4");
+  hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y,
+                                float* mean, float* rstd, int N, int T, int per_frame, float eps, hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse: bad shape");
+  const int frames = N * T;
+  hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
+  NPVP_CHECK_LAUNCH();
+  const long long total4 = (long long)frames * per_frame / 4;
+  hipLaunchKernelGGL(posfuse_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, x, add, beta, gamma,
+                     (const float*)mean, (const float*)rstd, y, T, per_frame, total4);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// du [N*T, per_frame]; dyxh (nullable) receives dy*uhat for the d(gamma) reduction; ws = 2*N*T floats
+extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
+                                const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
+                                long long ws_bytes, hipStream_t stream) {
+  const int frames = N * T;
+  NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse_bwd: bad shape");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * 2 * 4, "posfuse_bwd: workspace too small");
+  float* s1 = (float*)workspace; float* s2 = s1 + frames;
+  hipLaunchKernelGGL(posfuse_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, dy, x, add, gamma, mean, rstd, s1, s2, T,
+                     per_frame);
+  NPVP_CHECK_LAUNCH();
+  const long long total4 = (long long)frames * per_frame / 4;
+  hipLaunchKernelGGL(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
+                     rstd, (const float*)s1, (const float*)s2, du, dyxh, T, per_frame, total4);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const float* rstd, const float* w, const float* b,
+                                    const float* res, float* out, int frames, int per_frame, float drop_p,
+                                    unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
+                                    const unsigned long long* seed, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0, "frameln_act: bad shape");
+  NPVP_CHECK_ARG((drop_p == 0.f && dp_p == 0.f) || seed, "frameln_act: dropout needs a device seed");
+  FlnParams p;
+  fill_fln(p, h, mean, rstd, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
+  hipLaunchKernelGGL(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+static int fln_chunks(int frames) { return frames < 32 ? frames : 32; }
+
+extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
+  return ((long long)frames * 2 + (long long)fln_chunks(frames) * 2 * per_frame) * 4;
+}
+
+// dh [frames, per_frame]; dw, db [per_frame]
+extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                                    const float* b, float* dh, float* dw, float* db, int frames, int per_frame,
+                                    float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt,
+                                    int frames_per_sample, const unsigned long long* seed, void* workspace,
+                                    long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0, "frameln_act_bwd: bad shape");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
+                 "frameln_act_bwd: workspace too small");
+  FlnParams p;
+  fill_fln(p, h, mean, rstd, w, b, nullptr, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
+  float* s1 = (float*)workspace; float* s2 = s1 + frames; float* part = s2 + frames;
+  hipLaunchKernelGGL(frameln_act_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, p, dout, s1, s2);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(frameln_act_bwd_apply_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, dout,
+                     (const float*)s1, (const float*)s2, dh);
+  NPVP_CHECK_LAUNCH();
+  const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
+  const int nchunks = (frames + fpc - 1) / fpc;
+  hipLaunchKernelGGL(frameln_act_bwd_params_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
+                     dout, part, frames, fpc);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((per_frame + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, nchunks,
+                     2 * per_frame, per_frame);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((per_frame + 255) / 256), dim3(256), 0, stream,
+                     (const float*)part + per_frame, db, nchunks, 2 * per_frame, per_frame);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}

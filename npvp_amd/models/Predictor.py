@@ -1,0 +1,101 @@
+"""HIP-backed NP predictor: drop-in for ref/models/Predictor.py:265-359 (`Predictor`).  Same
+constructor signature, attributes (`stochastic`, `TP`, `observed_coor`, `predict_coor`, `nrmlp`, `fuser`,
+`EVT_Former`, `evt_posterior`, `evt_prior`, `transformer`), methods and the 603 state-dict keys,
+so reference checkpoints load with load_state_dict and LitPredictor-style callers keep working.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .submodules import CoorGenerator, NRMLP, PosFeatFuser, EventEncoder
+from .VidHRFormer import VidHRformerDecoderNAR, VidHRFormerEncoder
+
+
+class Predictor(nn.Module):
+    def __init__(self, max_H, max_W, max_T, h_list, w_list, to_list, tp_list, embed_dim=512, fuse_method='SPADE',
+                 param_free_norm_type='layer', evt_hidden_channels=256, evt_n_layers=1, stochastic=True,
+                 transformer_layers=4, num_heads=8, window_size=4, dropout=0.1, drop_path=0.1,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024, norm=None, return_intermediate=False, evt_former=True,
+                 learn_evt_token=False, evt_former_num_layers=4, rand_context=False):
+        super().__init__()
+        if norm is None:
+            # the reference's default argument is ONE nn.LayerNorm(512) instance shared by the encoder and
+            # the decoder (ref Predictor.py:270,290-291,299): a single tied weight under two state-dict keys
+            norm = nn.LayerNorm(512)
+        if not evt_former or learn_evt_token:
+            raise NotImplementedError("evt_former=False / learn_evt_token=True are outside the hot path")
+        if rand_context:
+            raise NotImplementedError("rand_context (unified model) is a 'next' row (SURVEY 8f #2)")
+        self.stochastic, self.evt_former = stochastic, evt_former
+        self.h_list, self.w_list = h_list, w_list
+        self.max_H, self.max_W = max_H, max_W
+        self.coor_generator = CoorGenerator(max_H, max_W, max_T)
+        self.register_buffer("observed_coor", self.coor_generator(to_list, h_list, w_list))
+        self.register_buffer("predict_coor", self.coor_generator(tp_list, h_list, w_list))
+        self.nrmlp = NRMLP(out_channels=embed_dim, fuse_method=fuse_method)
+        self.fuser = PosFeatFuser(x_channels=embed_dim, param_free_norm_type=param_free_norm_type)
+        self.EVT_Former = VidHRFormerEncoder(evt_former_num_layers, max_H, max_W, embed_dim, num_heads, window_size, dropout,
+                                             drop_path, Spatial_FFN_hidden_ratio, dim_feedforward, norm, learn_evt_token)
+        self.evt_posterior = EventEncoder(embed_dim, evt_hidden_channels, evt_n_layers, stochastic)
+        self.evt_prior = None
+        if self.stochastic:
+            self.evt_prior = EventEncoder(embed_dim, evt_hidden_channels, evt_n_layers, stochastic)
+        self.TP = tp_list.shape[0]
+        self.transformer = VidHRformerDecoderNAR(transformer_layers, max_H, max_W, embed_dim, num_heads, window_size, dropout,
+                                                 drop_path, Spatial_FFN_hidden_ratio, dim_feedforward, norm, return_intermediate)
+
+    def _pos(self, coor):
+        """(beta, gamma) tables; for fuse_method 'Add' gamma is identically zero (ref submodules.py:309-312) and
+        x*(1+0) is exact, so the fuser kernel is told to skip it."""
+        beta, gamma = self.nrmlp(coor)
+        return (beta, gamma if self.nrmlp.fuse_method == 'SPADE' else None)
+
+    # -- helpers on the canonical layout -------------------------------------------------------------
+    def _encode(self, feats, pos):
+        """(N,T,C,H,W) features -> canonical encoder output (N,T,H,W,C) and event coding (N,C,H,W)."""
+        N, T, C, H, W = feats.shape
+        x = ops.nchw_to_canonical(feats).view(N, T, H, W, C)
+        x = self.EVT_Former.forward_canonical(x, pos, self.fuser)
+        evt = ops.mean_mid(x.view(N, T, H * W * C))                                   # mean over T, ref :346
+        evt = ops._Transpose.apply(evt.view(N, H * W, C)).view(N, C, H, W)
+        return x, evt
+
+    def _decode(self, z, memory, op, pp):
+        N, C, H, W = z.shape
+        qe = ops._Transpose.apply(z.reshape(N, C, H * W)).view(N, H, W, C)
+        out = self.transformer.forward_canonical(qe, memory, op, pp, self.fuser, self.TP)
+        return ops.canonical_to_nchw(out, N, self.TP, H, W)
+
+    def forward(self, observed_features, predict_features_gt=None):
+        """observed_features: (N, To, C, H, W) -> (N, Tp, C, H, W) [, mu_o, logvar_o, mu_p, logvar_p]"""
+        op = self._pos(self.observed_coor)
+        pp = self._pos(self.predict_coor)
+        memory, obs_evt = self._encode(observed_features, op)
+        if self.stochastic:
+            zo, mu_o, logvar_o = self.evt_prior(obs_evt)
+            if predict_features_gt is not None:
+                _, pred_evt = self._encode(predict_features_gt, pp)
+                zp, mu_p, logvar_p = self.evt_posterior(pred_evt)
+            if self.training:
+                assert predict_features_gt is not None, \
+                    "please input groundtruth predict features for storchastic model training/val"
+                out = self._decode(zp, memory, op, pp)
+            else:
+                out = self._decode(zo, memory, op, pp)
+            if predict_features_gt is None:
+                return out
+            return out, mu_o, logvar_o, mu_p, logvar_p
+        mu_o = self.evt_posterior(obs_evt)
+        return self._decode(mu_o, memory, op, pp)
+
+    def evt_coding_forward(self, x, pos_beta, pos_gamma):
+        """x (N,T,C,H,W) -> (encoder output (N,T,C,H,W), event coding (N,C,H,W))   ref :337-350"""
+        N, T, C, H, W = x.shape
+        mem, evt = self._encode(x, (pos_beta, pos_gamma))
+        return ops.canonical_to_nchw(mem, N, T, H, W), evt
+
+    def reset_pos_coor(self, to_list, tp_list):
+        device = self.observed_coor.device
+        self.predict_coor = self.coor_generator(tp_list, self.h_list, self.w_list).to(device)
+        self.observed_coor = self.coor_generator(to_list, self.h_list, self.w_list).to(device)
+        self.TP = tp_list.shape[0]

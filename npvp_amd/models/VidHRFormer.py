@@ -1,0 +1,342 @@
+"""HIP-backed VidHRFormer blocks: drop-in for ref/models/VidHRFormer.py (same class names,
+constructor signatures, forward signatures, attribute names and state-dict keys).
+
+Everything runs on ONE canonical activation layout, x[N*T, H*W, C] (a contiguous (N,T,H,W,C)
+tensor); the reference's permute/reshape/rearrange round trips (ref :34,50,94,114,217,240,
+283-307,379,392) become index math inside the kernels.  Residual adds, dropout and drop-path
+are epilogues of the GEMM / frame-LN kernels, never separate passes.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import Drop, AttnCfg
+
+
+class _OutProj(nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(C, C))
+        self.bias = nn.Parameter(torch.zeros(C))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container with torch.nn.MultiheadAttention's layout (in_proj_weight [3C,C], in_proj_bias
+    [3C], out_proj.{weight,bias}) - the reference instantiates nn.MultiheadAttention at
+    ref/models/VidHRFormer.py:70,180,192,270.  The arithmetic (its key-is-not-value slow path) is:
+    q|k projection as ONE [R,2C] GEMM when q and k share their input, v projection, attention core
+    kernel, out-projection GEMM with the residual/dropout epilogue."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim // num_heads == 64, "the gfx950 attention core is built for head_dim 64 (embed_dim 512, 8 heads)"
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = _OutProj(embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def self_attention(self, x_qk, x_v, cfg, residual=None, drop=ops.NO_DROP):
+        """q = k source x_qk [R,C], value source x_v [R,C] -> residual + drop(out_proj(core))."""
+        C = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        qk = ops.linear(x_qk, w[:2 * C], b[:2 * C])
+        v = ops.linear(x_v, w[2 * C:], b[2 * C:])
+        o = ops.attn_packed(qk, v, cfg)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, drop=drop)
+
+    def cross_attention(self, x_q, x_k, x_v, cfg, residual=None, drop=ops.NO_DROP):
+        C = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        q = ops.linear(x_q, w[:C], b[:C])
+        k = ops.linear(x_k, w[C:2 * C], b[C:2 * C])
+        v = ops.linear(x_v, w[2 * C:], b[2 * C:])
+        o = ops.attn(q, k, v, cfg)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, drop=drop)
+
+
+class SpatialLocalMultiheadAttention(nn.Module):
+    """ref/models/VidHRFormer.py:247-307."""
+
+    def __init__(self, embed_dim, num_heads, window_size=7, dropout=0.):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.attn = MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+
+    def _cfg(self, N, T, H, W):
+        if H % self.window_size or W % self.window_size:
+            raise NotImplementedError("feature grid must be a multiple of the window (8/4 in every config); the "
+                                      "centre-pad branch of ref PadBlock is not on the hot path")
+        return AttnCfg(0, N * T, H * W, W, self.window_size, 0, 0, self.num_heads, 0,
+                       self.dropout if self.training else 0.0)
+
+    def fused(self, x, value, residual, drop):
+        N, T, H, W, C = x.shape
+        xv = x if value is None else value
+        y = self.attn.self_attention(x.reshape(-1, C), xv.reshape(-1, C), self._cfg(N, T, H, W),
+                                     None if residual is None else residual.reshape(-1, C), drop)
+        return y.view(N, T, H, W, C)
+
+    def forward(self, x, value=None):
+        """x, value: (N,T,H,W,C) -> (N,T,H,W,C)"""
+        return self.fused(x, value, None, ops.NO_DROP)
+
+    def extra_repr(self):
+        return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
+
+
+class MlpDWBN(nn.Module):
+    """ref/models/VidHRFormer.py:326-392 (AR_model=True: LayerNorm((C,H,W)) variant).
+    fc1/fc2 are GEMMs over the channels-last rows; each LayerNorm((Ch,H,W))+GELU(+dropout) is one
+    statistics pass + one fused apply pass; the depthwise 3x3 works on [F, H*W, Ch] directly."""
+
+    def __init__(self, encH, encW, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU,
+                 dw_act_layer=nn.GELU, drop=0.0, AR_model=True):
+        super().__init__()
+        if not AR_model:
+            raise NotImplementedError("only the AR_model=True (LayerNorm) variant is on the hot path")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.encH, self.encW = encH, encW
+        self.fc1 = nn.Conv2d(in_features, hidden_features, kernel_size=1)
+        self.act1 = act_layer()
+        self.norm1 = nn.LayerNorm((hidden_features, encH, encW))
+        self.dw3x3 = nn.Conv2d(hidden_features, hidden_features, kernel_size=3, stride=1, groups=hidden_features, padding=1)
+        self.act2 = dw_act_layer()
+        self.norm2 = nn.LayerNorm((hidden_features, encH, encW))
+        self.fc2 = nn.Conv2d(hidden_features, out_features, kernel_size=1)
+        self.act3 = act_layer()
+        self.norm3 = nn.LayerNorm((out_features, encH, encW))
+        self.drop = nn.Dropout(drop)
+        self.out_features = out_features
+
+    @staticmethod
+    def _cl(p):
+        """(Ch,H,W) parameter -> channels-last [H*W*Ch] (differentiable: a transpose kernel both ways)."""
+        Ch = p.shape[0]
+        return ops._Transpose.apply(p.reshape(1, Ch, -1)).reshape(-1)
+
+    def fused(self, x, residual, p_dp):
+        N, T, H, W, C = x.shape
+        F_, R = N * T, N * T * H * W
+        pd = self.drop.p if self.training else 0.0
+        hid = self.fc1.out_channels
+        h = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias)
+        a = ops.frameln_act(h, self._cl(self.norm1.weight), self._cl(self.norm1.bias), None, F_)
+        wtb = torch.cat([ops._Transpose.apply(self.dw3x3.weight.reshape(1, hid, 9)).reshape(9, hid),
+                         self.dw3x3.bias.reshape(1, hid)], dim=0)
+        h = ops.dwconv3x3(a, wtb, F_, H, W)
+        a = ops.frameln_act(h, self._cl(self.norm2.weight), self._cl(self.norm2.bias), None, F_, pd)
+        h = ops.linear(a.reshape(R, hid), self.fc2.weight.flatten(1), self.fc2.bias)
+        out = ops.frameln_act(h, self._cl(self.norm3.weight), self._cl(self.norm3.bias),
+                              None if residual is None else residual.reshape(R, self.out_features), F_, pd, p_dp, T)
+        return out.view(N, T, H, W, self.out_features)
+
+    def forward(self, x):
+        """x: (N,T,H,W,C)"""
+        return self.fused(x, None, 0.0)
+
+
+class DropPath(nn.Module):
+    """ref/models/VidHRFormer.py:528-542; kept for API parity.  Inside the blocks drop-path is fused
+    into the producing kernel's epilogue, this module only records the probability."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.drop_prob or not self.training:
+            return x
+        x2 = x.reshape(x.shape[0], -1)
+        pad = (-x2.shape[1]) % 4
+        if pad:
+            raise NotImplementedError("standalone DropPath needs a row length that is a multiple of 4")
+        return ops.drop_apply(x2.contiguous(), Drop(self.drop_prob, 1, 1, x.shape[0])).view(x.shape)
+
+    def extra_repr(self):
+        return "drop_prob={}".format(self.drop_prob)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class VidHRFormerBlockEnc(nn.Module):
+    """ref/models/VidHRFormer.py:54-116."""
+
+    def __init__(self, encH, encW, embed_dim, num_heads, window_size=7, dropout=0., drop_path=0.,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.Spatial_FFN_hidden_ratio = Spatial_FFN_hidden_ratio
+        self.SLMHSA = SpatialLocalMultiheadAttention(embed_dim, num_heads, window_size, dropout)
+        self.SpatialFFN = MlpDWBN(encH, encW, embed_dim, hidden_features=int(Spatial_FFN_hidden_ratio * embed_dim),
+                                  out_features=embed_dim, drop=dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = nn.LayerNorm(embed_dim)
+        self.temporal_MHSA = MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.linear1 = nn.Linear(embed_dim, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, embed_dim)
+        self.activation = nn.GELU()
+        self.drop1 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.drop2 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.drop3 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.norm4 = nn.LayerNorm(embed_dim)
+        self._dp = float(drop_path)
+
+    def forward(self, x, memory_pos, pos_fuser):
+        """x: (N,T,H,W,C) contiguous -> (N,T,H,W,C)."""
+        N, T, H, W, C = x.shape
+        P = H * W
+        tr = self.training
+        pd, dp = (self.dropout if tr else 0.0), (self._dp if tr else 0.0)
+        beta, gamma = memory_pos
+        x = x.contiguous()
+        # spatial window attention: x += drop_path(SLMHSA(fuse(LN1 x), value = LN1 x))           ref :87-88
+        x1 = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.SLMHSA.fused(pos_fuser(x1, beta, gamma), x1, x, Drop(dp, 1, T * P, N))
+        # conv feed-forward: x += drop_path(MlpDWBN(LN2 x))                                       ref :91
+        x = self.SpatialFFN.fused(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x, dp)
+        # temporal attention with the encoder mask: x += drop1(tMHA(q=k=fuse(LN3 x), v=LN3 x))    ref :94-107
+        x1 = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        temp = pos_fuser(x1, beta, gamma)
+        cfg = AttnCfg(1, N, P, W, 0, T, T, self.num_heads, 1, pd)
+        x = self.temporal_MHSA.self_attention(temp.reshape(-1, C), x1.reshape(-1, C), cfg, x.reshape(-1, C),
+                                              Drop(pd)).view(N, T, H, W, C)
+        # token FFN: x += drop3(linear2(drop2(GELU(linear1(LN4 x)))))                             ref :110-112
+        x1 = ops.layernorm(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        return ops.ffn(x1, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, pd)
+
+
+class VidHRFormerEncoder(nn.Module):
+    """ref/models/VidHRFormer.py:11-52 (evt_token=False path, ref/models/Predictor.py:46)."""
+
+    def __init__(self, num_layers, enc_H, enc_W, d_model, num_heads, window_size=7, dropout=0., drop_path=0.,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024, norm=None, evt_token=False):
+        super().__init__()
+        if evt_token:
+            raise NotImplementedError("learn_evt_token is outside the hot path (the reference always passes False)")
+        self.layers = _get_clones(VidHRFormerBlockEnc(enc_H, enc_W, d_model, num_heads, window_size, dropout, drop_path,
+                                                      Spatial_FFN_hidden_ratio, dim_feedforward), num_layers)
+        self.num_layers, self.norm, self.evt_token = num_layers, norm, evt_token
+
+    def forward_canonical(self, x, memory_pos, pos_fuser):
+        """x: (N,T,H,W,C) canonical -> (N,T,H,W,C) canonical (after the shared final LayerNorm)."""
+        for layer in self.layers:
+            x = layer(x, memory_pos, pos_fuser)
+        if self.norm is not None:
+            x = ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+    def forward(self, src, memory_pos, pos_fuser):
+        """src: (N,T,C,H,W) -> (N,T,C,H,W)   (reference signature)"""
+        N, T, C, H, W = src.shape
+        x = ops.nchw_to_canonical(src).view(N, T, H, W, C)
+        x = self.forward_canonical(x, memory_pos, pos_fuser)
+        return ops.canonical_to_nchw(x, N, T, H, W)
+
+
+class VidHRFormerBlockDecNAR(nn.Module):
+    """ref/models/VidHRFormer.py:163-245."""
+
+    def __init__(self, encH, encW, embed_dim, num_heads, window_size=7, dropout=0., drop_path=0.,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.Spatial_FFN_hidden_ratio = Spatial_FFN_hidden_ratio
+        hid = int(Spatial_FFN_hidden_ratio * embed_dim)
+        self.SLMHSA = SpatialLocalMultiheadAttention(embed_dim, num_heads, window_size, dropout)
+        self.SpatialFFN = MlpDWBN(encH, encW, embed_dim, hidden_features=hid, out_features=embed_dim, drop=dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = nn.LayerNorm(embed_dim)
+        self.temporal_MHSA = MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.drop1 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.linear1 = nn.Linear(embed_dim, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, embed_dim)
+        self.activation = nn.GELU()
+        self.drop2 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.drop3 = nn.Dropout(dropout) if dropout > 0. else nn.Identity()
+        self.norm4 = nn.LayerNorm(embed_dim)
+        self.EncDecAttn = MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.SpatialFFN1 = MlpDWBN(encH, encW, embed_dim, hidden_features=hid, out_features=embed_dim, drop=dropout)
+        self.norm5 = nn.LayerNorm(embed_dim)
+        self.norm6 = nn.LayerNorm(embed_dim)
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self._dp = float(drop_path)
+
+    def forward(self, tgt, query_evt, memory, memory_pos, tgt_pos, pos_fuser, fused_memory=None):
+        """tgt (N,T2,H,W,C); query_evt (N,H,W,C) = z (the reference repeats it over T2, ref Predictor.py:317:
+        a (N,T2,H,W,C) tensor whose time-steps are identical is accepted too); memory (N,T1,H,W,C).
+        fused_memory = pos_fuser(memory, *memory_pos), layer invariant (ref :232), hoisted by the decoder."""
+        N, T2, H, W, C = tgt.shape
+        T1, P = memory.shape[1], H * W
+        if query_evt.dim() == 5:
+            query_evt = query_evt[:, 0]
+        query_evt = query_evt.contiguous()
+        tr = self.training
+        pd, dp = (self.dropout if tr else 0.0), (self._dp if tr else 0.0)
+        tb, tg = tgt_pos
+        tgt = tgt.contiguous()
+        # spatial window attention over fuse(LN1 tgt + query_evt), value LN1 tgt                  ref :210-212
+        t2 = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.SLMHSA.fused(pos_fuser(t2, tb, tg, add=query_evt), t2, tgt, Drop(dp, 1, T2 * P, N))
+        x = self.SpatialFFN.fused(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x, dp)   # :214
+        # temporal self-attention (no mask)                                                       ref :217-221
+        x1 = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        temp = pos_fuser(x1, tb, tg)
+        cfg = AttnCfg(1, N, P, W, 0, T2, T2, self.num_heads, 0, pd)
+        x = self.temporal_MHSA.self_attention(temp.reshape(-1, C), x1.reshape(-1, C), cfg, x.reshape(-1, C),
+                                              Drop(pd)).view(N, T2, H, W, C)
+        x1 = ops.layernorm(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)                                # :224-226
+        x = ops.ffn(x1, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, pd)
+        # encoder-decoder attention; its drop_path acts per TIME-STEP (tensor is (T2, N*H*W, C))   ref :229-239
+        x1 = ops.layernorm(x, self.norm5.weight, self.norm5.bias, self.norm5.eps)
+        key = fused_memory if fused_memory is not None else pos_fuser(memory, *memory_pos)
+        query = pos_fuser(x1, tb, tg, add=query_evt)
+        cfg = AttnCfg(1, N, P, W, 0, T2, T1, self.num_heads, 0, pd)
+        x = self.EncDecAttn.cross_attention(query.reshape(-1, C), key.reshape(-1, C), memory.reshape(-1, C), cfg,
+                                            x.reshape(-1, C), Drop(dp, 1, P, T2)).view(N, T2, H, W, C)
+        return self.SpatialFFN1.fused(ops.layernorm(x, self.norm6.weight, self.norm6.bias, self.norm6.eps), x, dp)  # :243
+
+
+class VidHRformerDecoderNAR(nn.Module):
+    """ref/models/VidHRFormer.py:118-161 (return_intermediate=False)."""
+
+    def __init__(self, num_layers, encH, encW, embed_dim, num_heads, window_size=7, dropout=0., drop_path=0.,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024, norm=None, return_intermediate=False):
+        super().__init__()
+        if return_intermediate:
+            raise NotImplementedError("return_intermediate is never used by the predictor")
+        self.layers = _get_clones(VidHRFormerBlockDecNAR(encH, encW, embed_dim, num_heads, window_size, dropout, drop_path,
+                                                         Spatial_FFN_hidden_ratio, dim_feedforward), num_layers)
+        self.num_layers, self.norm, self.return_intermediate = num_layers, norm, return_intermediate
+
+    def forward_canonical(self, qe, memory, memory_pos, tgt_pos, pos_fuser, T2):
+        """qe (N,H,W,C), memory (N,T1,H,W,C) canonical -> (N,T2,H,W,C) canonical, after LN + ReLU."""
+        N, H, W, C = qe.shape
+        out = torch.zeros(N, T2, H, W, C, dtype=torch.float32, device=qe.device)
+        fused_memory = pos_fuser(memory, *memory_pos)
+        for layer in self.layers:
+            out = layer(out, qe, memory, memory_pos, tgt_pos, pos_fuser, fused_memory)
+        if self.norm is not None:
+            out = ops.layernorm(out, self.norm.weight, self.norm.bias, self.norm.eps, relu=True)
+        else:
+            out = torch.relu(out)
+        return out
+
+    def forward(self, query_evt, memory, memory_pos, tgt_pos, pos_fuser):
+        """query_evt (N,T2,C,H,W), memory (N,T1,C,H,W) -> (N,T2,C,H,W)   (reference signature)"""
+        N, T2, C, H, W = query_evt.shape
+        T1 = memory.shape[1]
+        qe = ops.nchw_to_canonical(query_evt[:, :1]).view(N, H, W, C)
+        mem = ops.nchw_to_canonical(memory).view(N, T1, H, W, C)
+        out = self.forward_canonical(qe, mem, memory_pos, tgt_pos, pos_fuser, T2)
+        return ops.canonical_to_nchw(out, N, T2, H, W)

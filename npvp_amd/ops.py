@@ -1,0 +1,550 @@
+"""torch.autograd glue over the C ABI of libnpvp_hip.so.  PyTorch supplies device memory,
+the current HIP stream and the autograd graph; every piece of arithmetic on the hot path is
+a hand-written gfx950 kernel reached through ctypes.  There is no CPU / eager fallback:
+tensors must be fp32 CUDA(ROCm) tensors and the library must be built.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+
+_p = ctypes.c_void_p
+
+
+def _ptr(t):
+    return _p(0) if t is None else _p(t.data_ptr())
+
+
+def _stream():
+    return _p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("npvp_amd ops need tensors on an MI355X device (no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise RuntimeError("npvp_amd ops are fp32")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, dev):
+    n = max(int(nbytes), 16)
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=dev), n
+
+
+# --------------------------------------------------------------------------- dropout state
+class _RngState:
+    """Device seed + per-call-site salt counter for the in-kernel counter-hash dropout masks.
+    `begin_step()` bumps the device seed (a captured graph replays that bump) and restarts the
+    salt counter, so eager and graph-replayed steps draw identical mask streams."""
+
+    def __init__(self):
+        self.seed = None
+        self.salt = 0
+
+    def seed_tensor(self, dev):
+        if self.seed is None or self.seed.device != dev:
+            self.seed = torch.full((1,), 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=dev)
+        return self.seed
+
+    def manual_seed(self, s, dev):
+        self.seed_tensor(dev).fill_(int(s) & 0x7FFFFFFFFFFFFFFF)
+        self.salt = 0
+
+    def begin_step(self, dev):
+        self.seed_tensor(dev).add_(0x632BE5AB)
+        self.salt = 0
+
+    def next_salt(self):
+        self.salt += 1
+        return self.salt
+
+
+rng = _RngState()
+
+
+class Drop:
+    """A dropout / drop-path site: probability, keying mode (0 element, 1 row group) and salt."""
+    __slots__ = ("p", "mode", "g1", "g2", "salt")
+
+    def __init__(self, p=0.0, mode=0, g1=1, g2=1):
+        self.p, self.mode, self.g1, self.g2 = float(p), mode, g1, g2
+        self.salt = rng.next_salt() if p > 0 else 0
+
+    @property
+    def on(self):
+        return self.p > 0.0
+
+
+NO_DROP = Drop(0.0)
+
+
+class GemmProbe:
+    """bench.py's live roofline probe: when armed, every GEMM launch of the probed operand layout is bracketed
+    by a pair of HIP events on the launching stream (no synchronisation; read after the timed region)."""
+    armed = None          # (a_kc, b_kc) or None
+    records = []          # (start_event, end_event, flops)
+
+    @classmethod
+    def arm(cls, a_kc, b_kc):
+        cls.armed, cls.records = (a_kc, b_kc), []
+
+    @classmethod
+    def disarm(cls):
+        cls.armed = None
+
+    @classmethod
+    def summary(cls):
+        """(launches, total_ms, total_flops) - call after torch.cuda.synchronize()."""
+        ms = sum(a.elapsed_time(b) for a, b, _ in cls.records)
+        return len(cls.records), ms, sum(f for _, _, f in cls.records)
+
+
+# --------------------------------------------------------------------------- raw kernel wrappers
+def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
+         drop=NO_DROP, alpha=1.0):
+    _chk(A, B, out, bias, aux_in, aux_out, residual)
+    L = lib()
+    wsb = L.npvp_gemm_workspace_bytes(M, N, K)
+    ws, wsn = (None, 0)
+    if wsb > 0:
+        ws, wsn = _ws(wsb, A.device)
+    seed = rng.seed_tensor(A.device) if drop.on else None
+    probe = GemmProbe.armed == (a_kc, b_kc)
+    if probe:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
+                          _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
+                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, _ptr(ws), wsn, _stream()),
+          "npvp_gemm_f32")
+    if probe:
+        e1.record()
+        GemmProbe.records.append((e0, e1, 2.0 * M * N * K))
+    return out
+
+
+def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP):
+    """y[R,N] = epilogue(x[R,K] w[N,K]^T)"""
+    R, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(R, N, dtype=torch.float32, device=x.device)
+    return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual, drop=drop)
+
+
+def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
+    """dx[R,K] = epilogue(dy[R,N] w[N,K])"""
+    R, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
+    return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop)
+
+
+def linear_wgrad(dy, x):
+    """dw[N,K] = dy[R,N]^T x[R,K]"""
+    R, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    return gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw)
+
+
+def colsum(x):
+    R, N = x.shape
+    L = lib()
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws, wsn = _ws(L.npvp_colsum_workspace_bytes(R, N), x.device)
+    check(L.npvp_colsum(_ptr(x), R, N, x.stride(0), _ptr(out), _ptr(ws), wsn, _stream()), "npvp_colsum")
+    return out
+
+
+def drop_apply(x2d, drop):
+    out = torch.empty_like(x2d)
+    check(lib().npvp_drop_apply(_ptr(x2d), _ptr(out), x2d.shape[0], x2d.shape[1], drop.p, drop.mode, drop.g1, drop.g2,
+                                _ptr(rng.seed_tensor(x2d.device)), drop.salt, _stream()), "npvp_drop_apply")
+    return out
+
+
+def transpose(x):
+    """[B,R,C] -> [B,C,R]"""
+    _chk(x)
+    x = _c(x)
+    B, R, C = x.shape
+    out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+    check(lib().npvp_transpose(_ptr(x), _ptr(out), B, R, C, _stream()), "npvp_transpose")
+    return out
+
+
+def reduce_mid(x, scale=1.0):
+    """[A,B,C] -> [A,C]: scale * sum over B"""
+    _chk(x)
+    x = _c(x)
+    A, B, C = x.shape
+    out = torch.empty(A, C, dtype=torch.float32, device=x.device)
+    check(lib().npvp_reduce_mid(_ptr(x), _ptr(out), A, B, C, scale, _stream()), "npvp_reduce_mid")
+    return out
+
+
+def broadcast_mid(x, B, scale=1.0):
+    """[A,C] -> [A,B,C]"""
+    _chk(x)
+    x = _c(x)
+    A, C = x.shape
+    out = torch.empty(A, B, C, dtype=torch.float32, device=x.device)
+    check(lib().npvp_broadcast_mid(_ptr(x), _ptr(out), A, B, C, scale, _stream()), "npvp_broadcast_mid")
+    return out
+
+
+# --------------------------------------------------------------------------- autograd Functions
+class _Transpose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return transpose(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return transpose(g)
+
+
+class _MeanMid(torch.autograd.Function):
+    """[A,B,C] -> [A,C] mean over B (event coding = mean over T, ref/models/Predictor.py:346)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.B = x.shape[1]
+        return reduce_mid(x, 1.0 / x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return broadcast_mid(g, ctx.B, 1.0 / ctx.B)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, relu):
+        _chk(x, w, b)
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, C, eps,
+                                       int(relu), _stream()), "npvp_layernorm_fwd")
+        ctx.save_for_backward(x2, w, b, mean, rstd)
+        ctx.relu, ctx.shape = int(relu), x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = _c(dy).reshape(rows, C)
+        L = lib()
+        dx = torch.empty_like(x2)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b)
+        ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+        check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
+                                   _ptr(db), rows, C, ctx.relu, _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+        return dx.reshape(ctx.shape), dw, db, None, None
+
+
+def layernorm(x, w, b, eps=1e-5, relu=False):
+    return _LayerNorm.apply(x, w, b, eps, relu)
+
+
+class _PosFuse(torch.autograd.Function):
+    """y = GroupNorm1(x + add) * (1 + gamma) + beta on [N*T, PF] frames (ref submodules.py:432-454)."""
+
+    @staticmethod
+    def forward(ctx, x, add, beta, gamma, N, T):
+        _chk(x, add, beta, gamma)
+        x = _c(x)
+        F_, PF = N * T, x.numel() // (N * T)
+        beta = _c(beta)
+        add_c = None if add is None else _c(add)
+        gamma_c = None if gamma is None else _c(gamma)
+        y = torch.empty_like(x)
+        mean = torch.empty(F_, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add_c), _ptr(beta), _ptr(gamma_c), _ptr(y), _ptr(mean), _ptr(rstd), N, T,
+                                     PF, 1e-5, _stream()), "npvp_posfuse_fwd")
+        ctx.save_for_backward(x, add_c, gamma_c, mean, rstd)
+        ctx.N, ctx.T, ctx.PF = N, T, PF
+        ctx.beta_shape = beta.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, add, gamma, mean, rstd = ctx.saved_tensors
+        N, T, PF = ctx.N, ctx.T, ctx.PF
+        dy = _c(dy)
+        du = torch.empty_like(x)
+        dyxh = torch.empty_like(x) if (gamma is not None and ctx.needs_input_grad[3]) else None
+        ws, wsn = _ws(8 * N * T, x.device)
+        check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(du),
+                                     _ptr(dyxh), N, T, PF, _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
+        dadd = dbeta = dgamma = None
+        if add is not None and ctx.needs_input_grad[1]:
+            dadd = reduce_mid(du.view(N, T, PF)).view(add.shape)
+        if ctx.needs_input_grad[2]:
+            dbeta = reduce_mid(dy.view(1, N, T * PF)).view(ctx.beta_shape)
+        if dyxh is not None:
+            dgamma = reduce_mid(dyxh.view(1, N, T * PF)).view(gamma.shape)
+        return du, dadd, dbeta, dgamma, None, None
+
+
+def posfuse(x, add, beta, gamma, N, T):
+    return _PosFuse.apply(x, add, beta, gamma, N, T)
+
+
+class _Linear(torch.autograd.Function):
+    """y = residual + drop(x w^T + b): nn.Linear / 1x1 conv / MHA projections with the residual add
+    and the dropout / drop-path that follows them in the reference fused into the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, drop):
+        _chk(x, w, b, residual)
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0:
+            x2 = x2.contiguous()
+        w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0) else w.contiguous()
+        r2 = None if residual is None else _c(residual).reshape(-1, w.shape[0])
+        y = linear_fwd(x2, w, b, residual=r2, drop=drop)
+        ctx.save_for_backward(x2, w)
+        ctx.drop, ctx.has_b, ctx.has_r, ctx.xshape = drop, b is not None, residual is not None, x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        N = w.shape[0]
+        dy2 = _c(dy).reshape(-1, N)
+        dz = drop_apply(dy2, ctx.drop) if ctx.drop.on else dy2
+        dx = linear_dgrad(dz, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dz, x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dres = dy if ctx.has_r else None
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, b=None, residual=None, drop=NO_DROP):
+    return _Linear.apply(x, w, b, residual, drop)
+
+
+class _FFN(torch.autograd.Function):
+    """out = x + drop3(linear2(drop2(GELU(linear1(xn)))))  (ref/models/VidHRFormer.py:110-112,224-226):
+    two GEMMs; bias+GELU+dropout and bias+dropout+residual live in their epilogues, and in backward the
+    GELU'/dropout product is the epilogue of the dgrad GEMM."""
+
+    @staticmethod
+    def forward(ctx, xn, x, w1, b1, w2, b2, p):
+        _chk(xn, x, w1, b1, w2, b2)
+        C = xn.shape[-1]
+        xn2, x2 = _c(xn).reshape(-1, C), _c(x).reshape(-1, C)
+        R, Fh = xn2.shape[0], w1.shape[0]
+        d2, d3 = Drop(p), Drop(p)
+        h = torch.empty(R, Fh, dtype=torch.float32, device=xn.device)
+        a = linear_fwd(xn2, w1, b1, act=1, aux_out=h, drop=d2)
+        y = linear_fwd(a, w2, b2, residual=x2, drop=d3)
+        ctx.save_for_backward(xn2, h, a, w1, w2)
+        ctx.d2, ctx.d3, ctx.shape = d2, d3, x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn2, h, a, w1, w2 = ctx.saved_tensors
+        C = xn2.shape[1]
+        dy2 = _c(dy).reshape(-1, C)
+        dz2 = drop_apply(dy2, ctx.d3) if ctx.d3.on else dy2
+        dw2 = linear_wgrad(dz2, a)
+        db2 = colsum(dz2)
+        dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)
+        dw1 = linear_wgrad(dh, xn2)
+        db1 = colsum(dh)
+        dxn = linear_dgrad(dh, w1)
+        return dxn.reshape(ctx.shape), dy, dw1, db1, dw2, db2, None
+
+
+def ffn(xn, x, w1, b1, w2, b2, p):
+    return _FFN.apply(xn, x, w1, b1, w2, b2, p)
+
+
+class AttnCfg:
+    __slots__ = ("mode", "dim0", "P", "W", "ws", "Tq", "Tk", "heads", "mask_mode", "drop")
+
+    def __init__(self, mode, dim0, P, W, ws, Tq, Tk, heads, mask_mode, p_drop):
+        self.mode, self.dim0, self.P, self.W, self.ws, self.Tq, self.Tk = mode, dim0, P, W, ws, Tq, Tk
+        self.heads, self.mask_mode = heads, mask_mode
+        self.drop = Drop(p_drop)
+
+
+def _attn_fwd(q, k, v, o, cfg):
+    hd = o.shape[1] // cfg.heads
+    seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    check(lib().npvp_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
+                              cfg.mode, cfg.dim0, cfg.P, cfg.W, cfg.ws, cfg.Tq, cfg.Tk, cfg.heads, hd, cfg.mask_mode,
+                              cfg.drop.p, _ptr(seed), cfg.drop.salt, _stream()), "npvp_attn_fwd")
+
+
+def _attn_bwd(q, k, v, go, dq, dk, dv, cfg):
+    hd = go.shape[1] // cfg.heads
+    seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    check(lib().npvp_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(go), go.stride(0),
+                              _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), cfg.mode, cfg.dim0,
+                              cfg.P, cfg.W, cfg.ws, cfg.Tq, cfg.Tk, cfg.heads, hd, cfg.mask_mode, cfg.drop.p, _ptr(seed),
+                              cfg.drop.salt, _stream()), "npvp_attn_bwd")
+
+
+class _AttnPacked(torch.autograd.Function):
+    """Self-attention core on a packed [R, 2C] q|k projection and a [R, C] v projection."""
+
+    @staticmethod
+    def forward(ctx, qk, v, cfg):
+        _chk(qk, v)
+        C = v.shape[1]
+        o = torch.empty_like(v)
+        _attn_fwd(qk[:, :C], qk[:, C:], v, o, cfg)
+        ctx.save_for_backward(qk, v)
+        ctx.cfg = cfg
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qk, v = ctx.saved_tensors
+        C = v.shape[1]
+        go = _c(go)
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        _attn_bwd(qk[:, :C], qk[:, C:], v, go, dqk[:, :C], dqk[:, C:], dv, ctx.cfg)
+        return dqk, dv, None
+
+
+class _Attn(torch.autograd.Function):
+    """Attention core with separate q [Rq,C], k [Rk,C], v [Rk,C] (the enc-dec site)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cfg):
+        _chk(q, k, v)
+        o = torch.empty_like(q)
+        _attn_fwd(q, k, v, o, cfg)
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = cfg
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v = ctx.saved_tensors
+        go = _c(go)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _attn_bwd(q, k, v, go, dq, dk, dv, ctx.cfg)
+        return dq, dk, dv, None
+
+
+def attn_packed(qk, v, cfg):
+    return _AttnPacked.apply(qk, v, cfg)
+
+
+def attn(q, k, v, cfg):
+    return _Attn.apply(q, k, v, cfg)
+
+
+class _FrameLnAct(torch.autograd.Function):
+    """out = res + droppath_n(drop(GELU(LayerNorm((Ch,H,W))(h))))   (ref VidHRFormer.py:381-382,384-386,388-390)"""
+
+    @staticmethod
+    def forward(ctx, h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample):
+        _chk(h, w_cl, b_cl, res)
+        h = _c(h)
+        PF = h.numel() // frames
+        w_cl, b_cl = _c(w_cl), _c(b_cl)
+        res_c = None if res is None else _c(res)
+        L = lib()
+        mean = torch.empty(frames, dtype=torch.float32, device=h.device)
+        rstd = torch.empty_like(mean)
+        check(L.npvp_frame_stats(_ptr(h), _p(0), _ptr(mean), _ptr(rstd), frames, 1, PF, 1e-5, _stream()), "npvp_frame_stats")
+        d, dp = Drop(p_drop), Drop(p_dp, 1)
+        out = torch.empty_like(h)
+        seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        check(L.npvp_frameln_act_fwd(_ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(res_c), _ptr(out), frames,
+                                     PF, d.p, d.salt, dp.p, dp.salt, frames_per_sample, _ptr(seed), _stream()),
+              "npvp_frameln_act_fwd")
+        ctx.save_for_backward(h, mean, rstd, w_cl, b_cl)
+        ctx.cfg = (frames, PF, d, dp, frames_per_sample, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, mean, rstd, w_cl, b_cl = ctx.saved_tensors
+        frames, PF, d, dp, fps, has_res = ctx.cfg
+        dout = _c(dout)
+        L = lib()
+        dh = torch.empty_like(h)
+        dw, db = torch.empty_like(w_cl), torch.empty_like(b_cl)
+        ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), h.device)
+        seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(dh), _ptr(dw),
+                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), _ptr(ws), wsn,
+                                     _stream()), "npvp_frameln_act_bwd")
+        return dh, dw, db, (dout if has_res else None), None, None, None, None
+
+
+def frameln_act(h, w_cl, b_cl, res, frames, p_drop=0.0, p_dp=0.0, frames_per_sample=1):
+    return _FrameLnAct.apply(h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample)
+
+
+class _DwConv(torch.autograd.Function):
+    """Depthwise 3x3 on [F, H*W, Ch]; wtb = [10, Ch]: 9 tap-major weight rows + the bias row."""
+
+    @staticmethod
+    def forward(ctx, a, wtb, frames, H, W):
+        _chk(a, wtb)
+        a, wtb = _c(a), _c(wtb)
+        Ch = wtb.shape[1]
+        out = torch.empty_like(a)
+        check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), frames, H, W, Ch, 0, _stream()),
+              "npvp_dwconv3x3")
+        ctx.save_for_backward(a, wtb)
+        ctx.cfg = (frames, H, W, Ch)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, wtb = ctx.saved_tensors
+        frames, H, W, Ch = ctx.cfg
+        dout = _c(dout)
+        L = lib()
+        da = torch.empty_like(a)
+        check(L.npvp_dwconv3x3(_ptr(dout), _ptr(wtb), _p(0), _ptr(da), frames, H, W, Ch, 1, _stream()), "npvp_dwconv3x3(bwd)")
+        dwtb = torch.empty_like(wtb)
+        ws, wsn = _ws(L.npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), a.device)
+        check(L.npvp_dwconv3x3_wgrad(_ptr(a), _ptr(dout), _ptr(dwtb), frames, H, W, Ch, _ptr(ws), wsn, _stream()),
+              "npvp_dwconv3x3_wgrad")
+        return da, dwtb, None, None, None
+
+
+def dwconv3x3(a, wtb, frames, H, W):
+    return _DwConv.apply(a, wtb, frames, H, W)
+
+
+def nchw_to_canonical(x):
+    """(N,T,C,H,W) -> canonical [N*T, H*W, C]"""
+    N, T, C, H, W = x.shape
+    return _Transpose.apply(x.reshape(N * T, C, H * W))
+
+
+def canonical_to_nchw(x, N, T, H, W):
+    """[N*T, H*W, C] -> (N,T,C,H,W)"""
+    C = x.shape[-1]
+    return _Transpose.apply(x.reshape(N * T, H * W, C)).reshape(N, T, C, H, W)
+
+
+def mean_mid(x):
+    return _MeanMid.apply(x)

@@ -1,0 +1,179 @@
+"""Stage-2 training step of the reference (LitPredictor.training_step_no_gan + shared_step +
+configure_optimizers, ref/models/Predictor.py:124-148,172-194,196-218) without Lightning:
+
+    zero_grad -> predictor(feats[, gt feats]) -> KL -> [frozen decoder -> image L1] -> feature L1
+    -> backward -> clip_grad_norm_(predictor.transformer, 1.0) -> AdamW(lr 1e-4) -> cosine warm restarts
+
+The clip + AdamW run as two kernels over FLAT parameter / gradient buffers (npvp_grad_norm_clip,
+npvp_adamw_step); the flat gradient buffer is also what the data-parallel all-reduce buckets
+(npvp_amd.dp) slice, so gradients are never copied.
+"""
+import math
+
+import torch
+import yaml
+
+from . import ops
+from ._lib import lib, check
+from .models.criterion import L1Loss, Div_KL
+
+
+class FlatBuffers:
+    """Re-point a module's parameters at slices of ONE flat fp32 buffer and their .grad at slices of a
+    second one.  The parameters of `tail_module` are laid out last, so they form a contiguous range.
+    Device agnostic (the data-parallel bucket logic is exercised on CPU/gloo); the optimiser kernels
+    that consume the buffers are HIP only."""
+
+    def __init__(self, module, tail_module=None):
+        params = [p for p in module.parameters() if p.requires_grad]
+        tail_ids = {id(p) for p in tail_module.parameters()} if tail_module is not None else set()
+        ordered = [p for p in params if id(p) not in tail_ids] + [p for p in params if id(p) in tail_ids]
+        dev = params[0].device
+        pad = lambda n: (n + 3) // 4 * 4          # keep every slice 16-byte aligned
+        total = sum(pad(p.numel()) for p in ordered)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params, self.offsets = ordered, []
+        off, tail_begin = 0, None
+        with torch.no_grad():
+            for p in ordered:
+                n = p.numel()
+                if tail_begin is None and id(p) in tail_ids:
+                    tail_begin = off
+                self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                self.offsets.append((off, n))
+                off += pad(n)
+        self.total = total
+        self.tail_begin = tail_begin if tail_begin is not None else total
+        self.tail_end = total
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, (off, n) in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2, ref Predictor.py:197)
+    on one flat fp32 buffer (FlatBuffers).  The parameters of `clip_module` (the decoder
+    `predictor.transformer`, ref :135 - which includes the LayerNorm it shares with the encoder) are laid
+    out last so the clip_grad_norm_ range is contiguous."""
+
+    def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_module=None,
+                 max_grad_norm=1.0):
+        self.buf = FlatBuffers(module, clip_module)
+        if not self.buf.flat_p.is_cuda:
+            raise RuntimeError("FlatAdamW needs the module on an MI355X device (no CPU fallback)")
+        dev = self.buf.flat_p.device
+        self.flat_p, self.flat_g, self.total = self.buf.flat_p, self.buf.flat_g, self.buf.total
+        self.params, self.offsets = self.buf.params, self.buf.offsets
+        self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.clip_begin, self.clip_end = (self.buf.tail_begin, self.buf.tail_end) if clip_module is not None else (0, 0)
+        self.max_grad_norm = max_grad_norm
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.hyper = torch.tensor([lr, 0.0], dtype=torch.float32, device=dev)      # {lr, step}
+        self.clip = torch.zeros(2, dtype=torch.float32, device=dev)                # {norm, coefficient}
+        self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self.param_groups = [{"lr": lr}]
+
+    def zero_grad(self, set_to_none=False):
+        self.buf.zero_grad()
+
+    def set_lr(self, lr):
+        self.hyper[0:1].fill_(lr)
+        self.param_groups[0]["lr"] = lr
+
+    def step(self):
+        L, P = lib(), ops._p
+        s = P(torch.cuda.current_stream().cuda_stream)
+        self.hyper[1:2].add_(1.0)
+        clip_ptr = P(0)
+        if self.clip_end > self.clip_begin and self.max_grad_norm is not None:
+            g = self.flat_g[self.clip_begin:self.clip_end]
+            check(L.npvp_grad_norm_clip(P(g.data_ptr()), g.numel(), float(self.max_grad_norm), P(self.clip.data_ptr()),
+                                        P(self._ws.data_ptr()), self._ws.numel() * 4, s), "npvp_grad_norm_clip")
+            clip_ptr = P(self.clip.data_ptr())
+        check(L.npvp_adamw_step(P(self.flat_p.data_ptr()), P(self.flat_g.data_ptr()), P(self.m.data_ptr()),
+                                P(self.v.data_ptr()), self.total, P(self.hyper.data_ptr()), self.betas[0], self.betas[1],
+                                self.eps, self.weight_decay, clip_ptr, self.clip_begin, self.clip_end, 1, s),
+              "npvp_adamw_step")
+
+    def grad_norm(self):
+        """Total L2 norm of the clipped range measured by the last step() (device scalar)."""
+        return self.clip[0]
+
+
+def cosine_warm_restarts_lr(base_lr, eta_min, T_0, epoch_float):
+    """torch CosineAnnealingWarmRestarts(T_0, T_mult=1, eta_min).step(epoch + batch_idx/len) as the reference
+    calls it every iteration (ref/models/Predictor.py:144-148,213-215)."""
+    t_cur = math.fmod(epoch_float, T_0)
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / T_0)) / 2
+
+
+def build_predictor_from_cfg(cls, P, num_past, num_future, **overrides):
+    """Construct a Predictor the way LitPredictor.__init__ does (ref/models/Predictor.py:28-47) from the
+    `Predictor:` section of a reference YAML config."""
+    h = torch.linspace(0, P['max_H'] - 1, P['max_H'])
+    w = torch.linspace(0, P['max_W'] - 1, P['max_W'])
+    to = torch.linspace(0, num_past - 1, num_past)
+    tp = torch.linspace(num_past, num_past + num_future - 1, num_future)
+    assert P['max_T'] == num_past + num_future, "Incompatible max_T and clip length"
+    return cls(P['max_H'], P['max_W'], P['max_T'], h, w, to, tp, P['embed_dim'], P['fuse_method'],
+               P['param_free_norm_type'], P['evt_hidden_channels'], 1, P['stochastic'], P['transformer_layers'],
+               evt_former=P['evt_former'], learn_evt_token=False, evt_former_num_layers=P['evt_former_num_layers'],
+               rand_context=P['rand_context'], **overrides)
+
+
+def load_config(path, batch_size=None, num_past=None, num_future=None):
+    """Read a reference YAML (ref/configs/*.yaml; hydra is not needed: the reference uses the compose API
+    with no overrides, ref/train_Predictor_lightning.py:51-56) and apply the benchmark's overrides of
+    Dataset.batch_size / num_past_frames / num_future_frames / Predictor.max_T."""
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    D, P = cfg["Dataset"], cfg["Predictor"]
+    if batch_size is not None:
+        D["batch_size"] = batch_size
+    if num_past is not None:
+        D["num_past_frames"] = num_past
+    if num_future is not None:
+        D["num_future_frames"] = num_future
+    P["max_T"] = D["num_past_frames"] + D["num_future_frames"]
+    for k in ("predictor_lr", "scheduler_eta_min", "KL_beta", "lam_PF_L1", "max_grad_norm"):
+        P[k] = float(P[k])
+    return cfg
+
+
+def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0,
+                         frozen_dec=None, future_frames=None, sync=True, grad_sync=None):
+    """One optimisation step on frozen-encoder features (predictor-only flavour), or the full step when the
+    frozen decoder and the target frames are given.  `opt` must be a FlatAdamW.  With sync=False nothing is
+    read back (bench / graph capture) and device scalars are returned."""
+    dev = past_feats.device
+    ops.rng.begin_step(dev)
+    opt.max_grad_norm = max_grad_norm
+    opt.zero_grad()
+    if predictor.stochastic:
+        pred, mu_o, lv_o, mu_p, lv_p = predictor(past_feats, future_feats)
+        kl = Div_KL(KL_beta)(mu_o, lv_o, mu_p, lv_p)
+    else:
+        pred = predictor(past_feats)
+        kl = torch.zeros((), dtype=torch.float32, device=dev)
+    pf = L1Loss(lam=lam_PF_L1)(pred, future_feats)
+    loss = pf + kl
+    img = None
+    if frozen_dec is not None:
+        img = L1Loss()(frozen_dec(pred), future_frames)
+        loss = loss + img
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish()        # every bucket reduced (side stream) before the clip needs the gradients
+    opt.step()
+    out = {"loss": loss.detach(), "PF_L1": pf.detach(), "KL": kl.detach(), "grad_norm": opt.grad_norm(),
+           "Image_L1": None if img is None else img.detach()}
+    if sync:
+        out = {k: (None if v is None else float(v)) for k, v in out.items()}
+    return out

@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel layer (npvp_amd.dp) is correct by construction -
+W ranks on shards of a global batch produce the gradients / BatchNorm statistics / parameters of one
+rank on the whole batch, with gradients reduced in place in the flat bucket buffer."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Net(nn.Module):
+    """Shaped like the predictor's coupling structure: a shared (tied) norm used twice, a BatchNorm head
+    (the EventEncoder), a `transformer` sub-module that forms the clip range, and an unused parameter."""
+
+    def __init__(self):
+        super().__init__()
+        norm = nn.LayerNorm(16)
+        self.enc = nn.Linear(16, 16)
+        self.enc_norm = norm
+        self.head = nn.Sequential(nn.Conv2d(4, 6, 3, 1, 1, bias=False), nn.BatchNorm2d(6), nn.ReLU(True))
+        self.transformer = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 16))
+        self.transformer.norm = norm
+        self.unused = nn.Parameter(torch.ones(5))
+
+    def forward(self, x, img):
+        h = self.enc_norm(self.enc(x))
+        z = self.head(img).mean(dim=(1, 2, 3), keepdim=False).unsqueeze(1)
+        return self.transformer.norm(self.transformer(h) + z)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from npvp_amd import dp
+    from npvp_amd.trainer import FlatBuffers
+    dp.init_distributed("gloo")
+    torch.manual_seed(0)
+    m = Net()
+    if rank != 0:                       # de-synchronise, then C3 broadcast must repair it
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(1.0)
+    dp.broadcast_module(m)
+    dp.convert_sync_batchnorm(m)
+    buf = FlatBuffers(m, m.transformer)
+    sync = dp.GradSync(buf, bucket_bytes=1024)       # tiny buckets: several per step
+    assert len(sync.buckets) >= 3
+    g = torch.Generator().manual_seed(1)
+    X, IMG = torch.randn(8, 16, generator=g), torch.randn(8, 4, 5, 5, generator=g)
+    x, img = dp.shard_batch(X, rank, world), dp.shard_batch(IMG, rank, world)
+    m.train()
+    for it in range(2):
+        buf.zero_grad()
+        y = m(x, img)
+        # loss = mean over the GLOBAL batch -> per-rank mean, gradients averaged by GradSync
+        (y ** 2).mean().backward()
+        sync.finish()
+    if rank == 0:
+        torch.save({"flat_g": buf.flat_g.clone(), "rm": m.head[1].running_mean.clone(), "rv": m.head[1].running_var.clone(),
+                    "tail": (buf.tail_begin, buf.tail_end), "launched": sync.launched}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process, whole batch
+    sys.path.insert(0, ROOT)
+    from npvp_amd.trainer import FlatBuffers
+    torch.manual_seed(0)
+    m = Net()
+    buf = FlatBuffers(m, m.transformer)
+    g = torch.Generator().manual_seed(1)
+    X, IMG = torch.randn(8, 16, generator=g), torch.randn(8, 4, 5, 5, generator=g)
+    m.train()
+    for it in range(2):
+        buf.zero_grad()
+        (m(X, IMG) ** 2).mean().backward()
+    assert torch.allclose(got["flat_g"], buf.flat_g, rtol=1e-4, atol=1e-6), (got["flat_g"] - buf.flat_g).abs().max()
+    assert torch.allclose(got["rm"], m.head[1].running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got["rv"], m.head[1].running_var, rtol=1e-4, atol=1e-6)
+    assert got["tail"] == (buf.tail_begin, buf.tail_end) and buf.tail_end - buf.tail_begin > 0
+    assert got["launched"] >= 6            # every bucket, both steps
+    # the tied norm sits in the clip (transformer) range, the unused parameter's gradient stays zero
+    assert float(m.unused.grad.abs().max()) == 0.0

@@ -1,0 +1,136 @@
+"""GPU: the HIP path (npvp_amd, through the C ABI) reproduces the golden vectors captured from the
+imported reference, and agrees with the oracle at larger / full BASELINE sizes.  Bar: 1e-3 rel fp32
+(BASELINE.json north_star); the fp32-MFMA GEMM path is held to 1e-4 here so regressions show early."""
+import pytest
+import torch
+
+import golden_cases as GC
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def impl():
+    import npvp_amd
+    assert torch.cuda.is_available()
+    return npvp_amd
+
+
+def test_posfuse(impl):
+    GC.compare(GC.case_posfuse(impl, DEV, "layer"), GC.load("posfuse_layer"), TOL)
+
+
+@pytest.mark.parametrize("fuse", ["Add", "SPADE"])
+def test_nrmlp(impl, fuse):
+    GC.compare(GC.case_nrmlp(impl, DEV, fuse), GC.load(f"nrmlp_{fuse}"), TOL)
+
+
+def test_slmhsa(impl):
+    GC.compare(GC.case_slmhsa(impl, DEV), GC.load("slmhsa"), TOL)
+
+
+def test_mlpdwbn(impl):
+    GC.compare(GC.case_mlpdwbn(impl, DEV), GC.load("mlpdwbn"), TOL)
+
+
+def test_block_enc_mask_quirk(impl):
+    GC.compare(GC.case_block_enc(impl, DEV), GC.load("block_enc"), TOL)
+
+
+def test_block_dec(impl):
+    GC.compare(GC.case_block_dec(impl, DEV), GC.load("block_dec"), TOL)
+
+
+def test_evtenc(impl):
+    GC.compare(GC.case_evtenc(impl, DEV), GC.load("evtenc"), TOL)
+
+
+def test_losses(impl):
+    GC.compare(GC.case_losses(impl, DEV), GC.load("losses"), TOL)
+
+
+@pytest.mark.parametrize("variant", ["D", "S"])
+def test_predictor(impl, variant):
+    GC.compare(GC.case_predictor(impl, DEV, variant), GC.load(f"predictor_{variant}"), TOL)
+
+
+@pytest.mark.parametrize("variant", ["D", "S"])
+def test_train_step(impl, variant):
+    mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+    res = GC.case_train_step(impl, DEV, variant, make_opt=mk)
+    g = GC.load(f"train_step_{variant}")
+    GC.compare({k: v for k, v in res.items() if k.endswith("_0")}, {k: v for k, v in g.items() if k.endswith("_0")}, TOL)
+    GC.compare({k: v for k, v in res.items() if k.endswith("_1")}, {k: v for k, v in g.items() if k.endswith("_1")}, 3e-3)
+
+
+def test_predictor_full_depth(impl):
+    GC.compare(GC.case_predictor_full(impl, DEV), GC.load("predictor_full_D"), TOL)
+
+
+def test_state_dict_roundtrip_with_oracle(impl):
+    """Same 603 keys: an oracle (= reference-layout) state dict loads into the HIP Predictor and back."""
+    import oracle
+    h = torch.linspace(0, 7, 8)
+    args = (8, 8, 5, h, h, torch.linspace(0, 1, 2), torch.linspace(2, 4, 3), 512, 'Add', 'layer', 256, 1, True, 1)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=1)
+    a, b = oracle.Predictor(*args, **kw), impl.Predictor(*args, **kw)
+    O.key_hashed_fill(a, 5)
+    b.load_state_dict(a.state_dict())
+    a.load_state_dict(b.state_dict())
+    assert b.EVT_Former.norm is b.transformer.norm
+
+
+@pytest.mark.parametrize("variant,N,To,Tp", [("S", 4, 5, 15), ("D", 2, 2, 18)])
+def test_against_oracle_larger(impl, variant, N, To, Tp):
+    """Full depth (4+8), c0-shaped (S, To=5, Tp=15) and c2'-shaped (D, To=2, Tp=18) clips: HIP vs oracle on
+    the same seeded inputs, forward (train mode, dropout 0) and input gradient."""
+    import oracle
+    stochastic = variant == "S"
+    h = torch.linspace(0, 7, 8)
+    to, tp = torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=4, dropout=0.0, drop_path=0.0)
+    args = (8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, stochastic, 8)
+    ref, hip = oracle.Predictor(*args, **kw), impl.Predictor(*args, **kw)
+    O.key_hashed_fill(ref, 7); O.key_hashed_fill(hip, 7)
+    hip = hip.to(DEV)
+    past, fut = O.synth_features((N, To, 512, 8, 8), 1), O.synth_features((N, Tp, 512, 8, 8), 2)
+    eps, cot = O.seeded_randn((N, 512, 8, 8), 3), O.seeded_randn((N, Tp, 512, 8, 8), 4)
+    outs = []
+    for m, d in ((ref, "cpu"), (hip, DEV)):
+        if stochastic:
+            e = eps.to(d)
+            m.evt_prior.eps_fn = m.evt_posterior.eps_fn = (lambda shape, e=e: e)
+        m.train()
+        p = past.to(d).requires_grad_()
+        o = m(p, fut.to(d)) if stochastic else m(p)
+        y = o[0] if stochastic else o
+        (y * cot.to(d)).sum().backward()
+        outs.append((y.detach().cpu(), p.grad.cpu(), m.transformer.norm.weight.grad.cpu()))
+    for a, b, n in zip(outs[1], outs[0], ["y", "g_past", "g_tied_norm"]):
+        e = GC.rel_err(a, b)
+        assert e < 1e-3, f"{n}: {e:.3e}"
+        assert e < TOL * 5, f"{n}: {e:.3e} (fp32 path regression)"
+
+
+def test_full_size_properties(impl):
+    """BASELINE c1 size (KTH NPVP-S, B=32, To=Tp=10, dropout 0.1 / drop-path 0.1 active): one training step runs,
+    output is finite, non-negative (final ReLU), gradients finite, loss decreases over a few steps on a fixed batch,
+    and eval mode is deterministic."""
+    torch.manual_seed(0)
+    h = torch.linspace(0, 7, 8)
+    m = impl.Predictor(8, 8, 20, h, h, torch.linspace(0, 9, 10), torch.linspace(10, 19, 10), 512, 'Add', 'layer', 256, 1,
+                       True, 8, evt_former=True, learn_evt_token=False, evt_former_num_layers=4).to(DEV)
+    opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer)
+    past, fut = O.synth_features((32, 10, 512, 8, 8), 1).to(DEV), O.synth_features((32, 10, 512, 8, 8), 2).to(DEV)
+    m.train()
+    losses = [impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-8, 1.0)["loss"] for _ in range(4)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(opt.flat_g).all())
+    m.eval()
+    with torch.no_grad():
+        y1, y2 = m(past), m(past)
+    assert torch.equal(y1, y2) and bool((y1 >= 0).all()) and y1.shape == (32, 10, 512, 8, 8)

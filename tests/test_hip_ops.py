@@ -1,0 +1,314 @@
+"""GPU parity tests, one HIP kernel family at a time, against the CPU oracle (oracle/ops.py) on
+the same seeded inputs - forward values and every gradient.  All calls go through the C ABI of
+libnpvp_hip.so (npvp_amd.ops -> ctypes).  Tolerances: the fp32-MFMA path is expected to agree to
+~1e-6; the bar written here (1e-4 rel-L2, 1e-3 for long reductions) sits inside the 1e-3 rel fp32
+bar of BASELINE.json's north_star."""
+import math
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def close(a, b, tol=TOL, what=""):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = rel(a, b)
+    assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
+
+
+@pytest.fixture(scope="module")
+def K():
+    import npvp_amd
+    from npvp_amd import ops
+    assert torch.cuda.is_available()
+    ops.rng.manual_seed(1234, torch.device(DEV))
+    return ops
+
+
+def g(t):
+    return t.to(DEV).requires_grad_(t.requires_grad)
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 32), (256, 512, 512), (160, 96, 64), (20, 36, 32), (1024, 2048, 512),
+                                    (640, 512, 2048), (2080, 224, 96)])
+def test_gemm_forward_variants(K, M, N, K_):
+    x = O.seeded_randn((M, K_), 1); w = O.seeded_randn((N, K_), 2) / math.sqrt(K_); b = O.seeded_randn((N,), 3)
+    r = O.seeded_randn((M, N), 4)
+    xg, wg, bg, rg = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    close(K.linear_fwd(xg, wg, None), x @ w.T, what="plain")
+    close(K.linear_fwd(xg, wg, bg), x @ w.T + b, what="bias")
+    aux = torch.empty(M, N, device=DEV)
+    y = K.linear_fwd(xg, wg, bg, act=1, aux_out=aux)
+    close(aux, x @ w.T + b, what="aux"); close(y, O.gelu(x @ w.T + b), what="gelu")
+    close(K.linear_fwd(xg, wg, bg, act=2, residual=rg), torch.relu(x @ w.T + b) + r, what="relu+res")
+    # dgrad: dx = dy @ w ; with GELU' epilogue (the reduction dim N must be a multiple of 32)
+    dy = O.seeded_randn((M, N), 5)
+    if N % 32 == 0:
+        close(K.linear_dgrad(dy.to(DEV), wg), dy @ w, what="dgrad")
+        hpre = O.seeded_randn((M, K_), 6)
+        hp = hpre.clone().requires_grad_()
+        (O.gelu(hp) * (dy @ w)).sum().backward()
+        close(K.linear_dgrad(dy.to(DEV), wg, act=3, aux_in=hpre.to(DEV)), hp.grad, what="dgrad*gelu'")
+    # wgrad: dw = dy^T x  (the reduction dim = token rows, a multiple of 64 on the path)
+    if M % 32 == 0:
+        close(K.linear_wgrad(dy.to(DEV), xg), dy.T @ x, what="wgrad")
+
+
+def test_gemm_wgrad_splitk_long_reduction(K):
+    R, N, K_ = 8192, 512, 256
+    dy = O.seeded_randn((R, N), 7); x = O.seeded_randn((R, K_), 8)
+    from npvp_amd._lib import lib
+    assert lib().npvp_gemm_workspace_bytes(N, K_, R) > 0, "expected the split-K path for this shape"
+    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=1e-5, what="split-K wgrad")
+    close(K.colsum(dy.to(DEV)), dy.sum(0), tol=1e-5, what="colsum")
+
+
+def test_gemm_full_size_against_rocblas(K):
+    """BASELINE c1 sizes (R = 32*10*64 = 20480 rows): a fast independent check of the big GEMM shapes."""
+    R = 20480
+    for N, K_ in ((2048, 512), (512, 2048), (1024, 512), (512, 512)):
+        x = torch.randn(R, K_, device=DEV); w = torch.randn(N, K_, device=DEV) / math.sqrt(K_)
+        y = K.linear_fwd(x, w, None)
+        ref = (x.double() @ w.double().T).float()
+        close(y, ref, tol=1e-5, what=f"fwd {N}x{K_}")
+        dy = torch.randn(R, N, device=DEV)
+        close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=1e-5, what=f"wgrad {N}x{K_}")
+        close(K.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=1e-5, what=f"dgrad {N}x{K_}")
+    # linearity (size-independent property): f(a x1 + x2) = a f(x1) + f(x2)
+    x1, x2 = torch.randn(R, 512, device=DEV), torch.randn(R, 512, device=DEV)
+    w = torch.randn(512, 512, device=DEV) / 22.6
+    close(K.linear_fwd(2.5 * x1 + x2, w, None), 2.5 * K.linear_fwd(x1, w, None) + K.linear_fwd(x2, w, None), tol=1e-5)
+
+
+def test_linear_autograd(K):
+    x = O.seeded_randn((3, 64, 512), 11).requires_grad_(); w = (O.seeded_randn((256, 512), 12) / 22.0).requires_grad_()
+    b = O.seeded_randn((256,), 13).requires_grad_(); r = O.seeded_randn((3, 64, 256), 14).requires_grad_()
+    cot = O.seeded_randn((3, 64, 256), 15)
+    y = torch.nn.functional.linear(x, w, b) + r
+    gx, gw, gb, gr = torch.autograd.grad((y * cot).sum(), [x, w, b, r])
+    xg, wg, bg, rg = g(x.detach().requires_grad_()), g(w.detach().requires_grad_()), g(b.detach().requires_grad_()), g(r.detach().requires_grad_())
+    yg = K.linear(xg, wg, bg, residual=rg)
+    hx, hw, hb, hr = torch.autograd.grad((yg * cot.to(DEV)).sum(), [xg, wg, bg, rg])
+    close(yg, y); close(hx, gx); close(hw, gw); close(hb, gb); close(hr, gr)
+
+
+def test_ffn(K):
+    R, C, Fh = 384, 512, 1024
+    xn = O.seeded_randn((R, C), 21).requires_grad_(); x = O.seeded_randn((R, C), 22).requires_grad_()
+    w1 = (O.seeded_randn((Fh, C), 23) / 22).requires_grad_(); b1 = (0.1 * O.seeded_randn((Fh,), 24)).requires_grad_()
+    w2 = (O.seeded_randn((C, Fh), 25) / 32).requires_grad_(); b2 = (0.1 * O.seeded_randn((C,), 26)).requires_grad_()
+    cot = O.seeded_randn((R, C), 27)
+    y = x + O.linear(O.gelu(O.linear(xn, w1, b1)), w2, b2)
+    ref = torch.autograd.grad((y * cot).sum(), [xn, x, w1, b1, w2, b2])
+    ins = [g(t.detach().requires_grad_()) for t in (xn, x, w1, b1, w2, b2)]
+    yg = K.ffn(*ins, 0.0)
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), ins)
+    close(yg, y)
+    for a, b_, n in zip(got, ref, ["dxn", "dx", "dw1", "db1", "dw2", "db2"]):
+        close(a, b_, what=n)
+
+
+# ------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,relu", [(64, False), (1000, True), (4099, False)])
+def test_layernorm(K, rows, relu):
+    x = O.seeded_randn((rows, 512), 31).requires_grad_()
+    w = (1 + 0.1 * O.seeded_randn((512,), 32)).requires_grad_(); b = (0.1 * O.seeded_randn((512,), 33)).requires_grad_()
+    cot = O.seeded_randn((rows, 512), 34)
+    y = O.layernorm(x, w, b)
+    y = torch.relu(y) if relu else y
+    ref = torch.autograd.grad((y * cot).sum(), [x, w, b])
+    ins = [g(t.detach().requires_grad_()) for t in (x, w, b)]
+    yg = K.layernorm(ins[0], ins[1], ins[2], 1e-5, relu)
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), ins)
+    close(yg, y)
+    for a, b_, n in zip(got, ref, ["dx", "dw", "db"]):
+        close(a, b_, what=n)
+
+
+@pytest.mark.parametrize("with_add,with_gamma", [(False, False), (True, False), (True, True)])
+def test_posfuse(K, with_add, with_gamma):
+    N, T, P, C = 3, 4, 64, 512
+    x = (0.5 + O.seeded_randn((N * T, P, C), 41)).requires_grad_()
+    add = O.seeded_randn((N, P, C), 42).requires_grad_() if with_add else None
+    beta = O.seeded_randn((T * P, C), 43).requires_grad_()
+    gamma = (0.3 * O.seeded_randn((T * P, C), 44)).requires_grad_() if with_gamma else None
+    cot = O.seeded_randn((N * T, P, C), 45)
+    y = O.posfuse(x, T, beta, gamma, add)
+    leaves = [t for t in (x, add, beta, gamma) if t is not None]
+    ref = torch.autograd.grad((y * cot).sum(), leaves)
+    gl = {id(t): g(t.detach().requires_grad_()) for t in leaves}
+    get = lambda t: None if t is None else gl[id(t)]
+    yg = K.posfuse(get(x), get(add), get(beta), get(gamma), N, T)
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), [gl[id(t)] for t in leaves])
+    close(yg, y)
+    for a, b_ in zip(got, ref):
+        close(a, b_)
+
+
+@pytest.mark.parametrize("Ch,with_res", [(2048, False), (512, True)])
+def test_frameln_act(K, Ch, with_res):
+    F_, P = 5, 64
+    h = (0.3 + O.seeded_randn((F_, P, Ch), 51)).requires_grad_()
+    w = (1 + 0.1 * O.seeded_randn((P, Ch), 52)).requires_grad_(); b = (0.1 * O.seeded_randn((P, Ch), 53)).requires_grad_()
+    res = O.seeded_randn((F_, P, Ch), 54).requires_grad_() if with_res else None
+    cot = O.seeded_randn((F_, P, Ch), 55)
+    y = O.gelu(O.frame_ln(h, w, b))
+    y = y + res if with_res else y
+    leaves = [t for t in (h, w, b, res) if t is not None]
+    ref = torch.autograd.grad((y * cot).sum(), leaves)
+    gl = [g(t.detach().requires_grad_()) for t in leaves]
+    yg = K.frameln_act(gl[0], gl[1].reshape(-1), gl[2].reshape(-1), gl[3] if with_res else None, F_)
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), gl)
+    close(yg, y)
+    for a, b_, n in zip(got, ref, ["dh", "dw", "db", "dres"]):
+        close(a.reshape(b_.shape), b_, what=n)
+
+
+def test_dwconv(K):
+    F_, H, W, Ch = 6, 8, 8, 256
+    a = O.seeded_randn((F_, H * W, Ch), 61).requires_grad_()
+    w = (0.3 * O.seeded_randn((Ch, 3, 3), 62)).requires_grad_(); b = (0.1 * O.seeded_randn((Ch,), 63)).requires_grad_()
+    cot = O.seeded_randn((F_, H * W, Ch), 64)
+    y = O.dwconv3x3(a, w, b, H, W)
+    ra, rw, rb = torch.autograd.grad((y * cot).sum(), [a, w, b])
+    ag = g(a.detach().requires_grad_())
+    wtb = torch.cat([w.detach().reshape(Ch, 9).t(), b.detach().reshape(1, Ch)], 0).contiguous().to(DEV).requires_grad_()
+    yg = K.dwconv3x3(ag, wtb, F_, H, W)
+    ga, gwtb = torch.autograd.grad((yg * cot.to(DEV)).sum(), [ag, wtb])
+    close(yg, y); close(ga, ra)
+    close(gwtb[:9].t().reshape(Ch, 3, 3), rw, what="dw"); close(gwtb[9], rb, what="db")
+
+
+# ------------------------------------------------------------------------------- attention cores
+def _attn_ref(q, k, v, rows_q, rows_k, mask):
+    return O.attn_core(q, k, v, rows_q, rows_k, 8, mask)
+
+
+@pytest.mark.parametrize("frames", [1, 3])
+def test_attn_spatial(K, frames):
+    from npvp_amd.ops import AttnCfg
+    R, C = frames * 64, 512
+    qk = O.seeded_randn((R, 2 * C), 71).requires_grad_(); v = O.seeded_randn((R, C), 72).requires_grad_()
+    cot = O.seeded_randn((R, C), 73)
+    rows = O.spatial_groups(frames, 8, 8, 4)
+    y = _attn_ref(qk[:, :C], qk[:, C:], v, rows, rows, None)
+    rqk, rv = torch.autograd.grad((y * cot).sum(), [qk, v])
+    qkg, vg = g(qk.detach().requires_grad_()), g(v.detach().requires_grad_())
+    yg = K.attn_packed(qkg, vg, AttnCfg(0, frames, 64, 8, 4, 0, 0, 8, 0, 0.0))
+    gqk, gv = torch.autograd.grad((yg * cot.to(DEV)).sum(), [qkg, vg])
+    close(yg, y); close(gqk, rqk, what="dqk"); close(gv, rv, what="dv")
+
+
+@pytest.mark.parametrize("Tq,Tk,mask", [(1, 1, 0), (2, 2, 1), (3, 3, 1), (10, 10, 1), (10, 10, 0), (17, 17, 1), (28, 28, 0),
+                                        (32, 32, 1), (4, 2, 0), (18, 2, 0), (10, 28, 0), (28, 10, 0)])
+def test_attn_temporal_and_cross(K, Tq, Tk, mask):
+    from npvp_amd.ops import AttnCfg
+    N, P, C = 2, 64, 512
+    q = O.seeded_randn((N * Tq * P, C), 81).requires_grad_()
+    k = O.seeded_randn((N * Tk * P, C), 82).requires_grad_(); v = O.seeded_randn((N * Tk * P, C), 83).requires_grad_()
+    cot = O.seeded_randn((N * Tq * P, C), 84)
+    m = O.encoder_temporal_mask(Tq) if mask else None
+    y = _attn_ref(q, k, v, O.temporal_groups(N, Tq, P), O.temporal_groups(N, Tk, P), m)
+    ref = torch.autograd.grad((y * cot).sum(), [q, k, v])
+    ins = [g(t.detach().requires_grad_()) for t in (q, k, v)]
+    yg = K.attn(ins[0], ins[1], ins[2], AttnCfg(1, N, P, 8, 0, Tq, Tk, 8, mask, 0.0))
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), ins)
+    close(yg, y)
+    for a, b_, n in zip(got, ref, ["dq", "dk", "dv"]):
+        close(a, b_, what=n)
+
+
+# ------------------------------------------------------------------------------- layout / reductions
+def test_transpose_and_mean(K):
+    x = O.seeded_randn((3, 4, 512, 8, 8), 91)
+    xc = K.nchw_to_canonical(x.to(DEV))
+    assert torch.equal(xc.cpu(), O.to_canonical(x))
+    assert torch.equal(K.canonical_to_nchw(xc, 3, 4, 8, 8).cpu(), x)
+    y = O.seeded_randn((3, 5, 1024), 92).requires_grad_()
+    yg = g(y.detach().requires_grad_())
+    m = K.mean_mid(yg)
+    close(m, y.mean(1), tol=1e-6)
+    (m * 2).sum().backward(); (y.mean(1) * 2).sum().backward()
+    close(yg.grad, y.grad, tol=1e-6)
+
+
+# ------------------------------------------------------------------------------- dropout (statistics + fwd/bwd replay)
+def test_dropout_statistics_and_replay(K):
+    from npvp_amd.ops import Drop
+    dev = torch.device(DEV)
+    R, N = 4096, 512
+    x = torch.ones(R, N, device=DEV)
+    d = Drop(0.1)
+    y = K.drop_apply(x, d)
+    keep = float((y != 0).float().mean())
+    assert abs(keep - 0.9) < 0.003, keep
+    assert abs(float(y.mean()) - 1.0) < 0.005
+    assert torch.equal(y, K.drop_apply(x, d)), "same (seed, salt) must replay the same mask"
+    assert not torch.equal(y, K.drop_apply(x, Drop(0.1))), "a new call site must draw a new mask"
+    # GEMM epilogue dropout is the same stream as drop_apply with the same site
+    w = torch.eye(N, device=DEV)
+    d2 = Drop(0.1)
+    assert torch.equal(K.linear_fwd(x, w, None, drop=d2) != 0, K.drop_apply(x, d2) != 0)
+    # per-sample drop-path: whole groups of g1 rows share one decision
+    dp = Drop(0.5, 1, 64, R // 64)
+    z = K.drop_apply(x, dp).view(R // 64, -1)
+    per = (z != 0).float().mean(1)
+    assert bool(((per == 0) | (per == 1)).all()) and 0.3 < float(per.mean()) < 0.7
+    # autograd replay: d/dx of sum(linear(x)) under dropout equals the forward mask pattern
+    K.rng.begin_step(dev)
+    xr = torch.randn(256, N, device=DEV, requires_grad=True)
+    yy = K.linear(xr, w, None, None, Drop(0.3))
+    (gx,) = torch.autograd.grad(yy.sum(), xr)
+    assert torch.equal(gx != 0, yy != 0)
+
+
+def test_attention_dropout_bwd_matches_finite_structure(K):
+    """With attention dropout on, backward must replay forward's mask: check dV against a forward-mode identity
+    (o is linear in v, so <cot, o(v)> = <dv, v>)."""
+    from npvp_amd.ops import AttnCfg
+    N, T, P, C = 1, 6, 64, 512
+    q = torch.randn(N * T * P, C, device=DEV); k = torch.randn(N * T * P, C, device=DEV)
+    v = torch.randn(N * T * P, C, device=DEV, requires_grad=True)
+    cot = torch.randn(N * T * P, C, device=DEV)
+    cfg = AttnCfg(1, N, P, 8, 0, T, T, 8, 0, 0.25)
+    o = K.attn(q, k, v, cfg)
+    (dv,) = torch.autograd.grad((o * cot).sum(), v)
+    lhs, rhs = float((o * cot).sum()), float((dv * v).sum())
+    assert abs(lhs - rhs) < 1e-3 * abs(lhs) + 1e-3, (lhs, rhs)
+
+
+# ------------------------------------------------------------------------------- optimiser
+def test_flat_adamw_matches_torch(K):
+    import npvp_amd
+    torch.manual_seed(0)
+    class M(torch.nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.a = torch.nn.Linear(37, 19); s.transformer = torch.nn.Linear(19, 23)
+    m1, m2 = M(), M()
+    m2.load_state_dict(m1.state_dict())
+    m2 = m2.to(DEV)
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-2)
+    o2 = npvp_amd.FlatAdamW(m2, lr=1e-2, clip_module=m2.transformer, max_grad_norm=0.5)
+    for it in range(3):
+        x = O.seeded_randn((8, 37), 100 + it)
+        o1.zero_grad(); o2.zero_grad()
+        (m1.transformer(m1.a(x)) ** 2).sum().backward()
+        (m2.transformer(m2.a(x.to(DEV))) ** 2).sum().backward()
+        n1 = torch.nn.utils.clip_grad_norm_(m1.transformer.parameters(), 0.5)
+        o1.step(); o2.step()
+        close(o2.grad_norm().reshape(()), n1.reshape(()), tol=1e-5, what="grad norm")
+        for (k1, p1), (k2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            close(p2, p1, tol=1e-5, what=f"step {it} {k1}")
