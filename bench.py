@@ -61,7 +61,12 @@ def cpu_baseline(cfg_file, To, Tp, clips=2, steps=2):
     host cores on a bounded sample of the same workload: `clips` clips of the same To/Tp, full depth."""
     import oracle
     from npvp_amd.trainer import load_config
-    cores = os.cpu_count() or 1
+    # the GPU box gives this job a 16-core share of a much larger host: more threads than that only thrash
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     cfg = load_config(os.path.join(ROOT, "configs", cfg_file), clips, To, Tp)
     P = cfg["Predictor"]
@@ -77,6 +82,11 @@ def cpu_baseline(cfg_file, To, Tp, clips=2, steps=2):
     return {"value": clips * (To + Tp) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{clips} clips x (To={To},Tp={Tp}), full-depth predictor train step, 1 warm-up + {steps} timed "
                       f"steps of the CPU oracle (torch {torch.__version__}, {dt:.2f} s/step)"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -108,6 +118,7 @@ def main():
         dp.broadcast_module(model)
         dp.convert_sync_batchnorm(model)
     model.train()
+    log(f"model built: {name}, {B} clips/GPU, To={To}, Tp={Tp}, world={world}")
     opt = npvp_amd.FlatAdamW(model, lr=P["predictor_lr"], clip_module=model.transformer, max_grad_norm=P["max_grad_norm"])
     gsync = dp.GradSync(opt.buf) if world > 1 else None
     ops.rng.manual_seed(cfg["Env"]["rand_seed"] + rank, dev)
@@ -130,6 +141,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     if not args.no_probe:
         ops.GemmProbe.arm(1, 1)
     fence()
@@ -139,6 +152,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.GemmProbe.disarm()
+    log(f"{args.steps} timed steps: {1000.0 * dt / args.steps:.2f} ms/step")
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
 
@@ -171,6 +185,7 @@ def main():
                           "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle on a bounded sample ...")
             res["cpu_baseline"] = cpu_baseline(cfg_file, To, Tp)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -37,7 +37,8 @@ def K():
 
 
 def g(t):
-    return t.to(DEV).requires_grad_(t.requires_grad)
+    """leaf copy on the device"""
+    return t.detach().to(DEV).requires_grad_(t.requires_grad)
 
 
 # ------------------------------------------------------------------------------- GEMM
