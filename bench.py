@@ -37,7 +37,11 @@ WORKLOADS = {   # name -> (config file, variant, per-GPU clips, To, Tp)
     "c3": ("config_Cityscapes_VFP_NPVP-S.yaml", "Cityscapes 128x128 NPVP-S (per-GPU shard)", 8, 2, 12),
     "c4": ("config_KITTI_VFP_NPVP-D.yaml", "KITTI 128x128 NPVP-D (per-GPU shard)", 8, 4, 16),
 }
-F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+# MI355X_MICROARCH.md dense matrix peaks: v_mfma_f32_32x32x2_f32 (fp32 in) and v_mfma_f32_32x32x16_bf16
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}
+KERNEL_NAME = {"f32": "gemm_f32_kernel<true,true> (forward GEMMs, v_mfma_f32_32x32x2_f32)",
+               "bf16x3": "gemm_bf16x3_kernel<true,true> (forward GEMMs; 3 x v_mfma_f32_32x32x16_bf16 per product: "
+                         "achieved = ALGORITHMIC fp32-equivalent flops, so frac <= 1/3 of the bf16 peak)"}
 
 
 def forward_macs_per_clip(To, Tp, stochastic):
@@ -95,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "f32"), choices=["f32", "bf16x3"],
+                    help="GEMM arithmetic: exact fp32 MFMA, or bf16x3 split-precision MFMA (fp32-accurate to ~1e-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     args = ap.parse_args()
@@ -103,6 +109,7 @@ def main():
     from npvp_amd import dp, ops
     from npvp_amd.trainer import load_config, cosine_warm_restarts_lr
 
+    ops.set_gemm_precision(args.gemm)
     rank, world, local = dp.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
@@ -169,16 +176,19 @@ def main():
         n, pms, pfl = ops.GemmProbe.summary()
         if n:
             ach = pfl / (pms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<true,true> (forward GEMMs, v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            peak = MFMA_PEAK_TFLOPS[args.gemm]
+            roof = {"bound": "mfma", "kernel": KERNEL_NAME[args.gemm],
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(1000.0 * pms / n, 2),
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
 
     if rank == 0:
         res = {"metric": "predictor train frames/sec", "value": round(frames / (ms * 1e-3), 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.gemm == "f32" else "f32 (bf16x3 split-precision MFMA, fp32 accumulate)",
+               "data": "synthetic",
                "config": {"workload": f"{name} predictor-only train step (features in HBM), {B} clips/GPU, To={To}, "
                                       f"Tp={Tp}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * B, "frames_per_clip": To + Tp, "parallelism": f"dp{world}",

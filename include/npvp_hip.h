@@ -38,14 +38,16 @@ const char* npvp_last_error(void);
  *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 multiply by GELU'(aux_in), 4 multiply by [aux_in > 0]
  *   drop_mode 0: per element; 1: per row group key=(row/drop_g1)%drop_g2 (DropPath)
  * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
+ * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1: bf16x3 split - operands are split on the
+ * fly into bf16 hi + lo and hi*hi + hi*lo + lo*hi is accumulated in fp32 on v_mfma_f32_32x32x16_bf16.
  * When the tile count is small and K large (weight gradients) the reduction is split over
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);
 int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B, long long ldb,
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
-                  const unsigned long long* seed, unsigned int salt, float alpha, void* workspace, long long ws_bytes,
-                  npvp_stream_t stream);
+                  const unsigned long long* seed, unsigned int salt, float alpha, int precision, void* workspace,
+                  long long ws_bytes, npvp_stream_t stream);
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.
@@ -85,6 +87,9 @@ int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, c
  * input gradient.  wgrad writes one contiguous [10][Ch] buffer: 9 taps then the bias gradient. */
 int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W, int Ch,
                    int flip, npvp_stream_t stream);
+/* im2col / col2im of the EventEncoder's dense 3x3 conv (ref/models/submodules.py:376), channels-last:
+ * col2im=0: in [F][H*W][C] -> out [F*H*W][9*C] (tap-major columns); col2im=1: the adjoint. */
+int npvp_im2col3x3(const float* in, float* out, int frames, int H, int W, int C, int col2im, npvp_stream_t stream);
 long long npvp_dwconv3x3_wgrad_workspace_bytes(int frames, int Ch);
 int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dwt_db, int frames, int H, int W, int Ch,
                          void* workspace, long long ws_bytes, npvp_stream_t stream);

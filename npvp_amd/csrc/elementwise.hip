@@ -188,7 +188,7 @@ extern "C" int npvp_broadcast_mid(const float* in, float* out, int A, int B, lon
   return NPVP_OK;
 }
 
-static int colsum_chunks(long long rows) { return (int)(rows < 512 ? rows : 512); }
+static int colsum_chunks(long long rows) { return (int)(rows < 128 ? rows : 128); }
 
 extern "C" long long npvp_colsum_workspace_bytes(long long rows, int N) { return (long long)colsum_chunks(rows) * N * 4; }
 

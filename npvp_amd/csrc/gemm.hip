@@ -96,18 +96,59 @@ template <> struct Stager<false> {  // source [K][rows], rows contiguous
   }
 };
 
+// ---- epilogue shared by both MFMA paths: C/D map of the 32x32 MFMA is col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
+                                              const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm, int wn,
+                                              int r, int h, int z) {
+  const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
+  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
+      const int col = n0 + wn * 64 + tn * 32 + r;
+      if (col >= p.N) continue;
+      const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        const long long idx = (long long)row * p.ldc + col;
+        float v = acc[g];
+        if (p.splits > 1) { Cz[idx] = v; continue; }
+        v = v * p.alpha + bv;
+        if (p.aux_out) p.aux_out[idx] = v;
+        if (p.act == 1) v = gelu_f(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
+        else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
+        if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
+        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+        Cz[idx] = v;
+      }
+    }
+  }
+}
+
+// XCD-aware, bijective tile remap (cdna guide T1): the 8 XCDs each walk a contiguous run of tiles
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int& n0) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = nid / p.tiles_n, tile_n = nid - tile_m * p.tiles_n;
+  m0 = tile_m * BM; n0 = tile_n * BN;
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int LDA = Stager<AKC>::LD, LDB = Stager<BKC>::LD;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
-  // XCD-aware, bijective tile remap (cdna guide T1)
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-  const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  const int tile_m = nid / p.tiles_n, tile_n = nid - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int m0, n0;
+  tile_of_block(p, m0, n0);
   const int z = blockIdx.y;
 
   // split-K: this block reduces k in [z*K, (z+1)*K)
@@ -154,36 +195,137 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
-  const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
-  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+}
+
+// =====================================================================================================
+// Split-precision path: every fp32 operand x is split on the fly into bf16 hi = rne(x) and lo = rne(x - hi)
+// and the product is accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (the lo*lo
+// term, ~2^-16 relative, is dropped).  3 bf16 MFMAs per fp32 MFMA-equivalent of 8x the k-depth: 16/3 = 5.3x the
+// fp32-MFMA rate, with ~2^-16 relative product error (measured end to end in tests: < 1e-4 on the full
+// predictor, vs the 1e-3 bar).  LDS image per operand and per precision half: [k/8][row][8 k] bf16, i.e. each
+// row's 8 consecutive k are one 16-byte slot, rows contiguous, (129 rows per k-group to skew banks): the MFMA
+// fragment of lane (row r, half h) is ONE conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int KG_STRIDE = 129 * 16;          // bytes between k-groups
+constexpr int OPER_BYTES = 4 * KG_STRIDE;    // one operand tile (128 rows x 32 k), one precision half
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+template <bool KC> struct SplitStager;
+
+template <> struct SplitStager<true> {     // source [rows][K]: thread = (row t/8 + 32 i, 4 k at (t%8)*4)
+  float4 r[4];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
+    const int t = threadIdx.x, kc = (t & 7) * 4;
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
-      const int col = n0 + wn * 64 + tn * 32 + r;
-      if (col >= p.N) continue;
-      const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (row >= p.M) continue;
-        const long long idx = (long long)row * p.ldc + col;
-        float v = acc[g];
-        if (p.splits > 1) { Cz[idx] = v; continue; }
-        v = v * p.alpha + bv;
-        if (p.aux_out) p.aux_out[idx] = v;
-        if (p.act == 1) v = gelu_f(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
-        else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
-        if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
-        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
-        Cz[idx] = v;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + (t >> 3) + 32 * i;
+      r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  __device__ __forceinline__ void store(char* hi, char* lo) const {
+    const int t = threadIdx.x, kc = t & 7;
+    const int off0 = (kc >> 1) * KG_STRIDE + (kc & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 3) + 32 * i;
+      bf16x4 h, l;
+      split4(r[i], h, l);
+      *reinterpret_cast<bf16x4*>(hi + off0 + row * 16) = h;
+      *reinterpret_cast<bf16x4*>(lo + off0 + row * 16) = l;
+    }
+  }
+};
+
+template <> struct SplitStager<false> {    // source [K][rows]: thread = (rows 2*(t%64), +1 ; k-group t/64), 8 float2 loads
+  float2 r[8];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
+    const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      r[j] = (row0 + rp < nrows) ? *reinterpret_cast<const float2*>(src + (long long)(k0 + kg * 8 + j) * ld + row0 + rp)
+                                 : make_float2(0.f, 0.f);
+  }
+  __device__ __forceinline__ void store(char* hi, char* lo) const {
+    const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
+    bf16x8 h0, l0, h1, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h0[j] = (__bf16)r[j].x; l0[j] = (__bf16)(r[j].x - (float)h0[j]);
+      h1[j] = (__bf16)r[j].y; l1[j] = (__bf16)(r[j].y - (float)h1[j]);
+    }
+    const int off = kg * KG_STRIDE + rp * 16;
+    *reinterpret_cast<bf16x8*>(hi + off) = h0; *reinterpret_cast<bf16x8*>(hi + off + 16) = h1;
+    *reinterpret_cast<bf16x8*>(lo + off) = l0; *reinterpret_cast<bf16x8*>(lo + off + 16) = l1;
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmParams p) {
+  // [buffer][A_hi | A_lo | B_hi | B_lo]
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * OPER_BYTES];
+  int m0, n0;
+  tile_of_block(p, m0, n0);
+  const int z = blockIdx.y;
+  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
+  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+  SplitStager<AKC> sa; SplitStager<BKC> sb;
+  const int nk = p.K / BK;
+  sa.load(A, p.lda, m0, p.M, 0);
+  sb.load(B, p.ldb, n0, p.N, 0);
+  sa.store(lds[0], lds[0] + OPER_BYTES);
+  sb.store(lds[0] + 2 * OPER_BYTES, lds[0] + 3 * OPER_BYTES);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK);
+      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK);
+    }
+    const char* a_hi = lds[cur] + h * KG_STRIDE + (wm * 64 + r) * 16;
+    const char* b_hi = lds[cur] + 2 * OPER_BYTES + h * KG_STRIDE + (wn * 64 + r) * 16;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {                     // two k16 steps per 32-deep tile; lane half h takes k-group 2kk+h
+      const int ko = kk * 2 * KG_STRIDE;
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a_hi + ko);
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a_hi + ko + 32 * 16);
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a_hi + OPER_BYTES + ko);
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a_hi + OPER_BYTES + ko + 32 * 16);
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b_hi + ko);
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b_hi + ko + 32 * 16);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(b_hi + OPER_BYTES + ko);
+      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(b_hi + OPER_BYTES + ko + 32 * 16);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      sa.store(lds[cur ^ 1], lds[cur ^ 1] + OPER_BYTES);
+      sb.store(lds[cur ^ 1] + 2 * OPER_BYTES, lds[cur ^ 1] + 3 * OPER_BYTES);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
@@ -228,10 +370,12 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
-                             void* workspace, long long ws_bytes, hipStream_t stream) {
+                             int precision, void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+  NPVP_CHECK_ARG(precision == 0 || precision == 1, "gemm: precision must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
+  NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
   NPVP_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm: A/B must be 16-byte aligned");
   NPVP_CHECK_ARG(!(a_kc == 0 && b_kc == 1), "gemm: (a_kc=0,b_kc=1) is not used by the path");
@@ -252,9 +396,15 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (splits > 1) { p.K = K / splits; p.C = (float*)workspace; p.ldc = N; }
 
   dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+  if (precision == 0) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+  } else {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, block, 0, stream, p);
+  }
   NPVP_CHECK_LAUNCH();
   if (splits > 1) {
     const long long total4 = (long long)M * N / 4;

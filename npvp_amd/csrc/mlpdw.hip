@@ -76,6 +76,41 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
   st4(o + 9 * Ch + c, ab);
 }
 
+// im2col for a 3x3 / pad 1 convolution over channels-last frames (EventEncoder conv2, ref/models/submodules.py:376):
+//   fwd (col2im = 0): out[(f,p)][tap*C + c] = in[f][p + off(tap)][c] (0 outside the grid)     in [F][P][C], out [F*P][9C]
+//   bwd (col2im = 1): out[f][q][c] = sum_tap in[(f, q - off(tap))][tap*C + c]                  in [F*P][9C], out [F][P][C]
+__global__ void im2col3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, long long total4,
+                                 int col2im) {
+  const int c4n = C / 4, P = H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    if (!col2im) {
+      const int c = (int)(i % c4n) * 4;
+      long long r = i / c4n;
+      const int tap = (int)(r % 9); r /= 9;                 // r = f*P + p
+      const int p = (int)(r % P);
+      const long long f = r / P;
+      const int h = p / W + tap / 3 - 1, w = p % W + tap % 3 - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h >= 0 && h < H && w >= 0 && w < W) v = ld4(in + (f * P + h * W + w) * C + c);
+      st4(out + r * 9 * C + (long long)tap * C + c, v);
+    } else {
+      const int c = (int)(i % c4n) * 4;
+      const long long r = i / c4n;                           // r = f*P + q
+      const int q = (int)(r % P);
+      const long long f = r / P;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int h = q / W - (tap / 3 - 1), w = q % W - (tap % 3 - 1);
+        if (h < 0 || h >= H || w < 0 || w >= W) continue;
+        const float4 v = ld4(in + (f * P + h * W + w) * 9 * C + (long long)tap * C + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      st4(out + r * C + c, s);
+    }
+  }
+}
+
 static int dw_chunks(int frames) { return frames < 256 ? frames : 256; }
 
 }  // namespace npvp
@@ -88,6 +123,15 @@ extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias
   const long long total4 = (long long)frames * H * W * Ch / 4;
   long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_im2col3x3(const float* in, float* out, int frames, int H, int W, int C, int col2im, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && C % 4 == 0, "im2col: bad shape");
+  const long long total4 = (long long)frames * H * W * (col2im ? 1 : 9) * C / 4;
+  long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, H, W, C, total4, col2im);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

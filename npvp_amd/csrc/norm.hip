@@ -117,13 +117,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     partial[(long long)blockIdx.x * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-// out[c] = sum_b in[b][c]   (small second stage of the column reductions)
-__global__ void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int nb, int stride, int ncols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
+// out[c] = sum_b in[b*stride + c]   (second stage of the column reductions).  A block owns 64 columns and
+// splits the nb partial rows over blockDim/64 row lanes (coalesced 256-B segments, LDS tree at the end).
+__global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int nb,
+                                                        int stride, int ncols) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6, nrl = blockDim.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += in[(long long)b * stride + c];
-  out[c] = s;
+  if (c < ncols)
+    for (int b = rl; b < nb; b += nrl) s += in[(long long)b * stride + c];
+  red[rl][cx] = s;
+  __syncthreads();
+  if (rl == 0 && c < ncols) {
+    float t = 0.f;
+    for (int i = 0; i < nrl; ++i) t += red[i][cx];
+    out[c] = t;
+  }
 }
 
 // ------------------------------------------------------------------ per-frame statistics
@@ -350,7 +360,9 @@ __global__ void frameln_act_bwd_params_kernel(FlnParams p, const float* __restri
 }
 
 int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream) {
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 255) / 256), dim3(256), 0, stream, in, out, nb, stride, ncols);
+  // few partial rows (frame-LN params: 32 x 131072) -> 4 row lanes; many (bias / LN column sums) -> 16
+  const int threads = nb >= 64 ? 1024 : 256;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 63) / 64), dim3(threads), 0, stream, in, out, nb, stride, ncols);
   return hipGetLastError() == hipSuccess ? NPVP_OK : NPVP_ERR_LAUNCH;
 }
 
@@ -419,10 +431,10 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, nb, 2 * C, C);
-  NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)part + C, db, nb, 2 * C, C);
-  NPVP_CHECK_LAUNCH();
+  if (launch_sum_rows((const float*)part, dw, nb, 2 * C, C, stream) || launch_sum_rows((const float*)part + C, db, nb, 2 * C, C, stream)) {
+    npvp_set_error("layernorm_bwd: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
   return NPVP_OK;
 }
 
@@ -507,11 +519,10 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   hipLaunchKernelGGL(frameln_act_bwd_params_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
                      dout, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((per_frame + 255) / 256), dim3(256), 0, stream, (const float*)part, dw, nchunks,
-                     2 * per_frame, per_frame);
-  NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((per_frame + 255) / 256), dim3(256), 0, stream,
-                     (const float*)part + per_frame, db, nchunks, 2 * per_frame, per_frame);
-  NPVP_CHECK_LAUNCH();
+  if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, per_frame, stream) ||
+      launch_sum_rows((const float*)part + per_frame, db, nchunks, 2 * per_frame, per_frame, stream)) {
+    npvp_set_error("frameln_act_bwd: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
   return NPVP_OK;
 }

@@ -52,30 +52,34 @@ class Predictor(nn.Module):
 
     # -- helpers on the canonical layout -------------------------------------------------------------
     def _encode(self, feats, pos):
-        """(N,T,C,H,W) features -> canonical encoder output (N,T,H,W,C) and event coding (N,C,H,W)."""
+        """(N,T,C,H,W) features -> canonical encoder output (N,T,H,W,C) and event coding [N, H*W, C] (mean over T)."""
         N, T, C, H, W = feats.shape
         x = ops.nchw_to_canonical(feats).view(N, T, H, W, C)
         x = self.EVT_Former.forward_canonical(x, pos, self.fuser)
-        evt = ops.mean_mid(x.view(N, T, H * W * C))                                   # mean over T, ref :346
-        evt = ops._Transpose.apply(evt.view(N, H * W, C)).view(N, C, H, W)
+        evt = ops.mean_mid(x.view(N, T, H * W * C)).view(N, H * W, C)                  # ref :346
         return x, evt
 
     def _decode(self, z, memory, op, pp):
-        N, C, H, W = z.shape
-        qe = ops._Transpose.apply(z.reshape(N, C, H * W)).view(N, H, W, C)
-        out = self.transformer.forward_canonical(qe, memory, op, pp, self.fuser, self.TP)
+        """z [N, H*W, C] canonical"""
+        N, T1, H, W, C = memory.shape
+        out = self.transformer.forward_canonical(z.view(N, H, W, C), memory, op, pp, self.fuser, self.TP)
         return ops.canonical_to_nchw(out, N, self.TP, H, W)
+
+    def _nchw(self, t):
+        N, P, C = t.shape
+        return ops._Transpose.apply(t).view(N, C, self.max_H, self.max_W)
 
     def forward(self, observed_features, predict_features_gt=None):
         """observed_features: (N, To, C, H, W) -> (N, Tp, C, H, W) [, mu_o, logvar_o, mu_p, logvar_p]"""
+        H, W = observed_features.shape[-2:]
         op = self._pos(self.observed_coor)
         pp = self._pos(self.predict_coor)
         memory, obs_evt = self._encode(observed_features, op)
         if self.stochastic:
-            zo, mu_o, logvar_o = self.evt_prior(obs_evt)
+            zo, mu_o, logvar_o = self.evt_prior.forward_canonical(obs_evt, H, W)
             if predict_features_gt is not None:
                 _, pred_evt = self._encode(predict_features_gt, pp)
-                zp, mu_p, logvar_p = self.evt_posterior(pred_evt)
+                zp, mu_p, logvar_p = self.evt_posterior.forward_canonical(pred_evt, H, W)
             if self.training:
                 assert predict_features_gt is not None, \
                     "please input groundtruth predict features for storchastic model training/val"
@@ -84,15 +88,15 @@ class Predictor(nn.Module):
                 out = self._decode(zo, memory, op, pp)
             if predict_features_gt is None:
                 return out
-            return out, mu_o, logvar_o, mu_p, logvar_p
-        mu_o = self.evt_posterior(obs_evt)
+            return out, self._nchw(mu_o), self._nchw(logvar_o), self._nchw(mu_p), self._nchw(logvar_p)
+        mu_o = self.evt_posterior.forward_canonical(obs_evt, H, W)
         return self._decode(mu_o, memory, op, pp)
 
     def evt_coding_forward(self, x, pos_beta, pos_gamma):
         """x (N,T,C,H,W) -> (encoder output (N,T,C,H,W), event coding (N,C,H,W))   ref :337-350"""
         N, T, C, H, W = x.shape
         mem, evt = self._encode(x, (pos_beta, pos_gamma))
-        return ops.canonical_to_nchw(mem, N, T, H, W), evt
+        return ops.canonical_to_nchw(mem, N, T, H, W), self._nchw(evt)
 
     def reset_pos_coor(self, to_list, tp_list):
         device = self.observed_coor.device

@@ -5,6 +5,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 
@@ -84,10 +85,26 @@ class PosFeatFuser(nn.Module):
         return ops.posfuse(x, add, pos_beta, pos_gamma, N, T).view(x.shape)
 
 
+def _bn_rows(x2, bn):
+    """BatchNorm2d semantics on channels-last rows x2 [R, C] (statistics over the R = N*H*W rows per channel).
+    Tiny tensors ((N*64) x 512): stock torch batch-norm kernels; under data parallelism `bn` has been swapped
+    for npvp_amd.dp.SyncBatchNorm2d and the statistics span all ranks."""
+    from ..dp import SyncBatchNorm2d, _SyncBNFn
+    import torch.distributed as dist
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    if isinstance(bn, SyncBatchNorm2d) and bn.training and dist.is_initialized() and dist.get_world_size() > 1:
+        return _SyncBNFn.apply(x2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True, None)
+    return F.batch_norm(x2, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+
+
 class EventEncoder(nn.Module):
-    """ref/models/submodules.py:368-410.  (N,512,8,8) in, 2 calls per step: stock PyTorch-ROCm convs /
-    BatchNorm (SURVEY K11 - not a kernel target).  Under data parallelism the BatchNorm layers are
-    swapped for npvp_amd.dp.SyncBatchNorm2d (the reference trains with sync_batchnorm=True)."""
+    """ref/models/submodules.py:368-410.  Same modules / state-dict keys (conv1.0, conv1.1, conv2.0, ...), but the
+    arithmetic runs channels-last on the canonical layout: the depthwise 3x3 is the MlpDWBN dwconv kernel, the dense
+    3x3 is im2col + the MFMA GEMM, the 1x1 convs are GEMMs (MIOpen's fallback for these shapes is a naive
+    direct-conv kernel that cost 10 % of a training step); BatchNorm + ReLU on the (N*64) x C rows stay stock torch
+    ops.  Under data parallelism the BatchNorm layers are npvp_amd.dp.SyncBatchNorm2d (the reference
+    trains with sync_batchnorm=True, ref/train_Predictor_lightning.py:41)."""
 
     def __init__(self, in_channels, hidden_channels, n_layers, stochastic):
         super().__init__()
@@ -105,17 +122,38 @@ class EventEncoder(nn.Module):
         self.mu_net = nn.Conv2d(hidden_channels, in_channels, 1, 1, bias=True)
         if stochastic:
             self.logvar_net = nn.Conv2d(hidden_channels, in_channels, 1, 1, bias=True)
-        self.eps_fn = None   # test hook: callable(shape) -> eps
+        self.eps_fn = None   # test hook: callable(shape (N,C,H,W)) -> eps
+
+    def forward_canonical(self, x, H, W):
+        """x [N, H*W, C] -> mu (and z, logvar) as [N, H*W, C]."""
+        N, P, C = x.shape
+        w1 = self.conv1[0].weight                                        # [C,1,3,3] depthwise, no bias
+        wtb = torch.cat([ops._Transpose.apply(w1.reshape(1, C, 9)).reshape(9, C), torch.zeros(1, C, device=x.device)], 0)
+        h = ops.dwconv3x3(x, wtb, N, H, W).reshape(N * P, C)
+        h = torch.relu(_bn_rows(h, self.conv1[1]))
+        w2 = self.conv2[0].weight                                        # [hid, C, 3, 3] -> tap-major [hid, 9*C]
+        cols = ops.im2col3x3(h.view(N, P, C), N, H, W)
+        h = ops.linear(cols, w2.permute(0, 2, 3, 1).reshape(w2.shape[0], 9 * C))
+        h = torch.relu(_bn_rows(h, self.conv2[1]))
+        for i in range(self.n_layers):
+            m = getattr(self, f'MLP_{i}')
+            h = torch.relu(_bn_rows(ops.linear(h, m[0].weight.flatten(1)), m[1]))
+        mu = ops.linear(h, self.mu_net.weight.flatten(1), self.mu_net.bias).view(N, P, C)
+        if not self.stochastic:
+            return mu
+        logvar = ops.linear(h, self.logvar_net.weight.flatten(1), self.logvar_net.bias).view(N, P, C)
+        if self.eps_fn is not None:
+            eps = ops.transpose(self.eps_fn((N, C, H, W)).reshape(N, C, P))
+        else:
+            eps = torch.randn(N, P, C, device=x.device)
+        return mu + torch.exp(0.5 * logvar) * eps, mu, logvar
 
     def forward(self, x):
-        x = self.conv2(self.conv1(x))
-        for i in range(self.n_layers):
-            x = getattr(self, f'MLP_{i}')(x)
-        mu = self.mu_net(x)
-        if self.stochastic:
-            logvar = self.logvar_net(x)
-            return self.reparameterize(mu, logvar), mu, logvar
-        return mu
+        """x (N,C,H,W) -> mu | (z, mu, logvar), each (N,C,H,W)   (reference signature)"""
+        N, C, H, W = x.shape
+        out = self.forward_canonical(ops._Transpose.apply(x.reshape(N, C, H * W)), H, W)
+        back = lambda t: ops._Transpose.apply(t).view(N, C, H, W)
+        return tuple(back(t) for t in out) if self.stochastic else back(out)
 
     def reparameterize(self, mu, logvar):
         eps = self.eps_fn(mu.shape) if self.eps_fn is not None else torch.randn(mu.shape, device=mu.device)

@@ -4,6 +4,7 @@ a hand-written gfx950 kernel reached through ctypes.  There is no CPU / eager fa
 tensors must be fp32 CUDA(ROCm) tensors and the library must be built.
 """
 import ctypes
+import os
 
 import torch
 
@@ -86,6 +87,16 @@ class Drop:
 NO_DROP = Drop(0.0)
 
 
+# GEMM arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 split precision (three
+# v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; ~2^-16 relative product error).  NPVP_GEMM=f32|bf16x3.
+GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[os.environ.get("NPVP_GEMM", "f32")]
+
+
+def set_gemm_precision(name):
+    global GEMM_PRECISION
+    GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[name]
+
+
 class GemmProbe:
     """bench.py's live roofline probe: when armed, every GEMM launch of the probed operand layout is bracketed
     by a pair of HIP events on the launching stream (no synchronisation; read after the timed region)."""
@@ -123,7 +134,8 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         e0.record()
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
-                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, _ptr(ws), wsn, _stream()),
+                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, GEMM_PRECISION, _ptr(ws), wsn,
+                          _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
@@ -532,6 +544,32 @@ class _DwConv(torch.autograd.Function):
 
 def dwconv3x3(a, wtb, frames, H, W):
     return _DwConv.apply(a, wtb, frames, H, W)
+
+
+class _Im2Col(torch.autograd.Function):
+    """[F, H*W, C] -> [F*H*W, 9*C] patches of a 3x3 / pad-1 conv (tap-major columns); backward = col2im."""
+
+    @staticmethod
+    def forward(ctx, x, frames, H, W):
+        _chk(x)
+        x = _c(x)
+        C = x.shape[-1]
+        out = torch.empty(frames * H * W, 9 * C, dtype=torch.float32, device=x.device)
+        check(lib().npvp_im2col3x3(_ptr(x), _ptr(out), frames, H, W, C, 0, _stream()), "npvp_im2col3x3")
+        ctx.cfg = (frames, H, W, C, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        frames, H, W, C, shape = ctx.cfg
+        g = _c(g)
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        check(lib().npvp_im2col3x3(_ptr(g), _ptr(out), frames, H, W, C, 1, _stream()), "npvp_im2col3x3(col2im)")
+        return out, None, None, None
+
+
+def im2col3x3(x, frames, H, W):
+    return _Im2Col.apply(x, frames, H, W)
 
 
 def nchw_to_canonical(x):

@@ -12,11 +12,14 @@ DEV = "cuda:0"
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def impl():
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def impl(request):
+    """Both GEMM arithmetic paths (exact fp32 MFMA / bf16x3 split MFMA) must reproduce the reference's vectors."""
     import npvp_amd
     assert torch.cuda.is_available()
-    return npvp_amd
+    npvp_amd.ops.set_gemm_precision(request.param)
+    yield npvp_amd
+    npvp_amd.ops.set_gemm_precision("f32")
 
 
 def test_posfuse(impl):

@@ -27,13 +27,16 @@ def close(a, b, tol=TOL, what=""):
     assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
 
 
-@pytest.fixture(scope="module")
-def K():
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def K(request):
+    """Every test runs on both GEMM arithmetic paths: exact fp32 MFMA and the bf16x3 split-precision MFMA."""
     import npvp_amd
     from npvp_amd import ops
     assert torch.cuda.is_available()
     ops.rng.manual_seed(1234, torch.device(DEV))
-    return ops
+    ops.set_gemm_precision(request.param)
+    yield ops
+    ops.set_gemm_precision("f32")
 
 
 def g(t):
@@ -72,7 +75,7 @@ def test_gemm_wgrad_splitk_long_reduction(K):
     dy = O.seeded_randn((R, N), 7); x = O.seeded_randn((R, K_), 8)
     from npvp_amd._lib import lib
     assert lib().npvp_gemm_workspace_bytes(N, K_, R) > 0, "expected the split-K path for this shape"
-    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=1e-5, what="split-K wgrad")
+    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=1e-5 if K.GEMM_PRECISION == 0 else 5e-5, what="split-K wgrad")
     close(K.colsum(dy.to(DEV)), dy.sum(0), tol=1e-5, what="colsum")
 
 
@@ -83,14 +86,15 @@ def test_gemm_full_size_against_rocblas(K):
         x = torch.randn(R, K_, device=DEV); w = torch.randn(N, K_, device=DEV) / math.sqrt(K_)
         y = K.linear_fwd(x, w, None)
         ref = (x.double() @ w.double().T).float()
-        close(y, ref, tol=1e-5, what=f"fwd {N}x{K_}")
+        tol = 1e-5 if K.GEMM_PRECISION == 0 else 5e-5
+        close(y, ref, tol=tol, what=f"fwd {N}x{K_}")
         dy = torch.randn(R, N, device=DEV)
-        close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=1e-5, what=f"wgrad {N}x{K_}")
-        close(K.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=1e-5, what=f"dgrad {N}x{K_}")
+        close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=tol, what=f"wgrad {N}x{K_}")
+        close(K.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=tol, what=f"dgrad {N}x{K_}")
     # linearity (size-independent property): f(a x1 + x2) = a f(x1) + f(x2)
     x1, x2 = torch.randn(R, 512, device=DEV), torch.randn(R, 512, device=DEV)
     w = torch.randn(512, 512, device=DEV) / 22.6
-    close(K.linear_fwd(2.5 * x1 + x2, w, None), 2.5 * K.linear_fwd(x1, w, None) + K.linear_fwd(x2, w, None), tol=1e-5)
+    close(K.linear_fwd(2.5 * x1 + x2, w, None), 2.5 * K.linear_fwd(x1, w, None) + K.linear_fwd(x2, w, None), tol=5e-5)
 
 
 def test_linear_autograd(K):
