@@ -38,8 +38,9 @@ const char* npvp_last_error(void);
  *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 multiply by GELU'(aux_in), 4 multiply by [aux_in > 0]
  *   drop_mode 0: per element; 1: per row group key=(row/drop_g1)%drop_g2 (DropPath)
  * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
- * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1: bf16x3 split - operands are split on the
- * fly into bf16 hi + lo and hi*hi + hi*lo + lo*hi is accumulated in fp32 on v_mfma_f32_32x32x16_bf16.
+ * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1 / 2: split precision - operands are split on
+ * the fly into 2 / 3 bf16 terms and the 3 / 6 leading cross products are accumulated in fp32 on
+ * v_mfma_f32_32x32x16_bf16 (relative product error ~2^-16 / ~2^-23).
  * When the tile count is small and K large (weight gradients) the reduction is split over
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);

@@ -199,27 +199,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 }
 
 // =====================================================================================================
-// Split-precision path: every fp32 operand x is split on the fly into bf16 hi = rne(x) and lo = rne(x - hi)
-// and the product is accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (the lo*lo
-// term, ~2^-16 relative, is dropped).  3 bf16 MFMAs per fp32 MFMA-equivalent of 8x the k-depth: 16/3 = 5.3x the
-// fp32-MFMA rate, with ~2^-16 relative product error (measured end to end in tests: < 1e-4 on the full
-// predictor, vs the 1e-3 bar).  LDS image per operand and per precision half: [k/8][row][8 k] bf16, i.e. each
-// row's 8 consecutive k are one 16-byte slot, rows contiguous, (129 rows per k-group to skew banks): the MFMA
-// fragment of lane (row r, half h) is ONE conflict-free ds_read_b128.
+// Split-precision path.  Every fp32 operand x is split on the fly into NS bf16 terms
+//     x = p0 + p1 (+ p2) + eps,   p0 = rne(x), p1 = rne(x - p0), p2 = rne(x - p0 - p1)
+// and the product is accumulated in fp32 on v_mfma_f32_32x32x16_bf16 from the cross terms of weight >= 2^-8(NS-1):
+//     NS = 2 ("bf16x3"): p0q0 + p0q1 + p1q0                      3 MFMAs / product, ~2^-16 relative error
+//     NS = 3 ("bf16x6"): p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1 6 MFMAs / product, ~2^-23: fp32-grade
+// i.e. 16/3 = 5.3x resp. 16/6 = 2.7x the fp32-input MFMA rate, with bf16's full fp32 exponent range (no scaling
+// pass, gradients of 1e-8 are safe - an fp16 split would need one).  LDS image per operand and per term:
+// [k/8][row][8 k] bf16 - a row's 8 consecutive k are one 16-byte slot, rows contiguous, 129 slots per k-group to
+// skew banks - so the MFMA fragment of lane (row r, half h) is ONE conflict-free ds_read_b128.  One LDS stage
+// (33 / 49.5 KB -> 3 workgroups per CU); the next K-tile is prefetched into registers while the MFMAs run.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int KG_STRIDE = 129 * 16;          // bytes between k-groups
-constexpr int OPER_BYTES = 4 * KG_STRIDE;    // one operand tile (128 rows x 32 k), one precision half
+constexpr int OPER_BYTES = 4 * KG_STRIDE;    // one operand tile (128 rows x 32 k), one split term
 
-__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
-  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-  lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-  lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-}
+template <int NS, bool KC> struct SplitStager;
 
-template <bool KC> struct SplitStager;
-
-template <> struct SplitStager<true> {     // source [rows][K]: thread = (row t/8 + 32 i, 4 k at (t%8)*4)
+template <int NS> struct SplitStager<NS, true> {     // source [rows][K]: thread = (row t/8 + 32 i, 4 k at (t%8)*4)
   float4 r[4];
   __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
     const int t = threadIdx.x, kc = (t & 7) * 4;
@@ -229,21 +226,25 @@ template <> struct SplitStager<true> {     // source [rows][K]: thread = (row t/
       r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void store(char* hi, char* lo) const {
+  __device__ __forceinline__ void store(char* base) const {      // base -> term 0; term s at base + s*OPER_BYTES
     const int t = threadIdx.x, kc = t & 7;
     const int off0 = (kc >> 1) * KG_STRIDE + (kc & 1) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (t >> 3) + 32 * i;
-      bf16x4 h, l;
-      split4(r[i], h, l);
-      *reinterpret_cast<bf16x4*>(hi + off0 + row * 16) = h;
-      *reinterpret_cast<bf16x4*>(lo + off0 + row * 16) = l;
+      float4 v = r[i];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        bf16x4 q;
+        q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(base + s * OPER_BYTES + off0 + row * 16) = q;
+        v.x -= (float)q[0]; v.y -= (float)q[1]; v.z -= (float)q[2]; v.w -= (float)q[3];
+      }
     }
   }
 };
 
-template <> struct SplitStager<false> {    // source [K][rows]: thread = (rows 2*(t%64), +1 ; k-group t/64), 8 float2 loads
+template <int NS> struct SplitStager<NS, false> {    // source [K][rows]: thread = (rows 2*(t%64), +1 ; k-group t/64), 8 float2 loads
   float2 r[8];
   __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
     const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
@@ -252,24 +253,36 @@ template <> struct SplitStager<false> {    // source [K][rows]: thread = (rows 2
       r[j] = (row0 + rp < nrows) ? *reinterpret_cast<const float2*>(src + (long long)(k0 + kg * 8 + j) * ld + row0 + rp)
                                  : make_float2(0.f, 0.f);
   }
-  __device__ __forceinline__ void store(char* hi, char* lo) const {
+  __device__ __forceinline__ void store(char* base) const {
     const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
-    bf16x8 h0, l0, h1, l1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      h0[j] = (__bf16)r[j].x; l0[j] = (__bf16)(r[j].x - (float)h0[j]);
-      h1[j] = (__bf16)r[j].y; l1[j] = (__bf16)(r[j].y - (float)h1[j]);
-    }
     const int off = kg * KG_STRIDE + rp * 16;
-    *reinterpret_cast<bf16x8*>(hi + off) = h0; *reinterpret_cast<bf16x8*>(hi + off + 16) = h1;
-    *reinterpret_cast<bf16x8*>(lo + off) = l0; *reinterpret_cast<bf16x8*>(lo + off + 16) = l1;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = r[j].x; b[j] = r[j].y; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x8 qa, qb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        qa[j] = (__bf16)a[j]; a[j] -= (float)qa[j];
+        qb[j] = (__bf16)b[j]; b[j] -= (float)qb[j];
+      }
+      *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off) = qa;
+      *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off + 16) = qb;
+    }
   }
 };
 
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmParams p) {
-  // [buffer][A_hi | A_lo | B_hi | B_lo]
-  __shared__ __attribute__((aligned(16))) char lds[2][4 * OPER_BYTES];
+#define NPVP_MFMA4(A0, A1, B0, B1)                                                  \
+  acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc00, 0, 0, 0);          \
+  acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc01, 0, 0, 0);          \
+  acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc10, 0, 0, 0);          \
+  acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc11, 0, 0, 0);
+
+template <int NS, bool AKC, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams p) {
+  // [A term 0..NS-1 | B term 0..NS-1]
+  __shared__ __attribute__((aligned(16))) char lds[2 * NS * OPER_BYTES];
   int m0, n0;
   tile_of_block(p, m0, n0);
   const int z = blockIdx.y;
@@ -279,51 +292,43 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmParams
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
-  SplitStager<AKC> sa; SplitStager<BKC> sb;
+  SplitStager<NS, AKC> sa; SplitStager<NS, BKC> sb;
+  char* const ldsA = lds;
+  char* const ldsB = lds + NS * OPER_BYTES;
+  const char* const fa = ldsA + h * KG_STRIDE + (wm * 64 + r) * 16;     // this lane's fragment slot, term 0, k16-step 0
+  const char* const fb = ldsB + h * KG_STRIDE + (wn * 64 + r) * 16;
   const int nk = p.K / BK;
   sa.load(A, p.lda, m0, p.M, 0);
   sb.load(B, p.ldb, n0, p.N, 0);
-  sa.store(lds[0], lds[0] + OPER_BYTES);
-  sb.store(lds[0] + 2 * OPER_BYTES, lds[0] + 3 * OPER_BYTES);
-  __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
+    sa.store(ldsA); sb.store(ldsB);                      // split + stage tile kt
+    __syncthreads();
+    if (kt + 1 < nk) {                                   // tile kt+1 travels HBM/L2 -> registers under the MFMAs
       sa.load(A, p.lda, m0, p.M, (kt + 1) * BK);
       sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK);
     }
-    const char* a_hi = lds[cur] + h * KG_STRIDE + (wm * 64 + r) * 16;
-    const char* b_hi = lds[cur] + 2 * OPER_BYTES + h * KG_STRIDE + (wn * 64 + r) * 16;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {                     // two k16 steps per 32-deep tile; lane half h takes k-group 2kk+h
       const int ko = kk * 2 * KG_STRIDE;
-      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a_hi + ko);
-      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a_hi + ko + 32 * 16);
-      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a_hi + OPER_BYTES + ko);
-      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a_hi + OPER_BYTES + ko + 32 * 16);
-      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(b_hi + ko);
-      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(b_hi + ko + 32 * 16);
-      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(b_hi + OPER_BYTES + ko);
-      const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(b_hi + OPER_BYTES + ko + 32 * 16);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+      bf16x8 a0[NS], a1[NS], b0[NS], b1[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        a0[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko);
+        a1[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko + 32 * 16);
+        b0[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko);
+        b1[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko + 32 * 16);
+      }
+      if (NS == 3) {                                      // smallest terms first
+        NPVP_MFMA4(a0[1], a1[1], b0[1], b1[1])
+        NPVP_MFMA4(a0[0], a1[0], b0[2], b1[2])
+        NPVP_MFMA4(a0[2], a1[2], b0[0], b1[0])
+      }
+      NPVP_MFMA4(a0[0], a1[0], b0[1], b1[1])
+      NPVP_MFMA4(a0[1], a1[1], b0[0], b1[0])
+      NPVP_MFMA4(a0[0], a1[0], b0[0], b1[0])
     }
-    if (kt + 1 < nk) {
-      sa.store(lds[cur ^ 1], lds[cur ^ 1] + OPER_BYTES);
-      sb.store(lds[cur ^ 1] + 2 * OPER_BYTES, lds[cur ^ 1] + 3 * OPER_BYTES);
-    }
-    __syncthreads();
+    __syncthreads();                                      // every wave is done with the stage before it is rewritten
   }
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
@@ -372,7 +377,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
                              int precision, void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  NPVP_CHECK_ARG(precision == 0 || precision == 1, "gemm: precision must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
+  NPVP_CHECK_ARG(precision >= 0 && precision <= 2, "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (bf16x6)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
@@ -400,10 +405,14 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+  } else if (precision == 1) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<2, false, false>), grid, block, 0, stream, p);
   } else {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, block, 0, stream, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
   }
   NPVP_CHECK_LAUNCH();
   if (splits > 1) {

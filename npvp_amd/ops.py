@@ -87,14 +87,17 @@ class Drop:
 NO_DROP = Drop(0.0)
 
 
-# GEMM arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 split precision (three
-# v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; ~2^-16 relative product error).  NPVP_GEMM=f32|bf16x3.
-GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[os.environ.get("NPVP_GEMM", "f32")]
+# GEMM arithmetic (NPVP_GEMM=f32|bf16x3|bf16x6), all with fp32 accumulation on the matrix cores:
+#   f32    exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)
+#   bf16x3 2-term bf16 split, 3 v_mfma_f32_32x32x16_bf16 per product, ~2^-16 relative product error
+#   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade (default)
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6")]
 
 
 def set_gemm_precision(name):
     global GEMM_PRECISION
-    GEMM_PRECISION = {"f32": 0, "bf16x3": 1}[name]
+    GEMM_PRECISION = GEMM_MODES[name]
 
 
 class GemmProbe:

@@ -116,14 +116,31 @@ def main():
              y_add=npy(y2), gx_add=npy(gx2), gadd=npy(ga2), meta=np.array([N, T, 11, 12, 14, 15]))
 
     # ------------------------------------------------------------------ NRMLP o CoorGenerator
+    # The MLP has ReLUs: a hidden unit whose pre-activation is within rounding noise of 0 makes d/dB
+    # discontinuous (one flipped unit moves gB by ~1e-3).  Pick the first fill seed with no unit closer than
+    # 1e-5 to the kink (fp32-grade paths differ by ~5e-7 there), so every arithmetic path (fp32 / split-precision MFMA) sits on the same side.
+    def nrmlp_margin(mod, coor):
+        x = mod.gaussian_mapping(coor)
+        worst = 1e9
+        for l in mod.MLP:
+            x = l(x)
+            if isinstance(l, nn.Linear):
+                worst = min(worst, float(x.abs().min()))
+        return worst
     for fuse in ("Add", "SPADE"):
-        ref = R.NRMLP(512, fuse_method=fuse)
-        O.key_hashed_fill(ref, 21)
         cg = R.CoorGenerator(8, 8, 7)
         coor = cg(torch.linspace(3, 6, 4), torch.linspace(0, 7, 8), torch.linspace(0, 7, 8))
+        for seed in range(21, 40000, 100):
+            ref = R.NRMLP(512, fuse_method=fuse)
+            O.key_hashed_fill(ref, seed)
+            with torch.no_grad():
+                mg = nrmlp_margin(ref, coor)
+            if mg > 1e-5:
+                break
+        print(f"  nrmlp[{fuse}]: fill seed {seed}, smallest |pre-activation| {mg:.2e}")
         b, g = ref(coor)
         mine = oracle.NRMLP(512, fuse_method=fuse)
-        O.key_hashed_fill(mine, 21)
+        O.key_hashed_fill(mine, seed)
         coor_m = oracle.CoorGenerator(8, 8, 7)(torch.linspace(3, 6, 4), torch.linspace(0, 7, 8), torch.linspace(0, 7, 8))
         bm, gm = mine(coor_m)
         check(f"coor[{fuse}]", coor_m, coor); check(f"nrmlp[{fuse}].beta", bm, b)
@@ -131,7 +148,7 @@ def main():
         gB = torch.autograd.grad((b * cot).sum() + (g * cot).sum(), ref.B)[0]
         gBm = torch.autograd.grad((bm * cot).sum() + (gm * cot).sum(), mine.B)[0]
         check(f"nrmlp[{fuse}].gB", gBm, gB)
-        save(f"nrmlp_{fuse}", coor=npy(coor), beta=npy(b), gamma=npy(g), gB=npy(gB), meta=np.array([21, 22]))
+        save(f"nrmlp_{fuse}", coor=npy(coor), beta=npy(b), gamma=npy(g), gB=npy(gB), meta=np.array([seed, 22]))
 
     # ------------------------------------------------------------------ spatial window MHA
     N, T = 1, 2
@@ -288,7 +305,9 @@ def main():
             torch.randn = real_randn
         om = mine(p2, fut) if stochastic else mine(p2)
         yt, ytm = (o[0], om[0]) if stochastic else (o, om)
-        loss = (yt * cot).sum(); lossm = (ytm * cot).sum()
+        # sum(cot * y^2): elements at the final ReLU's kink (y ~ 0) carry ~0 gradient, so a rounding-level
+        # sign difference there cannot move the compared gradients
+        loss = (yt * yt * cot).sum(); lossm = (ytm * ytm * cot).sum()
         if stochastic:
             loss = loss + R.Div_KL(1e-2)(*o[1:]); lossm = lossm + oracle.Div_KL(1e-2)(*om[1:])
             for i, n_ in enumerate(["mu_o", "logvar_o", "mu_p", "logvar_p"]):

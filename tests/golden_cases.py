@@ -24,9 +24,19 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def compare(results, golden, tol, skip=()):
+ERR_LOG = os.environ.get("NPVP_ERR_LOG")      # optional: append "<tag> <key> <rel-L2>" lines (GPU triage)
+
+
+def log_err(tag, key, e):
+    if ERR_LOG:
+        with open(ERR_LOG, "a") as f:
+            f.write(f"{tag} {key} {e:.3e}\n")
+
+
+def compare(results, golden, tol, skip=(), tag=""):
     """Every golden array (except meta) must be reproduced within rel-L2 `tol`."""
     worst = 0.0
+    errs = {}
     for key, g in golden.items():
         if key == "meta" or key in skip:
             continue
@@ -34,7 +44,10 @@ def compare(results, golden, tol, skip=()):
         mine = O.golden_view(results[key]) if results[key].numel() != g.size else results[key]
         e = rel_err(mine, g)
         worst = max(worst, e)
-        assert e < tol, f"{key}: rel-L2 {e:.3e} exceeds {tol:.1e}"
+        errs[key] = e
+        log_err(tag, key, e)
+    bad = {k: f"{v:.3e}" for k, v in errs.items() if not v < tol}
+    assert not bad, f"rel-L2 above {tol:.1e}: {bad}"
     return worst
 
 
@@ -65,7 +78,7 @@ def case_posfuse(impl, dev, norm="layer"):
 
 def case_nrmlp(impl, dev, fuse="Add"):
     m = impl.NRMLP(512, fuse_method=fuse)
-    O.key_hashed_fill(m, 21)
+    O.key_hashed_fill(m, int(load(f"nrmlp_{fuse}")["meta"][0]))   # seed chosen by make_golden (ReLU-kink margin)
     m = m.to(dev)
     coor = impl.CoorGenerator(8, 8, 7)(torch.linspace(3, 6, 4), torch.linspace(0, 7, 8), torch.linspace(0, 7, 8)).to(dev)
     b, g = m(coor)
@@ -184,7 +197,7 @@ def case_predictor(impl, dev, variant="D"):
     p = past.clone().requires_grad_()
     o = m(p, fut) if stochastic else m(p)
     yt = o[0] if stochastic else o
-    loss = (yt * cot).sum()
+    loss = (yt * yt * cot).sum()          # smooth at the final ReLU's kink (see make_golden.py)
     if stochastic:
         loss = loss + impl.Div_KL(1e-2)(*o[1:])
         for i, n_ in enumerate(["mu_o", "logvar_o", "mu_p", "logvar_p"]):

@@ -4,6 +4,7 @@ libnpvp_hip.so (npvp_amd.ops -> ctypes).  Tolerances: the fp32-MFMA path is expe
 ~1e-6; the bar written here (1e-4 rel-L2, 1e-3 for long reductions) sits inside the 1e-3 rel fp32
 bar of BASELINE.json's north_star."""
 import math
+import os
 
 import pytest
 import torch
@@ -24,10 +25,14 @@ def rel(a, b):
 def close(a, b, tol=TOL, what=""):
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     e = rel(a, b)
+    if os.environ.get("NPVP_ERR_LOG"):
+        import npvp_amd.ops as _o
+        with open(os.environ["NPVP_ERR_LOG"], "a") as f:
+            f.write(f"ops[{_o.GEMM_PRECISION}] {os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]} {what} {e:.3e}\n")
     assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16x6"])
 def K(request):
     """Every test runs on both GEMM arithmetic paths: exact fp32 MFMA and the bf16x3 split-precision MFMA."""
     import npvp_amd
@@ -36,7 +41,7 @@ def K(request):
     ops.rng.manual_seed(1234, torch.device(DEV))
     ops.set_gemm_precision(request.param)
     yield ops
-    ops.set_gemm_precision("f32")
+    ops.set_gemm_precision("bf16x6")
 
 
 def g(t):
@@ -75,7 +80,7 @@ def test_gemm_wgrad_splitk_long_reduction(K):
     dy = O.seeded_randn((R, N), 7); x = O.seeded_randn((R, K_), 8)
     from npvp_amd._lib import lib
     assert lib().npvp_gemm_workspace_bytes(N, K_, R) > 0, "expected the split-K path for this shape"
-    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=1e-5 if K.GEMM_PRECISION == 0 else 5e-5, what="split-K wgrad")
+    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=5e-5 if K.GEMM_PRECISION == 1 else 1e-5, what="split-K wgrad")
     close(K.colsum(dy.to(DEV)), dy.sum(0), tol=1e-5, what="colsum")
 
 
@@ -86,7 +91,7 @@ def test_gemm_full_size_against_rocblas(K):
         x = torch.randn(R, K_, device=DEV); w = torch.randn(N, K_, device=DEV) / math.sqrt(K_)
         y = K.linear_fwd(x, w, None)
         ref = (x.double() @ w.double().T).float()
-        tol = 1e-5 if K.GEMM_PRECISION == 0 else 5e-5
+        tol = 5e-5 if K.GEMM_PRECISION == 1 else 1e-5
         close(y, ref, tol=tol, what=f"fwd {N}x{K_}")
         dy = torch.randn(R, N, device=DEV)
         close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=tol, what=f"wgrad {N}x{K_}")
