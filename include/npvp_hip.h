@@ -41,14 +41,16 @@ const char* npvp_last_error(void);
  * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1 / 2: split precision - operands are split on
  * the fly into 2 / 3 bf16 terms and the 3 / 6 leading cross products are accumulated in fp32 on
  * v_mfma_f32_32x32x16_bf16 (relative product error ~2^-16 / ~2^-23).
+ * colsum_a (a_kc = 0 only, nullable): receives colsum_a[m] = sum_k A[k][m] - the bias gradient falls out of the
+ * weight-gradient GEMM's own operand staging (dW = dy^T x, db = column sums of dy), no extra pass over dy.
  * When the tile count is small and K large (weight gradients) the reduction is split over
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);
 int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B, long long ldb,
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
-                  const unsigned long long* seed, unsigned int salt, float alpha, int precision, void* workspace,
-                  long long ws_bytes, npvp_stream_t stream);
+                  const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
+                  void* workspace, long long ws_bytes, npvp_stream_t stream);
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.

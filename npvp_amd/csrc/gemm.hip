@@ -34,6 +34,7 @@ struct GemmParams {
   const float* residual;   // [M][ldr] or null (added last)
   float* aux_out;          // [M][ldc] pre-activation copy (after bias) or null
   const float* aux_in;     // [M][ldc] for act 3/4 (activation gradients)
+  float* colsum;           // a_kc==0 only: colsum[z][m] = sum over this split's k of A[k][m] (bias gradient), or null
   const unsigned long long* seed;  // device seed for dropout or null
   long long lda, ldb, ldc, ldr;
   int M, N, K;             // K = this launch's reduction length per split
@@ -93,6 +94,11 @@ template <> struct Stager<false> {  // source [K][rows], rows contiguous
       const int k = (t >> 5) + 8 * i;
       st4(s + k * LD + rc, r[i]);
     }
+  }
+  // sum over this thread's 4 k of its 4 rows (columns of the [K][rows] operand)
+  __device__ __forceinline__ void add_tile_sum(float4& a) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a.x += r[i].x; a.y += r[i].y; a.z += r[i].z; a.w += r[i].w; }
   }
 };
 
@@ -162,8 +168,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 
   Stager<AKC> sa; Stager<BKC> sb;
   const int nk = p.K / BK;
+  const bool want_cs = !AKC && p.colsum && n0 == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   sa.load(A, p.lda, m0, p.M, 0);
   sb.load(B, p.ldb, n0, p.N, 0);
+  if constexpr (!AKC) { if (want_cs) sa.add_tile_sum(cs); }
   sa.store(As[0]); sb.store(Bs[0]);
   __syncthreads();
 
@@ -191,10 +200,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
       acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-    if (kt + 1 < nk) { sa.store(As[cur ^ 1]); sb.store(Bs[cur ^ 1]); }
+    if (kt + 1 < nk) {
+      if constexpr (!AKC) { if (want_cs) sa.add_tile_sum(cs); }
+      sa.store(As[cur ^ 1]); sb.store(Bs[cur ^ 1]);
+    }
     __syncthreads();
   }
-
+  if constexpr (!AKC) {
+    if (want_cs) {            // 8 threads (t>>5) hold partial sums of the same 4 columns: fixed-order reduction through LDS
+      float* red = As[0];
+      st4(red + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4, cs);
+      __syncthreads();
+      if (threadIdx.x < 128 && m0 + (int)threadIdx.x < p.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i * 128 + threadIdx.x];
+        p.colsum[(long long)z * p.M + m0 + threadIdx.x] = t;
+      }
+    }
+  }
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
@@ -216,22 +240,25 @@ constexpr int OPER_BYTES = 4 * KG_STRIDE;    // one operand tile (128 rows x 32 
 
 template <int NS, bool KC> struct SplitStager;
 
-template <int NS> struct SplitStager<NS, true> {     // source [rows][K]: thread = (row t/8 + 32 i, 4 k at (t%8)*4)
+template <int NS> struct SplitStager<NS, true> {
+  // source [rows][K].  16 consecutive lanes = 8 rows x the two 4-k halves of ONE k-group, so a ds_write_b64
+  // wave-instruction covers 128 contiguous LDS bytes per 16-lane group (conflict free; the first version's
+  // (row, 8 k-chunks) mapping was 2-way: profiles/r01_pmc_gemm_bf16x6.md).  Global side: a row's 128 B
+  // (32 k) is read by 8 lanes as one full line.
   float4 r[4];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
-    const int t = threadIdx.x, kc = (t & 7) * 4;
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    const int kof = ((t >> 4) & 3) * 8 + (t & 1) * 4, rl = (t >> 6) * 8 + ((t >> 1) & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = row0 + (t >> 3) + 32 * i;
-      r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = row0 + rl + 32 * i;
+      r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kof) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void store(char* base) const {      // base -> term 0; term s at base + s*OPER_BYTES
-    const int t = threadIdx.x, kc = t & 7;
-    const int off0 = (kc >> 1) * KG_STRIDE + (kc & 1) * 8;
+  __device__ __forceinline__ void store(char* base, int t) const {      // base -> term 0; term s at base + s*OPER_BYTES
+    const int off0 = ((t >> 4) & 3) * KG_STRIDE + (t & 1) * 8, rl = (t >> 6) * 8 + ((t >> 1) & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = (t >> 3) + 32 * i;
+      const int row = rl + 32 * i;
       float4 v = r[i];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -244,31 +271,43 @@ template <int NS> struct SplitStager<NS, true> {     // source [rows][K]: thread
   }
 };
 
-template <int NS> struct SplitStager<NS, false> {    // source [K][rows]: thread = (rows 2*(t%64), +1 ; k-group t/64), 8 float2 loads
-  float2 r[8];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0) {
-    const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
+template <int NS> struct SplitStager<NS, false> {
+  // source [K][rows].  One row per lane (64 consecutive rows = 256 contiguous bytes per load), 8 k per k-group
+  // gathered in registers, then ONE ds_write_b128 per term with consecutive lanes on consecutive 16-byte slots
+  // (conflict free).
+  float r[2][8];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    const int row = t & 127, kgb = t >> 7;
+    const bool ok = row0 + row < nrows;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      r[j] = (row0 + rp < nrows) ? *reinterpret_cast<const float2*>(src + (long long)(k0 + kg * 8 + j) * ld + row0 + rp)
-                                 : make_float2(0.f, 0.f);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        r[i][j] = ok ? src[(long long)(k0 + (kgb + 2 * i) * 8 + j) * ld + row0 + row] : 0.f;
   }
-  __device__ __forceinline__ void store(char* base) const {
-    const int t = threadIdx.x, rp = (t & 63) * 2, kg = t >> 6;
-    const int off = kg * KG_STRIDE + rp * 16;
-    float a[8], b[8];
+  __device__ __forceinline__ float tile_sum() const {       // this thread's row (a column of the [K][rows] operand), 16 k
+    float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = r[j].x; b[j] = r[j].y; }
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      bf16x8 qa, qb;
+      for (int j = 0; j < 8; ++j) a += r[i][j];
+    return a;
+  }
+  __device__ __forceinline__ void store(char* base, int t) const {
+    const int row = t & 127, kgb = t >> 7;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        qa[j] = (__bf16)a[j]; a[j] -= (float)qa[j];
-        qb[j] = (__bf16)b[j]; b[j] -= (float)qb[j];
+    for (int i = 0; i < 2; ++i) {
+      const int off = (kgb + 2 * i) * KG_STRIDE + row * 16;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = r[i][j];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        bf16x8 q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[j] = (__bf16)a[j]; a[j] -= (float)q[j]; }
+        *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off) = q;
       }
-      *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off) = qa;
-      *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off + 16) = qb;
     }
   }
 };
@@ -298,15 +337,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
   const char* const fa = ldsA + h * KG_STRIDE + (wm * 64 + r) * 16;     // this lane's fragment slot, term 0, k16-step 0
   const char* const fb = ldsB + h * KG_STRIDE + (wn * 64 + r) * 16;
   const int nk = p.K / BK;
-  sa.load(A, p.lda, m0, p.M, 0);
-  sb.load(B, p.ldb, n0, p.N, 0);
+  const bool want_cs = !AKC && p.colsum && n0 == 0;
+  float cs = 0.f;
+  const int t = threadIdx.x;
+  sa.load(A, p.lda, m0, p.M, 0, t);
+  sb.load(B, p.ldb, n0, p.N, 0, t);
 
   for (int kt = 0; kt < nk; ++kt) {
-    sa.store(ldsA); sb.store(ldsB);                      // split + stage tile kt
+    if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
+    sa.store(ldsA, t); sb.store(ldsB, t);                // split + stage tile kt
     __syncthreads();
     if (kt + 1 < nk) {                                   // tile kt+1 travels HBM/L2 -> registers under the MFMAs
-      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK);
-      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK);
+      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, t);
+      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, t);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {                     // two k16 steps per 32-deep tile; lane half h takes k-group 2kk+h
@@ -330,6 +373,108 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
     }
     __syncthreads();                                      // every wave is done with the stage before it is rewritten
   }
+  if constexpr (!AKC) {
+    if (want_cs) {            // threads t and t+128 hold the two halves of column t&127
+      float* red = reinterpret_cast<float*>(lds);
+      red[threadIdx.x] = cs;
+      __syncthreads();
+      if (threadIdx.x < 128 && m0 + (int)threadIdx.x < p.M)
+        p.colsum[(long long)z * p.M + m0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+    }
+  }
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Producer / consumer form of the split-precision GEMM (the default for bf16x6).  In gemm_split_kernel every
+// wave alternates between "split + stage a tile" (VALU + LDS writes) and "MFMA", with barriers between: measured
+// MfmaUtil 34-42 % (profiles/r01_pmc_gemm_bf16x6.md) - the matrix pipe idles while its own wave stages.  Here a
+// workgroup is 8 waves: waves 0-3 (one per SIMD) ONLY read fragments and issue MFMAs on LDS stage kt&1, waves 4-7
+// (the SIMDs' second wave) ONLY load, split and write tile kt+1 into the other stage and prefetch tile kt+2 into
+// registers.  VALU / LDS-write work of a producer wave and the MFMAs of the consumer wave on the same SIMD run on
+// separate pipes concurrently; one barrier per K-step.  2 x 49.5 KB LDS -> one workgroup per CU.
+template <int NS, bool AKC, bool BKC>
+__global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(GemmParams p) {
+  constexpr int STAGE = 2 * NS * OPER_BYTES;                 // [A term 0..NS-1 | B term 0..NS-1]
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  int m0, n0;
+  tile_of_block(p, m0, n0);
+  const int z = blockIdx.y;
+  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
+  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
+  const int nk = p.K / BK;
+  const int wave = threadIdx.x >> 6;
+
+  if (wave >= 4) {
+    // ------------------------------------------------ producers
+    const int t = threadIdx.x - 256;
+    SplitStager<NS, AKC> sa; SplitStager<NS, BKC> sb;
+    const bool want_cs = !AKC && p.colsum && n0 == 0;
+    float cs = 0.f;
+    sa.load(A, p.lda, m0, p.M, 0, t);
+    sb.load(B, p.ldb, n0, p.N, 0, t);
+    if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
+    sa.store(lds, t); sb.store(lds + NS * OPER_BYTES, t);
+    if (nk > 1) { sa.load(A, p.lda, m0, p.M, BK, t); sb.load(B, p.ldb, n0, p.N, BK, t); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        char* st = lds + ((kt + 1) & 1) * STAGE;
+        if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
+        sa.store(st, t); sb.store(st + NS * OPER_BYTES, t);
+        if (kt + 2 < nk) { sa.load(A, p.lda, m0, p.M, (kt + 2) * BK, t); sb.load(B, p.ldb, n0, p.N, (kt + 2) * BK, t); }
+      }
+      __syncthreads();
+    }
+    if constexpr (!AKC) {
+      if (want_cs) {                       // threads t and t+128 hold the two halves of column t&127
+        float* red = reinterpret_cast<float*>(lds);
+        red[t] = cs;
+      }
+    }
+    __syncthreads();                       // matches the consumers' barrier before their epilogue
+    if constexpr (!AKC) {
+      if (want_cs && t < 128 && m0 + t < p.M) {
+        const float* red = reinterpret_cast<const float*>(lds);
+        p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------- consumers
+  const int lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  const int fa_off = h * KG_STRIDE + (wm * 64 + r) * 16;
+  const int fb_off = NS * OPER_BYTES + h * KG_STRIDE + (wn * 64 + r) * 16;
+  __syncthreads();                         // stage 0 is ready
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* fa = lds + (kt & 1) * STAGE + fa_off;
+    const char* fb = lds + (kt & 1) * STAGE + fb_off;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ko = kk * 2 * KG_STRIDE;
+      bf16x8 a0[NS], a1[NS], b0[NS], b1[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        a0[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko);
+        a1[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko + 32 * 16);
+        b0[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko);
+        b1[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko + 32 * 16);
+      }
+      if (NS == 3) {
+        NPVP_MFMA4(a0[1], a1[1], b0[1], b1[1])
+        NPVP_MFMA4(a0[0], a1[0], b0[2], b1[2])
+        NPVP_MFMA4(a0[2], a1[2], b0[0], b1[0])
+      }
+      NPVP_MFMA4(a0[0], a1[0], b0[1], b1[1])
+      NPVP_MFMA4(a0[1], a1[1], b0[0], b1[0])
+      NPVP_MFMA4(a0[0], a1[0], b0[0], b1[0])
+    }
+    __syncthreads();
+  }
+  __syncthreads();                         // matches the producers' column-sum barrier
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
@@ -365,9 +510,10 @@ static int pick_splits(int M, int N, int K) {
 
 using namespace npvp;
 
+// split-K partial slabs [splits][M][N] followed by the column-sum partials [splits][M]
 extern "C" long long npvp_gemm_workspace_bytes(int M, int N, int K) {
   const int s = pick_splits(M, N, K);
-  return s > 1 ? (long long)s * M * N * 4 : 0;
+  return s > 1 ? ((long long)s * M * N + (long long)s * M) * 4 : 0;
 }
 
 // See include/npvp_hip.h for the contract.
@@ -375,9 +521,10 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
-                             int precision, void* workspace, long long ws_bytes, hipStream_t stream) {
+                             int precision, float* colsum_a, void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  NPVP_CHECK_ARG(precision >= 0 && precision <= 2, "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (bf16x6)");
+  NPVP_CHECK_ARG(precision >= 0 && precision <= 3,
+                 "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x6) or 3 (bf16x6, producer/consumer waves)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
@@ -387,6 +534,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   NPVP_CHECK_ARG((act != 3 && act != 4) || aux_in, "gemm: act 3/4 need aux_in");
   NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p out of range");
   NPVP_CHECK_ARG(drop_p == 0.f || seed, "gemm: dropout needs a device seed");
+  NPVP_CHECK_ARG(!colsum_a || a_kc == 0, "gemm: colsum_a is the column sum of a [K][M] operand (a_kc = 0)");
 
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux_out = aux_out; p.aux_in = aux_in;
@@ -396,9 +544,13 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int splits = pick_splits(M, N, K);
   const bool plain = !bias && act == 0 && !aux_out && !residual && drop_p == 0.f;
-  if (splits > 1 && (!plain || ws_bytes < (long long)splits * M * N * 4 || !workspace || (N % 4) != 0)) splits = 1;
+  if (splits > 1 && (!plain || ws_bytes < npvp_gemm_workspace_bytes(M, N, K) || !workspace || (N % 4) != 0)) splits = 1;
   p.splits = splits;
-  if (splits > 1) { p.K = K / splits; p.C = (float*)workspace; p.ldc = N; }
+  p.colsum = colsum_a;
+  if (splits > 1) {
+    p.K = K / splits; p.C = (float*)workspace; p.ldc = N;
+    if (colsum_a) p.colsum = (float*)workspace + (long long)splits * M * N;
+  }
 
   dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
   if (precision == 0) {
@@ -409,10 +561,15 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_kernel<2, false, false>), grid, block, 0, stream, p);
-  } else {
+  } else if (precision == 2) {
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
+  } else {
+    const dim3 block2(512);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, true>), grid, block2, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, false>), grid, block2, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_pc_kernel<3, false, false>), grid, block2, 0, stream, p);
   }
   NPVP_CHECK_LAUNCH();
   if (splits > 1) {
@@ -421,6 +578,10 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
                        splits, alpha);
     NPVP_CHECK_LAUNCH();
+    if (colsum_a && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream)) {
+      npvp_set_error("gemm: column-sum reduce launch failed");
+      return NPVP_ERR_LAUNCH;
+    }
   }
   return NPVP_OK;
 }

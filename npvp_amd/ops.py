@@ -90,8 +90,9 @@ NO_DROP = Drop(0.0)
 # GEMM arithmetic (NPVP_GEMM=f32|bf16x3|bf16x6), all with fp32 accumulation on the matrix cores:
 #   f32    exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)
 #   bf16x3 2-term bf16 split, 3 v_mfma_f32_32x32x16_bf16 per product, ~2^-16 relative product error
-#   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade (default)
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+#   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade; every wave stages and multiplies
+#   bf16x6pc same arithmetic, producer/consumer waves (4 MFMA waves + 4 staging waves per workgroup)
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3}
 GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6")]
 
 
@@ -123,8 +124,8 @@ class GemmProbe:
 
 # --------------------------------------------------------------------------- raw kernel wrappers
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         drop=NO_DROP, alpha=1.0):
-    _chk(A, B, out, bias, aux_in, aux_out, residual)
+         drop=NO_DROP, alpha=1.0, colsum_a=None):
+    _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
     wsb = L.npvp_gemm_workspace_bytes(M, N, K)
     ws, wsn = (None, 0)
@@ -137,8 +138,8 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         e0.record()
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
-                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, GEMM_PRECISION, _ptr(ws), wsn,
-                          _stream()),
+                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, GEMM_PRECISION, _ptr(colsum_a),
+                          _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
@@ -162,12 +163,15 @@ def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
     return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop)
 
 
-def linear_wgrad(dy, x):
-    """dw[N,K] = dy[R,N]^T x[R,K]"""
+def linear_wgrad(dy, x, with_bias_grad=False):
+    """dw[N,K] = dy[R,N]^T x[R,K]; with_bias_grad also returns db[N] = column sums of dy, accumulated by the same
+    kernel while it stages dy (no separate reduction pass)."""
     R, N = dy.shape
     K = x.shape[1]
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    return gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias_grad else None
+    gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db)
+    return (dw, db) if with_bias_grad else dw
 
 
 def colsum(x):
@@ -345,8 +349,14 @@ class _Linear(torch.autograd.Function):
         dy2 = _c(dy).reshape(-1, N)
         dz = drop_apply(dy2, ctx.drop) if ctx.drop.on else dy2
         dx = linear_dgrad(dz, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dz, x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dz) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad(dz, x2, want_b)
+            if want_b:
+                dw, db = dw
+        elif want_b:
+            db = colsum(dz)
         dres = dy if ctx.has_r else None
         return dx, dw, db, dres, None
 
@@ -380,11 +390,9 @@ class _FFN(torch.autograd.Function):
         C = xn2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
         dz2 = drop_apply(dy2, ctx.d3) if ctx.d3.on else dy2
-        dw2 = linear_wgrad(dz2, a)
-        db2 = colsum(dz2)
+        dw2, db2 = linear_wgrad(dz2, a, True)
         dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)
-        dw1 = linear_wgrad(dh, xn2)
-        db1 = colsum(dh)
+        dw1, db1 = linear_wgrad(dh, xn2, True)
         dxn = linear_dgrad(dh, w1)
         return dxn.reshape(ctx.shape), dy, dw1, db1, dw2, db2, None
 

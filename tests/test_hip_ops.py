@@ -32,7 +32,7 @@ def close(a, b, tol=TOL, what=""):
     assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16x6"])
+@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16x6", "bf16x6pc"])
 def K(request):
     """Every test runs on both GEMM arithmetic paths: exact fp32 MFMA and the bf16x3 split-precision MFMA."""
     import npvp_amd
@@ -72,7 +72,8 @@ def test_gemm_forward_variants(K, M, N, K_):
         close(K.linear_dgrad(dy.to(DEV), wg, act=3, aux_in=hpre.to(DEV)), hp.grad, what="dgrad*gelu'")
     # wgrad: dw = dy^T x  (the reduction dim = token rows, a multiple of 64 on the path)
     if M % 32 == 0:
-        close(K.linear_wgrad(dy.to(DEV), xg), dy.T @ x, what="wgrad")
+        dw, db = K.linear_wgrad(dy.to(DEV), xg, True)
+        close(dw, dy.T @ x, what="wgrad"); close(db, dy.sum(0), what="fused bias grad")
 
 
 def test_gemm_wgrad_splitk_long_reduction(K):
@@ -80,7 +81,9 @@ def test_gemm_wgrad_splitk_long_reduction(K):
     dy = O.seeded_randn((R, N), 7); x = O.seeded_randn((R, K_), 8)
     from npvp_amd._lib import lib
     assert lib().npvp_gemm_workspace_bytes(N, K_, R) > 0, "expected the split-K path for this shape"
-    close(K.linear_wgrad(dy.to(DEV), x.to(DEV)), dy.T @ x, tol=5e-5 if K.GEMM_PRECISION == 1 else 1e-5, what="split-K wgrad")
+    dw, db = K.linear_wgrad(dy.to(DEV), x.to(DEV), True)
+    close(dw, dy.T @ x, tol=5e-5 if K.GEMM_PRECISION == 1 else 1e-5, what="split-K wgrad")
+    close(db, dy.sum(0), tol=1e-5, what="split-K fused bias grad")
     close(K.colsum(dy.to(DEV)), dy.sum(0), tol=1e-5, what="colsum")
 
 
