@@ -38,12 +38,16 @@ WORKLOADS = {   # name -> (config file, variant, per-GPU clips, To, Tp)
     "c4": ("config_KITTI_VFP_NPVP-D.yaml", "KITTI 128x128 NPVP-D (per-GPU shard)", 8, 4, 16),
 }
 # MI355X_MICROARCH.md dense matrix peaks: v_mfma_f32_32x32x2_f32 (fp32 in) and v_mfma_f32_32x32x16_bf16
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x6": 2500.0, "bf16x6pc": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16x6": 2500.0, "bf16x6pc": 2500.0, "bf16x6db": 2500.0,
+                    "bf16x3db": 2500.0}
 KERNEL_NAME = {"f32": "gemm_f32_kernel<true,true> (forward GEMMs, v_mfma_f32_32x32x2_f32)",
                "bf16x3": "gemm_split_kernel<2,true,true> (forward GEMMs; 3 x v_mfma_f32_32x32x16_bf16 per product: "
                          "achieved = ALGORITHMIC fp32-equivalent flops, so frac <= 1/3 of the bf16 peak)",
                "bf16x6": "gemm_split_kernel<3,true,true> (forward GEMMs; 6 x v_mfma_f32_32x32x16_bf16 per product: "
                          "achieved = ALGORITHMIC fp32-equivalent flops, so frac <= 1/6 of the bf16 peak)",
+               "bf16x6db": "gemm_split_db_kernel<3,true,true> (forward GEMMs; 6 x v_mfma_f32_32x32x16_bf16 per product: "
+                           "achieved = ALGORITHMIC fp32-equivalent flops, so frac <= 1/6 of the bf16 peak)",
+               "bf16x3db": "gemm_split_db_kernel<2,true,true> (forward GEMMs; 3 x v_mfma_f32_32x32x16_bf16 per product)",
                "bf16x6pc": "gemm_split_pc_kernel<3,true,true> (forward GEMMs; 6 x v_mfma_f32_32x32x16_bf16 per product: "
                            "achieved = ALGORITHMIC fp32-equivalent flops, so frac <= 1/6 of the bf16 peak)"}
 
@@ -103,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
-    ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "bf16x6"), choices=["f32", "bf16x3", "bf16x6", "bf16x6pc"],
+    ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "bf16x6db"), choices=["f32", "bf16x3", "bf16x6", "bf16x6pc", "bf16x6db", "bf16x3db"],
                     help="GEMM arithmetic: exact fp32 MFMA, or 2-/3-term bf16 split-precision MFMA (see npvp_amd/ops.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")

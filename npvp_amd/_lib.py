@@ -56,7 +56,7 @@ def lib():
                 f"{LIB_PATH} is missing - the HIP extension has not been built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `python npvp_amd/build.py`). "
                 "npvp_amd has no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, mode=os.RTLD_NOW)        # resolve every symbol now: a broken build fails here
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args

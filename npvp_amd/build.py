@@ -52,7 +52,8 @@ def build(force=False, verbose=True):
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if force or jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        # --no-undefined: a symbol dropped from one translation unit must fail HERE, not at first call on the GPU box
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--no-undefined", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -43,6 +43,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
   float alpha;
+  int dbg;                 // profiling ablations (results INVALID): 1 = no global loads, 2 = no split VALU, 4 = no MFMA
 };
 
 // ---- operand staging: one 128 x 32 (rows x k) tile -----------------------------------
@@ -340,14 +341,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
   const bool want_cs = !AKC && p.colsum && n0 == 0;
   float cs = 0.f;
   const int t = threadIdx.x;
+  bf16x8 cfrag;
+  for (int j = 0; j < 8; ++j) cfrag[j] = (__bf16)(float)(lane + j);
   sa.load(A, p.lda, m0, p.M, 0, t);
   sb.load(B, p.ldb, n0, p.N, 0, t);
 
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
-    sa.store(ldsA, t); sb.store(ldsB, t);                // split + stage tile kt
-    __syncthreads();
-    if (kt + 1 < nk) {                                   // tile kt+1 travels HBM/L2 -> registers under the MFMAs
+    if (!(p.dbg & 2)) { sa.store(ldsA, t); sb.store(ldsB, t); }   // split + stage tile kt
+    if (!(p.dbg & 8)) __syncthreads();
+    if (kt + 1 < nk && !(p.dbg & 1)) {                   // tile kt+1 travels HBM/L2 -> registers under the MFMAs
       sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, t);
       sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, t);
     }
@@ -357,10 +360,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
       bf16x8 a0[NS], a1[NS], b0[NS], b1[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
+        if (p.dbg & 16) { a0[s] = a1[s] = b0[s] = b1[s] = cfrag; continue; }   // ablation: no LDS fragment reads
         a0[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko);
         a1[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko + 32 * 16);
         b0[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko);
         b1[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko + 32 * 16);
+      }
+      if (p.dbg & 4) {
+        asm volatile("" :: "v"(a0[0]), "v"(a1[0]), "v"(b0[0]), "v"(b1[0]), "v"(a0[NS - 1]), "v"(a1[NS - 1]), "v"(b0[NS - 1]), "v"(b1[NS - 1]));
+        continue;
       }
       if (NS == 3) {                                      // smallest terms first
         NPVP_MFMA4(a0[1], a1[1], b0[1], b1[1])
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
       NPVP_MFMA4(a0[1], a1[1], b0[0], b1[0])
       NPVP_MFMA4(a0[0], a1[0], b0[0], b1[0])
     }
-    __syncthreads();                                      // every wave is done with the stage before it is rewritten
+    if (!(p.dbg & 8)) __syncthreads();                    // every wave is done with the stage before it is rewritten
   }
   if constexpr (!AKC) {
     if (want_cs) {            // threads t and t+128 hold the two halves of column t&127
@@ -478,6 +486,145 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(GemmParams p) {
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Double-buffered, software-pipelined form of the split-precision GEMM ("db").  The ablations of
+// gemm_split_kernel (tools/gemm_bench.py --dbg) show its matrix pipe at 42-51 % even with loads and staging
+// removed: every wave serialises [stage -> barrier -> fragment reads -> 48 MFMAs -> barrier].  Here the K-step
+// is 16 deep with TWO LDS stages (2 x 24.2 KB -> still 3 workgroups per CU): within one K-step a wave issues
+// its fragment reads, then its 24 MFMAs with the split + ds_write of the NEXT tile (already in registers)
+// placed in the MFMA shadows, then one barrier.  Global loads run two tiles ahead in a second register set.
+constexpr int OPER16 = 2 * KG_STRIDE;        // one operand tile (128 rows x 16 k), one split term
+
+template <int NS, bool KC> struct SplitStager16;
+
+template <int NS> struct SplitStager16<NS, true> {    // [rows][K]: 16 lanes = 8 rows x 2 four-k halves of one k-group
+  float4 r[2];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    // rows past the edge are CLAMPED, not zero-filled: they only feed output rows/columns that are never stored,
+    // and an unconditional load keeps the K-step one basic block (the scheduler can then interleave it with MFMAs)
+    const int kof = ((t >> 4) & 1) * 8 + (t & 1) * 4, rl = (t >> 5) * 8 + ((t >> 1) & 7);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = min(row0 + rl + 64 * i, nrows - 1);
+      r[i] = ld4(src + (long long)row * ld + k0 + kof);
+    }
+  }
+  template <int I> __device__ __forceinline__ void store_part(char* base, int t) const {
+    const int off = ((t >> 4) & 1) * KG_STRIDE + (t & 1) * 8 + ((t >> 5) * 8 + ((t >> 1) & 7) + 64 * I) * 16;
+    float4 v = r[I];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x4 q;
+      q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(base + s * OPER16 + off) = q;
+      v.x -= (float)q[0]; v.y -= (float)q[1]; v.z -= (float)q[2]; v.w -= (float)q[3];
+    }
+  }
+  __device__ __forceinline__ float tile_sum() const { return 0.f; }
+};
+
+template <int NS> struct SplitStager16<NS, false> {   // [K][rows]: one row per lane, thread t>>7 takes k-group 0/1
+  float r2[2][4];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    const int row = min(row0 + (t & 127), nrows - 1), kg = t >> 7;        // clamped, see above
+    const float* q = src + (long long)(k0 + kg * 8) * ld + row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r2[j >> 2][j & 3] = q[(long long)j * ld];
+  }
+  template <int I> __device__ __forceinline__ void store_part(char* base, int t) const {
+    // half I of this lane's 8 k (4 bf16 = 8 bytes per term); two halves make the 16-byte slot
+    const int off = (t >> 7) * KG_STRIDE + (t & 127) * 16 + I * 8;
+    float a0 = r2[I][0], a1 = r2[I][1], a2 = r2[I][2], a3 = r2[I][3];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x4 q;
+      q[0] = (__bf16)a0; q[1] = (__bf16)a1; q[2] = (__bf16)a2; q[3] = (__bf16)a3;
+      *reinterpret_cast<bf16x4*>(base + s * OPER16 + off) = q;
+      a0 -= (float)q[0]; a1 -= (float)q[1]; a2 -= (float)q[2]; a3 -= (float)q[3];
+    }
+  }
+  __device__ __forceinline__ float tile_sum() const {
+    return r2[0][0] + r2[0][1] + r2[0][2] + r2[0][3] + r2[1][0] + r2[1][1] + r2[1][2] + r2[1][3];
+  }
+};
+
+template <int NS, bool AKC, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmParams p) {
+  constexpr int STAGE = 2 * NS * OPER16;                      // [A term 0..NS-1 | B term 0..NS-1]
+  constexpr int BK16 = 16;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  int m0, n0;
+  tile_of_block(p, m0, n0);
+  const int z = blockIdx.y;
+  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
+  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  const int nk = p.K / BK16;
+  const bool want_cs = !AKC && p.colsum && n0 == 0;
+  float cs = 0.f;
+  const int fa_off = h * KG_STRIDE + (wm * 64 + r) * 16;
+  const int fb_off = NS * OPER16 + h * KG_STRIDE + (wn * 64 + r) * 16;
+
+  SplitStager16<NS, AKC> a0s, a1s;       // two register sets: tiles kt+1 and kt+2
+  SplitStager16<NS, BKC> b0s, b1s;
+  // prologue: tile 0 -> stage 0, tile 1 -> set 0
+  a0s.load(A, p.lda, m0, p.M, 0, t); b0s.load(B, p.ldb, n0, p.N, 0, t);
+  if constexpr (!AKC) { if (want_cs) cs += a0s.tile_sum(); }
+  a0s.template store_part<0>(lds, t); a0s.template store_part<1>(lds, t);
+  b0s.template store_part<0>(lds + NS * OPER16, t); b0s.template store_part<1>(lds + NS * OPER16, t);
+  { const int k1 = min(BK16, p.K - BK16); a0s.load(A, p.lda, m0, p.M, k1, t); b0s.load(B, p.ldb, n0, p.N, k1, t); }
+  __syncthreads();
+
+#define NPVP_DB_STEP(KT, SA_CUR, SB_CUR, SA_NXT, SB_NXT)                                                        \
+  {                                                                                                             \
+    const char* st = lds + ((KT) & 1) * STAGE;                                                                  \
+    char* nx = lds + (((KT) + 1) & 1) * STAGE;                                                                  \
+    const int k2 = min(((KT) + 2) * BK16, p.K - BK16);     /* past the end: re-read the last tile, never consumed */ \
+    SA_NXT.load(A, p.lda, m0, p.M, k2, t); SB_NXT.load(B, p.ldb, n0, p.N, k2, t);                               \
+    bf16x8 fa0[NS], fa1[NS], fb0[NS], fb1[NS];                                                                  \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                            \
+      fa0[s] = *reinterpret_cast<const bf16x8*>(st + fa_off + s * OPER16);                                      \
+      fa1[s] = *reinterpret_cast<const bf16x8*>(st + fa_off + s * OPER16 + 32 * 16);                            \
+      fb0[s] = *reinterpret_cast<const bf16x8*>(st + fb_off + s * OPER16);                                      \
+      fb1[s] = *reinterpret_cast<const bf16x8*>(st + fb_off + s * OPER16 + 32 * 16);                            \
+    }                                                                                                           \
+    /* the stores below are unconditional: after the last tile they fill the stage nobody reads again */        \
+    if constexpr (!AKC) { if (want_cs && (KT) + 1 < nk) cs += SA_CUR.tile_sum(); }                              \
+    SA_CUR.template store_part<0>(nx, t);                                                                       \
+    if (NS == 3) { NPVP_MFMA4(fa0[1], fa1[1], fb0[1], fb1[1]) }                                                 \
+    SA_CUR.template store_part<1>(nx, t);                                                                       \
+    if (NS == 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[2], fb1[2]) }                                                 \
+    SB_CUR.template store_part<0>(nx + NS * OPER16, t);                                                         \
+    if (NS == 3) { NPVP_MFMA4(fa0[2], fa1[2], fb0[0], fb1[0]) }                                                 \
+    if (NS != 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[1], fb1[1]) }                                                 \
+    SB_CUR.template store_part<1>(nx + NS * OPER16, t);                                                         \
+    if (NS == 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[1], fb1[1]) }                                                 \
+    NPVP_MFMA4(fa0[1], fa1[1], fb0[0], fb1[0])                                                                  \
+    NPVP_MFMA4(fa0[0], fa1[0], fb0[0], fb1[0])                                                                  \
+    __syncthreads();                                                                                            \
+  }
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    NPVP_DB_STEP(kt, a0s, b0s, a1s, b1s)
+    NPVP_DB_STEP(kt + 1, a1s, b1s, a0s, b0s)
+  }
+  if (kt < nk) NPVP_DB_STEP(kt, a0s, b0s, a1s, b1s)
+#undef NPVP_DB_STEP
+
+  if constexpr (!AKC) {
+    if (want_cs) {            // threads t and t+128 hold the two k-group halves of column t&127
+      float* red = reinterpret_cast<float*>(lds);
+      red[t] = cs;
+      __syncthreads();
+      if (t < 128 && m0 + t < p.M) p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+    }
+  }
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+}
+
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
                                      long long ldc, int splits, float alpha) {
@@ -523,8 +670,11 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
                              int precision, float* colsum_a, void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  NPVP_CHECK_ARG(precision >= 0 && precision <= 3,
-                 "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x6) or 3 (bf16x6, producer/consumer waves)");
+  const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
+  precision &= 0xff;
+  NPVP_CHECK_ARG(precision >= 0 && precision <= 5,
+                 "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x6), 3 (bf16x6 producer/consumer), "
+                 "4 (bf16x6 double-buffered pipeline) or 5 (bf16x3 double-buffered pipeline)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
@@ -547,6 +697,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (splits > 1 && (!plain || ws_bytes < npvp_gemm_workspace_bytes(M, N, K) || !workspace || (N % 4) != 0)) splits = 1;
   p.splits = splits;
   p.colsum = colsum_a;
+  p.dbg = dbg;
   if (splits > 1) {
     p.K = K / splits; p.C = (float*)workspace; p.ldc = N;
     if (colsum_a) p.colsum = (float*)workspace + (long long)splits * M * N;
@@ -565,6 +716,14 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
+  } else if (precision == 4) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false>), grid, block, 0, stream, p);
+  } else if (precision == 5) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_db_kernel<2, false, false>), grid, block, 0, stream, p);
   } else {
     const dim3 block2(512);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, true>), grid, block2, 0, stream, p);

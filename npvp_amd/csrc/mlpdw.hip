@@ -36,23 +36,28 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ a, const float* __res
   }
 }
 
-// part[chunk][tap 0..8 | bias][Ch]:  dW[tap][c] = sum_{f,p} dout[f,p,c] * a[f, p + tap, c];  db[c] = sum dout
+// part[chunk][tap 0..8 | bias][Ch]:  dW[tap][c] = sum_{f,p} dout[f,p,c] * a[f, p + tap, c];  db[c] = sum dout.
+// Block = 64 channel-quads x 4 pixel groups (pixel p handled by group p & 3): 4x the loads in flight of the first
+// version (one thread per channel-quad walking all 64 pixels), fixed-order LDS reduction over the 4 groups.
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dout,
                                                               float* __restrict__ part, int H, int W, int Ch, int frames,
                                                               int frames_per_chunk) {
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c >= Ch) return;
+  __shared__ float4 red[3][10][64];
+  const int cx = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  const bool live = c < Ch;
   const int P = H * W;
   float4 aw[9], ab = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int t = 0; t < 9; ++t) aw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int f0 = blockIdx.y * frames_per_chunk, f1 = min(frames, f0 + frames_per_chunk);
-  for (long long f = f0; f < f1; ++f) {
-    const float* af = a + f * P * Ch + c;
-    const float* df = dout + f * P * Ch + c;
-    for (int h = 0; h < H; ++h) {
-      for (int w = 0; w < W; ++w) {
-        const float4 d = ld4(df + (long long)(h * W + w) * Ch);
+  if (live) {
+    for (long long f = f0; f < f1; ++f) {
+      const float* af = a + f * P * Ch + c;
+      const float* df = dout + f * P * Ch + c;
+      for (int p = pg; p < P; p += 4) {
+        const int h = p / W, w = p - h * W;
+        const float4 d = ld4(df + (long long)p * Ch);
         ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
 #pragma unroll
         for (int ky = -1; ky <= 1; ++ky) {
@@ -70,10 +75,22 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
       }
     }
   }
-  float* o = part + (long long)blockIdx.y * 10 * Ch;
+  if (pg > 0) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) st4(o + t * Ch + c, aw[t]);
-  st4(o + 9 * Ch + c, ab);
+    for (int t = 0; t < 9; ++t) red[pg - 1][t][cx] = aw[t];
+    red[pg - 1][9][cx] = ab;
+  }
+  __syncthreads();
+  if (pg == 0 && live) {
+    float* o = part + (long long)blockIdx.y * 10 * Ch;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      float4 s = t < 9 ? aw[t] : ab;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) { const float4 q = red[g][t][cx]; s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w; }
+      st4(o + t * Ch + c, s);
+    }
+  }
 }
 
 // im2col for a 3x3 / pad 1 convolution over channels-last frames (EventEncoder conv2, ref/models/submodules.py:376):
@@ -146,7 +163,7 @@ extern "C" int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dw
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv_wgrad: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), "dwconv_wgrad: workspace too small");
   const int chunks = dw_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 255) / 256, nchunks), dim3(256), 0, stream, a, dout,
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 63) / 64, nchunks), dim3(256), 0, stream, a, dout,
                      (float*)workspace, H, W, Ch, frames, fpc);
   NPVP_CHECK_LAUNCH();
   const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream);

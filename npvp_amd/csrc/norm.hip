@@ -331,10 +331,13 @@ __global__ void frameln_act_bwd_apply_kernel(FlnParams p, const float* __restric
   }
 }
 
-// dw[e] = sum_f dy_ln*hhat, db[e] = sum_f dy_ln.  grid.x covers e (float4), grid.y = frame chunks whose
-// partial sums go to part[chunk][2][per_frame] (summed by sum_rows_kernel).
-__global__ void frameln_act_bwd_params_kernel(FlnParams p, const float* __restrict__ dout, float* __restrict__ part,
-                                              int frames, int frames_per_chunk) {
+// One pass for BOTH the input gradient and the parameter gradients: thread = 4 consecutive elements e of the frame,
+// loop over the frames of a chunk:  dh[f][e] = rstd (g - s1[f] - hhat s2[f]),  dw[e] += dy_ln*hhat,  db[e] += dy_ln.
+// grid.x covers e (float4), grid.y = frame chunks whose partial sums go to part[chunk][2][per_frame]
+// (summed by sum_rows_kernel).  Saves the separate apply pass of the first version (a full re-read of dout and h).
+__global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ s1,
+                                             const float* __restrict__ s2, float* __restrict__ dh,
+                                             float* __restrict__ part, int frames, int frames_per_chunk) {
   const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e >= p.per_frame) return;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
@@ -344,7 +347,7 @@ __global__ void frameln_act_bwd_params_kernel(FlnParams p, const float* __restri
   const int f1 = min(frames, f0 + frames_per_chunk);
   for (long long f = f0; f < f1; ++f) {
     const long long g0 = f * p.per_frame + e;
-    const float mu = p.mean[f], rs = p.rstd[f];
+    const float mu = p.mean[f], rs = p.rstd[f], a1 = s1[f], a2 = s2[f];
     const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
     const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
@@ -353,6 +356,10 @@ __global__ void frameln_act_bwd_params_kernel(FlnParams p, const float* __restri
     const float dw_ = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
     aw.x += dx_ * hx; aw.y += dy_ * hy; aw.z += dz_ * hz; aw.w += dw_ * hw;
     ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
+    float4 o;
+    o.x = rs * (dx_ * ww.x - a1 - hx * a2); o.y = rs * (dy_ * ww.y - a1 - hy * a2);
+    o.z = rs * (dz_ * ww.z - a1 - hz * a2); o.w = rs * (dw_ * ww.w - a1 - hw * a2);
+    st4(dh + g0, o);
   }
   float* o = part + (long long)blockIdx.y * 2 * p.per_frame;
   st4(o + e, aw);
@@ -511,13 +518,10 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   float* s1 = (float*)workspace; float* s2 = s1 + frames; float* part = s2 + frames;
   hipLaunchKernelGGL(frameln_act_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, p, dout, s1, s2);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(frameln_act_bwd_apply_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, dout,
-                     (const float*)s1, (const float*)s2, dh);
-  NPVP_CHECK_LAUNCH();
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(frameln_act_bwd_params_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
-                     dout, part, frames, fpc);
+  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
+                     dout, (const float*)s1, (const float*)s2, dh, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, per_frame, stream) ||
       launch_sum_rows((const float*)part + per_frame, db, nchunks, 2 * per_frame, per_frame, stream)) {

@@ -92,8 +92,9 @@ NO_DROP = Drop(0.0)
 #   bf16x3 2-term bf16 split, 3 v_mfma_f32_32x32x16_bf16 per product, ~2^-16 relative product error
 #   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade; every wave stages and multiplies
 #   bf16x6pc same arithmetic, producer/consumer waves (4 MFMA waves + 4 staging waves per workgroup)
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3}
-GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6")]
+#   bf16x6db / bf16x3db: same arithmetic, 16-deep K-steps, two LDS stages, staging interleaved with the MFMAs
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3, "bf16x6db": 4, "bf16x3db": 5}
+GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6db")]
 
 
 def set_gemm_precision(name):

@@ -32,7 +32,7 @@ def close(a, b, tol=TOL, what=""):
     assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16x6", "bf16x6pc"])
+@pytest.fixture(scope="module", params=["f32", "bf16x3", "bf16x6", "bf16x6pc", "bf16x6db", "bf16x3db"])
 def K(request):
     """Every test runs on both GEMM arithmetic paths: exact fp32 MFMA and the bf16x3 split-precision MFMA."""
     import npvp_amd
@@ -41,7 +41,7 @@ def K(request):
     ops.rng.manual_seed(1234, torch.device(DEV))
     ops.set_gemm_precision(request.param)
     yield ops
-    ops.set_gemm_precision("bf16x6")
+    ops.set_gemm_precision("bf16x6db")
 
 
 def g(t):
@@ -82,7 +82,7 @@ def test_gemm_wgrad_splitk_long_reduction(K):
     from npvp_amd._lib import lib
     assert lib().npvp_gemm_workspace_bytes(N, K_, R) > 0, "expected the split-K path for this shape"
     dw, db = K.linear_wgrad(dy.to(DEV), x.to(DEV), True)
-    close(dw, dy.T @ x, tol=5e-5 if K.GEMM_PRECISION == 1 else 1e-5, what="split-K wgrad")
+    close(dw, dy.T @ x, tol=5e-5 if K.GEMM_PRECISION in (1, 5) else 1e-5, what="split-K wgrad")
     close(db, dy.sum(0), tol=1e-5, what="split-K fused bias grad")
     close(K.colsum(dy.to(DEV)), dy.sum(0), tol=1e-5, what="colsum")
 
@@ -94,7 +94,7 @@ def test_gemm_full_size_against_rocblas(K):
         x = torch.randn(R, K_, device=DEV); w = torch.randn(N, K_, device=DEV) / math.sqrt(K_)
         y = K.linear_fwd(x, w, None)
         ref = (x.double() @ w.double().T).float()
-        tol = 5e-5 if K.GEMM_PRECISION == 1 else 1e-5
+        tol = 5e-5 if K.GEMM_PRECISION in (1, 5) else 1e-5
         close(y, ref, tol=tol, what=f"fwd {N}x{K_}")
         dy = torch.randn(R, N, device=DEV)
         close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=tol, what=f"wgrad {N}x{K_}")

@@ -7,6 +7,8 @@ from npvp_amd import ops
 
 dev = "cuda:0"
 modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["f32", "bf16x3", "bf16x6"]
+dbg = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--dbg=")]
+dbg = dbg[0] if dbg else 0
 iters = 20
 R = 20480
 shapes = [(512, 512), (1024, 512), (2048, 512), (512, 2048), (512, 1024)]      # (N_out, K_in) of the linears
@@ -26,6 +28,7 @@ def timeit(fn):
 
 for mode in modes:
     ops.set_gemm_precision(mode)
+    ops.GEMM_PRECISION |= dbg << 8        # ablation flags: 1 no global loads, 2 no split/stage, 4 no MFMA (results invalid)
     tot_t, tot_f = 0.0, 0.0
     for N, K in shapes:
         x = torch.randn(R, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
