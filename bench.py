@@ -121,6 +121,7 @@ def main():
     rank, world, local = dp.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    local = local % torch.cuda.device_count()         # NPVP_DIST_BACKEND=gloo rehearsal: ranks may share a card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -30,12 +30,13 @@ def init_distributed(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("NPVP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            # gloo + CUDA tensors (several ranks sharing one card) is the single-GPU rehearsal of the RCCL path
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
