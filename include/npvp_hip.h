@@ -50,7 +50,12 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
-                  void* workspace, long long ws_bytes, npvp_stream_t stream);
+                  const void* b_pre, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* Weights change once per optimiser step but are staged by every tile of three GEMMs: split them ONCE into the bf16
+ * term planes the split-precision kernel consumes (3 terms x N*K bf16 each, blocked like the LDS image).
+ * F feeds y = x w^T (pass as b_pre with b_kc = 1), D feeds dx = dy w (b_pre with b_kc = 0).  b_pre is optional
+ * (NULL = split B on the fly) and only honoured by precision 4 with a_kc = 1. */
+int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void* D, npvp_stream_t stream);
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.

@@ -21,6 +21,7 @@
 // so that the 8 XCDs each walk a contiguous run of tiles (B = the weight stays in the
 // XCD's L2; each A row-panel is fetched by one XCD).
 #include "common.h"
+#include <type_traits>
 
 namespace npvp {
 
@@ -43,6 +44,9 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
   float alpha;
+  const void* b_pre;       // pre-split B planes (bf16, blocked [term][K/8][N][8]) or null: see split_weight kernels
+  long long b_pre_plane;   // bf16 elements per term plane (= N*K)
+  int colgroups;           // XCD tiling: 1 = every XCD sweeps all tile columns; G>1 = XCD x owns column group x%G (see tile_of_block)
   int dbg;                 // profiling ablations (results INVALID): 1 = no global loads, 2 = no split VALU, 4 = no MFMA
 };
 
@@ -139,12 +143,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
   }
 }
 
-// XCD-aware, bijective tile remap (cdna guide T1): the 8 XCDs each walk a contiguous run of tiles
+// XCD-aware, bijective tile remap (cdna guide T1).  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one),
+// each XCD has a private 4 MiB L2.  Default (colgroups = 1): XCD x walks a contiguous run of tiles, tile_n fastest, so an
+// A row-panel is fetched by one XCD and reused from its L2 across the tile columns - but then the XCD needs ALL of B
+// resident, and the 4 MiB weights of the 512<->2048 layers do not fit next to the streaming A panels (rocprofv3:
+// FETCH_SIZE 2.5x the algorithmic bytes).  colgroups = G > 1: XCD x owns column group x % G (a B slice <= 2 MB that stays
+// L2 resident) and row group x / G; A panels are then read by G XCDs.  Placement only changes speed, never results.
 __device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int& n0) {
   const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-  const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  const int tile_m = nid / p.tiles_n, tile_n = nid - tile_m * p.tiles_n;
+  const int xcd = bid & 7, loc = bid >> 3;
+  int tile_m, tile_n;
+  if (p.colgroups > 1) {
+    const int G = p.colgroups, tn_g = p.tiles_n / G, tm_g = p.tiles_m / (8 / G);
+    const int lm = loc / tn_g;
+    tile_m = (xcd / G) * tm_g + lm;
+    tile_n = (xcd % G) * tn_g + (loc - lm * tn_g);
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    tile_m = nid / p.tiles_n;
+    tile_n = nid - tile_m * p.tiles_n;
+  }
   m0 = tile_m * BM; n0 = tile_n * BN;
 }
 
@@ -548,7 +567,64 @@ template <int NS> struct SplitStager16<NS, false> {   // [K][rows]: one row per 
   }
 };
 
-template <int NS, bool AKC, bool BKC>
+// B operand from PRE-SPLIT planes: weights change once per optimiser step but are staged by every tile of three
+// GEMMs, so they are split once (split_weight_kernel) into NS bf16 planes laid out exactly like the LDS image,
+// [term][K/8][N][8 k]: a tile's (term, k-group) slab is 128 rows x 16 B = 2 KB contiguous.  Staging B is then three
+// coalesced 16-byte loads + three ds_write_b128 per thread and K-step - no conversion VALU at all.  (The K-step of
+// the db kernel is issue bound: 72 MFMA + ~360 VALU + ~90 LDS/VMEM instructions per SIMD against 2304 MFMA cycles.)
+template <int NS> struct PreStager16 {
+  uint4 r[NS];
+  __device__ __forceinline__ void load(const GemmParams& p, int n0, int k0, int t) {
+    const int row = min(n0 + (t & 127), p.N - 1), kg = t >> 7;
+    const uint4* base = reinterpret_cast<const uint4*>(p.b_pre) + (long long)(k0 / 8 + kg) * p.N + row;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) r[s] = base[(long long)s * (p.b_pre_plane / 8)];
+  }
+  template <int I> __device__ __forceinline__ void store_part(char* base, int t) const {
+    const int off = (t >> 7) * KG_STRIDE + (t & 127) * 16;
+    if (I == 0) {
+      *reinterpret_cast<uint4*>(base + off) = r[0];
+      if (NS > 2) *reinterpret_cast<uint4*>(base + 2 * OPER16 + off) = r[NS - 1];
+    } else {
+      *reinterpret_cast<uint4*>(base + OPER16 + off) = r[1];
+    }
+  }
+};
+
+// w [N][K] (row stride ld) -> fwd planes F[term][K/8][N][8 over k]  and  dgrad planes D[term][N/8][K][8 over n]
+__global__ void split_weight_fwd_kernel(const float* __restrict__ w, long long ld, int N, int K, __bf16* __restrict__ F) {
+  const long long total = (long long)N * (K / 8);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), kb = (int)(i / N);
+    const float4 a = ld4(w + (long long)n * ld + kb * 8), b = ld4(w + (long long)n * ld + kb * 8 + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      bf16x8 q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { q[j] = (__bf16)v[j]; v[j] -= (float)q[j]; }
+      *reinterpret_cast<bf16x8*>(F + ((long long)s * N * K) + i * 8) = q;
+    }
+  }
+}
+__global__ void split_weight_dgrad_kernel(const float* __restrict__ w, long long ld, int N, int K, __bf16* __restrict__ D) {
+  const long long total = (long long)(N / 8) * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K), nb = (int)(i / K);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[(long long)(nb * 8 + j) * ld + k];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      bf16x8 q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { q[j] = (__bf16)v[j]; v[j] -= (float)q[j]; }
+      *reinterpret_cast<bf16x8*>(D + ((long long)s * N * K) + i * 8) = q;
+    }
+  }
+}
+
+template <int NS, bool AKC, bool BKC, bool BPRE>
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmParams p) {
   constexpr int STAGE = 2 * NS * OPER16;                      // [A term 0..NS-1 | B term 0..NS-1]
   constexpr int BK16 = 16;
@@ -568,13 +644,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   const int fb_off = NS * OPER16 + h * KG_STRIDE + (wn * 64 + r) * 16;
 
   SplitStager16<NS, AKC> a0s, a1s;       // two register sets: tiles kt+1 and kt+2
-  SplitStager16<NS, BKC> b0s, b1s;
+  typename std::conditional<BPRE, PreStager16<NS>, SplitStager16<NS, BKC>>::type b0s, b1s;
+#define NPVP_BLOAD(ST, K0) { if constexpr (BPRE) ST.load(p, n0, (K0) + z * p.K, t); else ST.load(B, p.ldb, n0, p.N, (K0), t); }
   // prologue: tile 0 -> stage 0, tile 1 -> set 0
-  a0s.load(A, p.lda, m0, p.M, 0, t); b0s.load(B, p.ldb, n0, p.N, 0, t);
+  a0s.load(A, p.lda, m0, p.M, 0, t); NPVP_BLOAD(b0s, 0)
   if constexpr (!AKC) { if (want_cs) cs += a0s.tile_sum(); }
   a0s.template store_part<0>(lds, t); a0s.template store_part<1>(lds, t);
   b0s.template store_part<0>(lds + NS * OPER16, t); b0s.template store_part<1>(lds + NS * OPER16, t);
-  { const int k1 = min(BK16, p.K - BK16); a0s.load(A, p.lda, m0, p.M, k1, t); b0s.load(B, p.ldb, n0, p.N, k1, t); }
+  { const int k1 = min(BK16, p.K - BK16); a0s.load(A, p.lda, m0, p.M, k1, t); if constexpr (!BPRE) NPVP_BLOAD(b0s, k1) }
   __syncthreads();
 
 #define NPVP_DB_STEP(KT, SA_CUR, SB_CUR, SA_NXT, SB_NXT)                                                        \
@@ -582,7 +659,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
     const char* st = lds + ((KT) & 1) * STAGE;                                                                  \
     char* nx = lds + (((KT) + 1) & 1) * STAGE;                                                                  \
     const int k2 = min(((KT) + 2) * BK16, p.K - BK16);     /* past the end: re-read the last tile, never consumed */ \
-    SA_NXT.load(A, p.lda, m0, p.M, k2, t); SB_NXT.load(B, p.ldb, n0, p.N, k2, t);                               \
+    SA_NXT.load(A, p.lda, m0, p.M, k2, t);                                                                      \
+    /* pre-split B needs no conversion: ONE register set, tile kt+1 loaded at the top of step kt, stored at its end */ \
+    if constexpr (BPRE) { NPVP_BLOAD(SB_CUR, min(((KT) + 1) * BK16, p.K - BK16)) } else { NPVP_BLOAD(SB_NXT, k2) }  \
     bf16x8 fa0[NS], fa1[NS], fb0[NS], fb1[NS];                                                                  \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                            \
       fa0[s] = *reinterpret_cast<const bf16x8*>(st + fa_off + s * OPER16);                                      \
@@ -596,13 +675,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
     if (NS == 3) { NPVP_MFMA4(fa0[1], fa1[1], fb0[1], fb1[1]) }                                                 \
     SA_CUR.template store_part<1>(nx, t);                                                                       \
     if (NS == 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[2], fb1[2]) }                                                 \
-    SB_CUR.template store_part<0>(nx + NS * OPER16, t);                                                         \
+    if constexpr (!BPRE) SB_CUR.template store_part<0>(nx + NS * OPER16, t);                                    \
     if (NS == 3) { NPVP_MFMA4(fa0[2], fa1[2], fb0[0], fb1[0]) }                                                 \
     if (NS != 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[1], fb1[1]) }                                                 \
-    SB_CUR.template store_part<1>(nx + NS * OPER16, t);                                                         \
+    if constexpr (!BPRE) SB_CUR.template store_part<1>(nx + NS * OPER16, t);                                    \
     if (NS == 3) { NPVP_MFMA4(fa0[0], fa1[0], fb0[1], fb1[1]) }                                                 \
     NPVP_MFMA4(fa0[1], fa1[1], fb0[0], fb1[0])                                                                  \
     NPVP_MFMA4(fa0[0], fa1[0], fb0[0], fb1[0])                                                                  \
+    if constexpr (BPRE) { SB_CUR.template store_part<0>(nx + NS * OPER16, t); SB_CUR.template store_part<1>(nx + NS * OPER16, t); } \
     __syncthreads();                                                                                            \
   }
 
@@ -613,6 +693,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   }
   if (kt < nk) NPVP_DB_STEP(kt, a0s, b0s, a1s, b1s)
 #undef NPVP_DB_STEP
+#undef NPVP_BLOAD
 
   if constexpr (!AKC) {
     if (want_cs) {            // threads t and t+128 hold the two k-group halves of column t&127
@@ -663,12 +744,25 @@ extern "C" long long npvp_gemm_workspace_bytes(int M, int N, int K) {
   return s > 1 ? ((long long)s * M * N + (long long)s * M) * 4 : 0;
 }
 
+// w [N][K] fp32 -> bf16 planes (3 terms each): F for y = x w^T (B operand [N][K]), D for dx = dy w (B operand [K][N]).
+// Each output holds 3*N*K bf16.  Either may be null.
+extern "C" int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void* D, hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ld % 4 == 0, "split_weight: N, K must be multiples of 8");
+  NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0, "split_weight: w must be 16-byte aligned");
+  const long long total = (long long)N * K / 8;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  if (F) { hipLaunchKernelGGL(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)F); NPVP_CHECK_LAUNCH(); }
+  if (D) { hipLaunchKernelGGL(split_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)D); NPVP_CHECK_LAUNCH(); }
+  return NPVP_OK;
+}
+
 // See include/npvp_hip.h for the contract.
 extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B,
                              long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
-                             int precision, float* colsum_a, void* workspace, long long ws_bytes, hipStream_t stream) {
+                             int precision, float* colsum_a, const void* b_pre, void* workspace, long long ws_bytes,
+                             hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
   precision &= 0xff;
@@ -698,6 +792,19 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.splits = splits;
   p.colsum = colsum_a;
   p.dbg = dbg;
+  // pre-split B planes are only consumed by the db bf16x6 kernel with a row-major A and an unsplit reduction
+  p.b_pre = (precision == 4 && a_kc && splits == 1 && K % 16 == 0 && N % 8 == 0) ? b_pre : nullptr;
+  p.b_pre_plane = (long long)N * K;
+  b_pre = p.b_pre;
+  // B-slice residency rule (see tile_of_block): smallest G in {1,2,4,8} with N*K*4/G <= 2 MB that tiles the grid evenly
+  p.colgroups = 1;
+  if (splits == 1 && !(dbg & 32)) {
+    for (int G = 1; G <= 8; G *= 2) {
+      if ((long long)N * K * 4 / G > (2ll << 20)) continue;
+      if (G > 1 && (p.tiles_n % G == 0) && (p.tiles_m % (8 / G) == 0) && ((p.tiles_m * p.tiles_n) % 8 == 0)) p.colgroups = G;
+      break;
+    }
+  }
   if (splits > 1) {
     p.K = K / splits; p.C = (float*)workspace; p.ldc = N;
     if (colsum_a) p.colsum = (float*)workspace + (long long)splits * M * N;
@@ -717,13 +824,14 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
   } else if (precision == 4) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false>), grid, block, 0, stream, p);
+    if (b_pre && a_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);
   } else if (precision == 5) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_db_kernel<2, false, false>), grid, block, 0, stream, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true, false>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_split_db_kernel<2, false, false, false>), grid, block, 0, stream, p);
   } else {
     const dim3 block2(512);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, true>), grid, block2, 0, stream, p);

@@ -102,6 +102,41 @@ def set_gemm_precision(name):
     GEMM_PRECISION = GEMM_MODES[name]
 
 
+class WeightPlanes:
+    """Optional (NPVP_PRESPLIT=1) per-step cache of pre-split weight planes (npvp_split_weight) for the B operand of
+    the forward / dgrad GEMMs.  Measured on MI355X: it removes half of the split VALU work but does not change the
+    GEMM time (the K-step is not VALU-issue bound after all: 150.7 vs 151.4 TF over the c1 shapes), so it is OFF by
+    default.  The cache lives ON the owning tensor object (the Parameter, or the flat parameter buffer it is a view
+    of), never in a table keyed by device address: a freed weight's address is reused by the next model's weights.
+    An entry is re-split after `invalidate()` (FlatAdamW.step) or an in-place torch update (version counter)."""
+    epoch = 0
+    enabled = os.environ.get("NPVP_PRESPLIT", "0") == "1"
+
+    @classmethod
+    def invalidate(cls):
+        cls.epoch += 1
+
+    @classmethod
+    def get(cls, w, want):
+        """want = 'F' (forward, B = w as [N][K]) or 'D' (dgrad, B = w as [K][N]); returns a device buffer or None."""
+        if not cls.enabled or GEMM_PRECISION != 4 or w.dim() != 2 or w.shape[0] % 8 or w.shape[1] % 8 or w.stride(1) != 1:
+            return None
+        owner = w._base if w._base is not None else w
+        if not owner.is_leaf and owner.grad_fn is not None:
+            return None                     # a temporary (e.g. a permuted conv weight): nothing persistent to cache on
+        store = owner.__dict__.setdefault("_npvp_planes", {})
+        key = (w.storage_offset(), tuple(w.shape), w.stride(0))
+        ent = store.get(key)
+        if ent is None or ent[0] != cls.epoch or ent[1] != w._version:
+            N, K = w.shape
+            planes = ent[2] if ent is not None else torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
+            check(lib().npvp_split_weight(_ptr(w), w.stride(0), N, K, _p(planes[0].data_ptr()), _p(planes[1].data_ptr()),
+                                          _stream()), "npvp_split_weight")
+            ent = (cls.epoch, w._version, planes)
+            store[key] = ent
+        return ent[2][0 if want == "F" else 1]
+
+
 class GemmProbe:
     """bench.py's live roofline probe: when armed, every GEMM launch of the probed operand layout is bracketed
     by a pair of HIP events on the launching stream (no synchronisation; read after the timed region)."""
@@ -125,7 +160,7 @@ class GemmProbe:
 
 # --------------------------------------------------------------------------- raw kernel wrappers
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         drop=NO_DROP, alpha=1.0, colsum_a=None):
+         drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None):
     _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
     wsb = L.npvp_gemm_workspace_bytes(M, N, K)
@@ -140,7 +175,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
                           drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, GEMM_PRECISION, _ptr(colsum_a),
-                          _ptr(ws), wsn, _stream()),
+                          _ptr(b_pre), _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
@@ -153,7 +188,8 @@ def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP):
     R, K = x.shape
     N = w.shape[0]
     y = torch.empty(R, N, dtype=torch.float32, device=x.device)
-    return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual, drop=drop)
+    return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual,
+                drop=drop, b_pre=WeightPlanes.get(w, "F") if R >= 1024 else None)
 
 
 def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
@@ -161,7 +197,8 @@ def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
     R, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
-    return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop)
+    return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop,
+                b_pre=WeightPlanes.get(w, "D") if R >= 1024 else None)
 
 
 def linear_wgrad(dy, x, with_bias_grad=False):

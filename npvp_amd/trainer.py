@@ -101,6 +101,7 @@ class FlatAdamW:
                                 P(self.v.data_ptr()), self.total, P(self.hyper.data_ptr()), self.betas[0], self.betas[1],
                                 self.eps, self.weight_decay, clip_ptr, self.clip_begin, self.clip_end, 1, s),
               "npvp_adamw_step")
+        ops.WeightPlanes.invalidate()        # the parameters just changed under the cached bf16 planes
 
     def grad_norm(self):
         """Total L2 norm of the clipped range measured by the last step() (device scalar)."""
