@@ -65,7 +65,8 @@ int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y,
 long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C);
 int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                        const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
-                       void* workspace, long long ws_bytes, npvp_stream_t stream);
+                       const float* dres /* nullable: dx += dres, the residual branch's gradient */, void* workspace,
+                       long long ws_bytes, npvp_stream_t stream);
 
 /* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
  * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL

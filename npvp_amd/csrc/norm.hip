@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      float* __restrict__ dx, float* __restrict__ partial, long long rows,
-                                                     int relu) {
+                                                     int relu, const float* __restrict__ dres) {
   constexpr int C = NV * 256;
   __shared__ float red[4][2 * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       o.y = rs * (g[i].y - s1 - xh[i].y * s2);
       o.z = rs * (g[i].z - s1 - xh[i].z * s2);
       o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+      if (dres) { const float4 e = ld4(dres + row * C + c0); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
       st4(dx + row * C + c0, o);
     }
   }
@@ -423,7 +424,7 @@ extern "C" long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C) {
 
 extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                                   const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
-                                  void* workspace, long long ws_bytes, hipStream_t stream) {
+                                  const float* dres, void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0, "layernorm_bwd: no rows");
   NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm_bwd: C must be 256, 512, 768 or 1024");
   const int nb = ln_bwd_blocks(rows);
@@ -431,10 +432,10 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   float* part = (float*)workspace;
   dim3 grid(nb), block(256);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]

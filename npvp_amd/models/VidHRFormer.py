@@ -199,18 +199,19 @@ class VidHRFormerBlockEnc(nn.Module):
         beta, gamma = memory_pos
         x = x.contiguous()
         # spatial window attention: x += drop_path(SLMHSA(fuse(LN1 x), value = LN1 x))           ref :87-88
-        x1 = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, x1 = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.SLMHSA.fused(pos_fuser(x1, beta, gamma), x1, x, Drop(dp, 1, T * P, N))
         # conv feed-forward: x += drop_path(MlpDWBN(LN2 x))                                       ref :91
-        x = self.SpatialFFN.fused(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x, dp)
+        x, x1 = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self.SpatialFFN.fused(x1, x, dp)
         # temporal attention with the encoder mask: x += drop1(tMHA(q=k=fuse(LN3 x), v=LN3 x))    ref :94-107
-        x1 = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        x, x1 = ops.layernorm_res(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         temp = pos_fuser(x1, beta, gamma)
         cfg = AttnCfg(1, N, P, W, 0, T, T, self.num_heads, 1, pd)
         x = self.temporal_MHSA.self_attention(temp.reshape(-1, C), x1.reshape(-1, C), cfg, x.reshape(-1, C),
                                               Drop(pd)).view(N, T, H, W, C)
         # token FFN: x += drop3(linear2(drop2(GELU(linear1(LN4 x)))))                             ref :110-112
-        x1 = ops.layernorm(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        x, x1 = ops.layernorm_res(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)
         return ops.ffn(x1, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, pd)
 
 
@@ -286,25 +287,27 @@ class VidHRFormerBlockDecNAR(nn.Module):
         tb, tg = tgt_pos
         tgt = tgt.contiguous()
         # spatial window attention over fuse(LN1 tgt + query_evt), value LN1 tgt                  ref :210-212
-        t2 = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        tgt, t2 = ops.layernorm_res(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.SLMHSA.fused(pos_fuser(t2, tb, tg, add=query_evt), t2, tgt, Drop(dp, 1, T2 * P, N))
-        x = self.SpatialFFN.fused(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x, dp)   # :214
+        x, x1 = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self.SpatialFFN.fused(x1, x, dp)                                                                     # :214
         # temporal self-attention (no mask)                                                       ref :217-221
-        x1 = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        x, x1 = ops.layernorm_res(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         temp = pos_fuser(x1, tb, tg)
         cfg = AttnCfg(1, N, P, W, 0, T2, T2, self.num_heads, 0, pd)
         x = self.temporal_MHSA.self_attention(temp.reshape(-1, C), x1.reshape(-1, C), cfg, x.reshape(-1, C),
                                               Drop(pd)).view(N, T2, H, W, C)
-        x1 = ops.layernorm(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)                                # :224-226
+        x, x1 = ops.layernorm_res(x, self.norm4.weight, self.norm4.bias, self.norm4.eps)                         # :224-226
         x = ops.ffn(x1, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, pd)
         # encoder-decoder attention; its drop_path acts per TIME-STEP (tensor is (T2, N*H*W, C))   ref :229-239
-        x1 = ops.layernorm(x, self.norm5.weight, self.norm5.bias, self.norm5.eps)
+        x, x1 = ops.layernorm_res(x, self.norm5.weight, self.norm5.bias, self.norm5.eps)
         key = fused_memory if fused_memory is not None else pos_fuser(memory, *memory_pos)
         query = pos_fuser(x1, tb, tg, add=query_evt)
         cfg = AttnCfg(1, N, P, W, 0, T2, T1, self.num_heads, 0, pd)
         x = self.EncDecAttn.cross_attention(query.reshape(-1, C), key.reshape(-1, C), memory.reshape(-1, C), cfg,
                                             x.reshape(-1, C), Drop(dp, 1, P, T2)).view(N, T2, H, W, C)
-        return self.SpatialFFN1.fused(ops.layernorm(x, self.norm6.weight, self.norm6.bias, self.norm6.eps), x, dp)  # :243
+        x, x1 = ops.layernorm_res(x, self.norm6.weight, self.norm6.bias, self.norm6.eps)
+        return self.SpatialFFN1.fused(x1, x, dp)                                                                     # :243
 
 
 class VidHRformerDecoderNAR(nn.Module):

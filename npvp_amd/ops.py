@@ -309,12 +309,53 @@ class _LayerNorm(torch.autograd.Function):
         db = torch.empty_like(b)
         ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
-                                   _ptr(db), rows, C, ctx.relu, _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+                                   _ptr(db), rows, C, ctx.relu, _p(0), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
         return dx.reshape(ctx.shape), dw, db, None, None
 
 
 def layernorm(x, w, b, eps=1e-5, relu=False):
     return _LayerNorm.apply(x, w, b, eps, relu)
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """(x, LN(x)) for the pre-norm residual pattern  x + f(LN(x))  of every sub-layer (ref VidHRFormer.py:87-112).
+    Returning x through the Function lets backward fold the residual branch's gradient into the LayerNorm backward
+    kernel (dx = d_residual + LN'(dy)) instead of leaving a separate [R, C] add to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _chk(x, w, b)
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, C, eps, 0,
+                                       _stream()), "npvp_layernorm_fwd")
+        ctx.save_for_backward(x2, w, b, mean, rstd)
+        ctx.shape = x.shape
+        return x.view_as(x), y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2, w, b, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        L = lib()
+        dx, dw, db = torch.empty_like(x2), torch.empty_like(w), torch.empty_like(b)
+        ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+        if dy is None:
+            return dres, None, None, None
+        dy2 = _c(dy).reshape(rows, C)
+        dr2 = None if dres is None else _c(dres).reshape(rows, C)
+        check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
+                                   _ptr(db), rows, C, 0, _ptr(dr2), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+        return dx.reshape(ctx.shape), dw, db, None
+
+
+def layernorm_res(x, w, b, eps=1e-5):
+    """returns (x, LN(x)); use the returned x as the residual operand"""
+    return _LayerNormRes.apply(x, w, b, eps)
 
 
 class _PosFuse(torch.autograd.Function):

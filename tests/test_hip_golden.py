@@ -1,6 +1,8 @@
 """GPU: the HIP path (npvp_amd, through the C ABI) reproduces the golden vectors captured from the
 imported reference, and agrees with the oracle at larger / full BASELINE sizes.  Bar: 1e-3 rel fp32
 (BASELINE.json north_star); the fp32-MFMA GEMM path is held to 1e-4 here so regressions show early."""
+import os
+
 import pytest
 import torch
 
@@ -16,7 +18,7 @@ MODE = "bf16x6"
 MODE_TOL = {"f32": 1e-4, "bf16x6": 1e-4, "bf16x6pc": 1e-4, "bf16x6db": 1e-4, "bf16x3": 5e-3, "bf16x3db": 5e-3}
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x6", "bf16x6pc", "bf16x6db", "bf16x3"])
+@pytest.fixture(scope="module", params=["bf16x6db", "f32"] + (["bf16x6", "bf16x6pc", "bf16x3"] if os.environ.get("NPVP_TEST_ALL_MODES") else []))
 def impl(request):
     """The exact fp32-MFMA path and the default bf16x6 split path must reproduce the reference's vectors to 1e-4
     (north_star bar: 1e-3).  bf16x3 (2-term split, ~2^-16 product error) is an opt-in fast mode: forward outputs
