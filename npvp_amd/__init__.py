@@ -7,11 +7,11 @@ anywhere, but calling an op without the built library or without a GPU raises - 
 """
 from .models import (Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, VidHRFormerBlockEnc, VidHRFormerBlockDecNAR,
                      SpatialLocalMultiheadAttention, MlpDWBN, MultiheadAttention, CoorGenerator, NRMLP, PosFeatFuser,
-                     EventEncoder, L1Loss, Div_KL, DropPath)
-from .trainer import FlatAdamW, predictor_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg
+                     EventEncoder, L1Loss, Div_KL, DropPath, ResnetEncoder, ResnetDecoder, build_frozen_autoencoder)
+from .trainer import FlatAdamW, predictor_train_step, full_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg
 from . import ops
 
 __all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
            "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
-           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "FlatAdamW", "predictor_train_step",
+           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "FlatAdamW", "predictor_train_step", "full_train_step",
            "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops"]

@@ -178,3 +178,16 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
     if sync:
         out = {k: (None if v is None else float(v)) for k, v in out.items()}
     return out
+
+
+def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0,
+                    sync=True, grad_sync=None):
+    """The reference's complete Stage-2 step from pixels (shared_step + training_step_no_gan,
+    ref/models/Predictor.py:124-148,172-194): frozen encoder on past and future frames under no_grad, predictor,
+    frozen decoder on the predicted features (gradient flows through it), loss = L1(img) + lam*L1(feat) + KL."""
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        past_feats = enc(past_frames)
+        future_feats = enc(future_frames)
+    return predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm,
+                                frozen_dec=dec, future_frames=future_frames, sync=sync, grad_sync=grad_sync)

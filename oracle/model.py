@@ -16,7 +16,7 @@ __all__ = [
     "CoorGenerator", "NRMLP", "PosFeatFuser", "EventEncoder", "MultiheadAttention",
     "SpatialLocalMultiheadAttention", "MlpDWBN", "VidHRFormerBlockEnc",
     "VidHRFormerEncoder", "VidHRFormerBlockDecNAR", "VidHRformerDecoderNAR",
-    "Predictor", "L1Loss", "Div_KL", "predictor_train_step", "build_predictor_from_cfg",
+    "Predictor", "L1Loss", "Div_KL", "predictor_train_step", "full_train_step", "build_predictor_from_cfg",
 ]
 
 
@@ -500,3 +500,14 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
     opt.step()
     return {"loss": float(loss.detach()), "PF_L1": float(pf.detach()), "KL": float(kl.detach()), "grad_norm": float(gn),
             "Image_L1": None if img is None else float(img.detach())}
+
+
+def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0):
+    """Complete Stage-2 step from pixels (ref/models/Predictor.py:124-148,172-194): frozen encoder (no_grad, eval) on
+    past and future frames -> predictor -> frozen decoder (eval; gradient flows through it) -> L1(img) + lam*L1(feat) + KL.
+    `enc` / `dec` are the frozen autoencoder modules (stock torch; the caller passes them in)."""
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        past_feats, future_feats = enc(past_frames), enc(future_frames)
+    return predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm,
+                                frozen_dec=dec, future_frames=future_frames)

@@ -221,6 +221,8 @@ def key_hashed_fill(module, seed=0):
                 val = 0.1 * r
             elif key.endswith("nrmlp.B") or key == "B":
                 val = 10.0 * r
+            elif leaf == "gamma":          # NonLocalAttenion2D skip gain of the frozen autoencoder (reference init: 0)
+                val = 0.1 * r
             elif leaf == "bias" or leaf == "in_proj_bias":
                 val = 0.02 * r
             elif is_norm and leaf == "weight":

@@ -391,6 +391,74 @@ def main():
     save("predictor_full_D", y_strided=npy(y.flatten()[::7]), y_mean=npy(y.mean()), y_std=npy(y.std()),
          meta=np.array([N, To, Tp, 111, 112]))
 
+    # ------------------------------------------------------------------ frozen autoencoder (stock-torch restatement
+    # in npvp_amd/models/ResNetAutoEncoder.py) and the FULL Stage-2 step from pixels
+    import npvp_amd
+    for tag, (ci, ngf, nd, nres, S, out_layer) in {"64": (1, 64, 3, 2, 64, 'Sigmoid'), "128": (3, 32, 4, 3, 128, 'Tanh')}.items():
+        re_ = R.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
+        me = npvp_amd.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
+        rd = R.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
+        md = npvp_amd.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
+        assert list(re_.state_dict().keys()) == list(me.state_dict().keys()) and list(rd.state_dict().keys()) == list(md.state_dict().keys())
+        O.key_hashed_fill(re_, 121); O.key_hashed_fill(me, 121); O.key_hashed_fill(rd, 122); O.key_hashed_fill(md, 122)
+        for m_ in (re_, me, rd, md):
+            m_.eval()
+        x = torch.rand(1, 2, ci, S, S, generator=torch.Generator().manual_seed(123))
+        with torch.no_grad():
+            fr, fm = re_(x), me(x)
+        check(f"ae{tag}.enc", fm, fr)
+        f1, f2 = fr.clone().requires_grad_(), fr.clone().requires_grad_()
+        y1, y2 = rd(f1), md(f2)
+        cot = O.seeded_randn(y1.shape, 124)
+        (y1 * cot).sum().backward(); (y2 * cot).sum().backward()
+        check(f"ae{tag}.dec", y2, y1); check(f"ae{tag}.dec_gin", f2.grad, f1.grad)
+        save(f"ae_{tag}", feats=npy(fr), frames=npy(y1), g_feats=npy(f1.grad), meta=np.array([ci, ngf, nd, nres, S, 121, 122, 123, 124]))
+
+    N, To, Tp = 2, 3, 4
+    to, tp = torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, rand_context=False, dropout=0.0, drop_path=0.0)
+    ref = R.Predictor(8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, True, 2, norm=nn.LayerNorm(512), **kw)
+    mine = oracle.Predictor(8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, True, 2, **kw)
+    O.key_hashed_fill(ref, 131); O.key_hashed_fill(mine, 131)
+    renc = R.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    rdec = R.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    menc = npvp_amd.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    mdec = npvp_amd.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    for m_, sd in ((renc, 121), (menc, 121), (rdec, 122), (mdec, 122)):
+        O.key_hashed_fill(m_, sd); m_.eval()
+        for p_ in m_.parameters():
+            p_.requires_grad_(False)
+    g_ = torch.Generator().manual_seed(133)
+    pf, ff = torch.rand(N, To, 1, 64, 64, generator=g_), torch.rand(N, Tp, 1, 64, 64, generator=g_)
+    eps = O.seeded_randn((N, 512, 8, 8), 134)
+    mine.evt_prior.eps_fn = mine.evt_posterior.eps_fn = lambda shape: eps
+    ref.train(); mine.train()
+    opt_r, opt_m = torch.optim.AdamW(ref.parameters(), lr=1e-4), torch.optim.AdamW(mine.parameters(), lr=1e-4)
+    # reference side: shared_step + training_step_no_gan restated on the reference's own modules
+    ref.zero_grad()
+    with torch.no_grad():
+        past_feats, fut_feats = renc(pf), renc(ff)
+    torch.randn = lambda *a, **k: eps
+    try:
+        pred, mu_o, lv_o, mu_p, lv_p = ref(past_feats, fut_feats)
+    finally:
+        torch.randn = real_randn
+    kl = R.Div_KL(1e-6)(mu_o, lv_o, mu_p, lv_p)
+    frames = rdec(pred)
+    img = R.L1Loss()(frames, ff); pfl = R.L1Loss(lam=0.01)(pred, fut_feats)
+    loss = img + pfl + kl
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(ref.transformer.parameters(), max_norm=1.0, norm_type=2)
+    opt_r.step()
+    sm = oracle.full_train_step(mine, opt_m, menc, mdec, pf, ff, 0.01, 1e-6, 1.0)
+    check("full_step.loss", torch.tensor(sm["loss"]), loss); check("full_step.Image_L1", torch.tensor(sm["Image_L1"]), img)
+    check("full_step.grad_norm", torch.tensor(sm["grad_norm"]), gn)
+    rp, mp = ref.state_dict(), mine.state_dict()
+    check("full_step.w_dec_lin1", mp["transformer.layers.1.linear1.weight"], rp["transformer.layers.1.linear1.weight"])
+    save("train_step_full_S", loss=npy(loss), img=npy(img), pf=npy(pfl), kl=npy(kl), grad_norm=npy(gn),
+         w_dec_lin1=npy(rp["transformer.layers.1.linear1.weight"].flatten()[:256]),
+         w_evt_fc1=npy(rp["EVT_Former.layers.0.SpatialFFN.fc1.bias"].flatten()[:256]), meta=np.array([N, To, Tp, 131, 121, 122, 133, 134]))
+
     with open(os.path.join(HERE, "ORACLE_VS_REFERENCE.txt"), "w") as f:
         f.write("# oracle (CPU restatement) vs imported reference, rel-L2, torch %s, generated by make_golden.py\n" % torch.__version__)
         for n_, e in REPORT:

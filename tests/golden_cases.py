@@ -247,3 +247,44 @@ def case_predictor_full(impl, dev):
     with torch.no_grad():
         y = m(past)
     return dict(y_strided=y.flatten()[::7], y_mean=y.mean(), y_std=y.std())
+
+
+def case_ae(impl, dev, tag="64"):
+    """Frozen autoencoder (stock-torch restatement): encoder features, decoder frames, decoder input-gradient."""
+    ci, ngf, nd, nres, S, out_layer = {"64": (1, 64, 3, 2, 64, 'Sigmoid'), "128": (3, 32, 4, 3, 128, 'Tanh')}[tag]
+    enc = impl.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
+    dec = impl.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
+    O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122)
+    enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+    x = torch.rand(1, 2, ci, S, S, generator=torch.Generator().manual_seed(123)).to(dev)
+    with torch.no_grad():
+        feats = enc(x)
+    f = feats.clone().requires_grad_()
+    y = dec(f)
+    cot = O.seeded_randn(y.shape, 124).to(dev)
+    (y * cot).sum().backward()
+    return dict(feats=feats, frames=y, g_feats=f.grad)
+
+
+def case_full_step(pred_impl, ae_impl, dev, make_opt=None):
+    """One complete Stage-2 step from pixels: frozen enc -> predictor -> frozen dec -> L1(img) + 0.01 L1(feat) + KL."""
+    N, To, Tp = 2, 3, 4
+    m = _small_predictor(pred_impl, True, 131, dev)
+    enc = ae_impl.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    dec = ae_impl.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122)
+    enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+    for q in list(enc.parameters()) + list(dec.parameters()):
+        q.requires_grad_(False)
+    g_ = torch.Generator().manual_seed(133)
+    pf, ff = torch.rand(N, To, 1, 64, 64, generator=g_).to(dev), torch.rand(N, Tp, 1, 64, 64, generator=g_).to(dev)
+    eps = O.seeded_randn((N, 512, 8, 8), 134).to(dev)
+    m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: eps
+    m.train()
+    opt = make_opt(m) if make_opt is not None else torch.optim.AdamW(m.parameters(), lr=1e-4)
+    s = pred_impl.full_train_step(m, opt, enc, dec, pf, ff, 0.01, 1e-6, 1.0)
+    sd = m.state_dict()
+    return dict(loss=torch.tensor(s["loss"]), img=torch.tensor(s["Image_L1"]), pf=torch.tensor(s["PF_L1"]),
+                kl=torch.tensor(s["KL"]), grad_norm=torch.tensor(s["grad_norm"]),
+                w_dec_lin1=sd["transformer.layers.1.linear1.weight"].flatten()[:256].clone(),
+                w_evt_fc1=sd["EVT_Former.layers.0.SpatialFFN.fc1.bias"].flatten()[:256].clone())

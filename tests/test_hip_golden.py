@@ -80,6 +80,17 @@ def test_train_step(impl, variant):
     GC.compare({k: v for k, v in res.items() if k.endswith("_1")}, {k: v for k, v in g.items() if k.endswith("_1")}, max(3e-3, TOL))
 
 
+@pytest.mark.parametrize("tag", ["64", "128"])
+def test_frozen_autoencoder(impl, tag):
+    """stock PyTorch-ROCm (MIOpen) run of the frozen AE restatement vs the reference's vectors"""
+    GC.compare(GC.case_ae(impl, DEV, tag), GC.load(f"ae_{tag}"), 1e-4, tag=f"ae_{tag}[{MODE}]")
+
+
+def test_full_step_from_pixels(impl):
+    mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+    GC.compare(GC.case_full_step(impl, impl, DEV, make_opt=mk), GC.load("train_step_full_S"), TOL, tag=f"full_step[{MODE}]")
+
+
 def test_predictor_full_depth(impl):
     GC.compare(GC.case_predictor_full(impl, DEV), GC.load("predictor_full_D"), TOL, tag=f"predictor_full[{MODE}]")
 

@@ -75,3 +75,16 @@ def test_state_dict_keys_match_reference_census():
     assert m.EVT_Former.norm is m.transformer.norm
     n = sum(p.numel() for p in m.parameters())
     assert abs(n - 103.91e6) < 0.02e6
+
+
+@pytest.mark.parametrize("tag", ["64", "128"])
+def test_frozen_autoencoder_restatement(tag):
+    """The frozen AE is stock torch on any device: its restatement (npvp_amd/models/ResNetAutoEncoder.py) is pinned
+    to the reference's vectors on CPU here and on the GPU in test_hip_golden.py."""
+    import npvp_amd
+    GC.compare(GC.case_ae(npvp_amd, "cpu", tag), GC.load(f"ae_{tag}"), TOL)
+
+
+def test_full_step_from_pixels():
+    import npvp_amd
+    GC.compare(GC.case_full_step(oracle, npvp_amd, "cpu"), GC.load("train_step_full_S"), TOL)
