@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "bf16x6db"), choices=["f32", "bf16x3", "bf16x6", "bf16x6pc", "bf16x6db", "bf16x3db"],
                     help="GEMM arithmetic: exact fp32 MFMA, or 2-/3-term bf16 split-precision MFMA (see npvp_amd/ops.py)")
+    ap.add_argument("--flavour", default="predictor", choices=["predictor", "full"],
+                    help="predictor: feature grids resident in HBM (the BASELINE metric's step); full: SURVEY 8d's second "
+                         "flavour, pixels -> frozen encoder -> predictor -> frozen decoder -> image L1 (AE = stock PyTorch-ROCm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     args = ap.parse_args()
@@ -143,9 +146,20 @@ def main():
     past = torch.relu(torch.randn(B, To, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
     fut = torch.relu(torch.randn(B, Tp, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
     iters_per_epoch = 100
+    if args.flavour == "full":
+        D = cfg["Dataset"]
+        enc, dec = npvp_amd.build_frozen_autoencoder(cfg["AE"], D["img_channels"])
+        enc, dec = enc.to(dev), dec.to(dev)
+        S = D["img_size"]
+        past_px = torch.rand(B, To, D["img_channels"], S, S, generator=g).to(dev)
+        fut_px = torch.rand(B, Tp, D["img_channels"], S, S, generator=g).to(dev)
+        log(f"frozen autoencoder built (ngf={cfg['AE']['ngf']}, {S}x{S}x{D['img_channels']} pixels)")
 
     def step(i):
         opt.set_lr(cosine_warm_restarts_lr(P["predictor_lr"], P["scheduler_eta_min"], P["scheduler_T0"], i / iters_per_epoch))
+        if args.flavour == "full":
+            return npvp_amd.full_train_step(model, opt, enc, dec, past_px, fut_px, P["lam_PF_L1"], P["KL_beta"],
+                                            P["max_grad_norm"], sync=False, grad_sync=gsync)
         return npvp_amd.predictor_train_step(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"],
                                              sync=False, grad_sync=gsync)
 
@@ -198,12 +212,14 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.gemm == "f32" else f"f32 ({args.gemm} split-precision MFMA, fp32 accumulate)",
                "data": "synthetic",
-               "config": {"workload": f"{name} predictor-only train step (features in HBM), {B} clips/GPU, To={To}, "
+               "config": {"workload": f"{name} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
+                                                     else "FULL train step from pixels (frozen AE enc/dec in stock PyTorch-ROCm)")
+                                      + f", {B} clips/GPU, To={To}, "
                                       f"Tp={Tp}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * B, "frames_per_clip": To + Tp, "parallelism": f"dp{world}",
                           "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6)},
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")
             res["cpu_baseline"] = cpu_baseline(cfg_file, To, Tp)
         print(json.dumps(res), flush=True)
