@@ -40,7 +40,10 @@ const char* npvp_last_error(void);
  * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
  * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1 / 2: split precision - operands are split on
  * the fly into 2 / 3 bf16 terms and the 3 / 6 leading cross products are accumulated in fp32 on
- * v_mfma_f32_32x32x16_bf16 (relative product error ~2^-16 / ~2^-23).
+ * v_mfma_f32_32x32x16_bf16 (relative product error ~2^-16 / ~2^-23).  precision 3 / 4 / 5: the same arithmetic as
+ * 2 / 2 / 1 in other kernel organisations (producer-consumer waves; 16-deep double-buffered K-steps, 4 = default).
+ * precision 6 (EXPERIMENTAL, not used by the path): two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 per product,
+ * ~2^-22 - but only for operands inside fp16's exponent range (|x| < 65504, precision degrades below 2^-24).
  * colsum_a (a_kc = 0 only, nullable): receives colsum_a[m] = sum_k A[k][m] - the bias gradient falls out of the
  * weight-gradient GEMM's own operand staging (dW = dy^T x, db = column sums of dy), no extra pass over dy.
  * When the tile count is small and K large (weight gradients) the reduction is split over

@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 32, GEMM_THREADS = 256;
 
 struct GemmParams {
+  float a_scale = 1.f, b_scale = 1.f;   // f16x3 path: power-of-two operand scales (alpha already carries 1/(sa*sb))
   const float* A; const float* B; float* C;
   const float* bias;       // [N] or null
   const float* residual;   // [M][ldr] or null (added last)
@@ -706,6 +707,156 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// fp16 two-term split ("f16x3"): x*s = hi + lo/2^11 + eps,  hi = rne_f16(x*s), lo = rne_f16((x*s - hi) * 2^11), |eps| <=
+// 2^-22 |x*s| (fp16 carries 11 significand bits, so TWO terms reach fp32-grade where bf16 needs three).  The product is
+//     sum hiA*hiB                       -> accumulator set M        (1 MFMA)
+//     sum hiA*loB + loA*hiB             -> accumulator set X        (2 MFMAs),   C = (M + X * 2^-11) / (sA sB)
+// 3 v_mfma_f32_32x32x16_f16 per product instead of 6 bf16 ones; lo is stored pre-scaled by 2^11 so that it is a normal
+// fp16 number whenever hi is.  fp16 has a 5-bit exponent: operands are pre-multiplied by the caller's power-of-two
+// scales sA / sB (exact) to sit inside it; the representation is exact to 2^-22 relative for |x*s| in [2^-14, 65504] and
+// degrades gradually (absolute error 2^-36) below.  Same LDS image, staging and pipeline as gemm_split_db_kernel.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <bool KC> struct HalfStager16;
+
+template <> struct HalfStager16<true> {
+  float4 r[2];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    const int kof = ((t >> 4) & 1) * 8 + (t & 1) * 4, rl = (t >> 5) * 8 + ((t >> 1) & 7);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = min(row0 + rl + 64 * i, nrows - 1);
+      r[i] = ld4(src + (long long)row * ld + k0 + kof);
+    }
+  }
+  template <int I> __device__ __forceinline__ void store_part(char* base, int t, float sc) const {
+    const int off = ((t >> 4) & 1) * KG_STRIDE + (t & 1) * 8 + ((t >> 5) * 8 + ((t >> 1) & 7) + 64 * I) * 16;
+    const float4 v = r[I];
+    const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
+    f16x4 hi, lo;
+    hi[0] = (_Float16)x0; hi[1] = (_Float16)x1; hi[2] = (_Float16)x2; hi[3] = (_Float16)x3;
+    lo[0] = (_Float16)((x0 - (float)hi[0]) * 2048.f); lo[1] = (_Float16)((x1 - (float)hi[1]) * 2048.f);
+    lo[2] = (_Float16)((x2 - (float)hi[2]) * 2048.f); lo[3] = (_Float16)((x3 - (float)hi[3]) * 2048.f);
+    *reinterpret_cast<f16x4*>(base + off) = hi;
+    *reinterpret_cast<f16x4*>(base + OPER16 + off) = lo;
+  }
+  __device__ __forceinline__ float tile_sum() const { return 0.f; }
+};
+
+template <> struct HalfStager16<false> {
+  float r2[2][4];
+  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
+    const int row = min(row0 + (t & 127), nrows - 1), kg = t >> 7;
+    const float* q = src + (long long)(k0 + kg * 8) * ld + row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r2[j >> 2][j & 3] = q[(long long)j * ld];
+  }
+  template <int I> __device__ __forceinline__ void store_part(char* base, int t, float sc) const {
+    const int off = (t >> 7) * KG_STRIDE + (t & 127) * 16 + I * 8;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = r2[I][j] * sc;
+      hi[j] = (_Float16)x;
+      lo[j] = (_Float16)((x - (float)hi[j]) * 2048.f);
+    }
+    *reinterpret_cast<f16x4*>(base + off) = hi;
+    *reinterpret_cast<f16x4*>(base + OPER16 + off) = lo;
+  }
+  __device__ __forceinline__ float tile_sum() const {
+    return r2[0][0] + r2[0][1] + r2[0][2] + r2[0][3] + r2[1][0] + r2[1][1] + r2[1][2] + r2[1][3];
+  }
+};
+
+#define NPVP_HMFMA4(P, A0, A1, B0, B1)                                               \
+  P##00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, P##00, 0, 0, 0);            \
+  P##01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, P##01, 0, 0, 0);            \
+  P##10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, P##10, 0, 0, 0);            \
+  P##11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, P##11, 0, 0, 0);
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h3_kernel(GemmParams p) {
+  constexpr int STAGE = 4 * OPER16;                           // [A hi | A lo | B hi | B lo]
+  constexpr int BK16 = 16;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  int m0, n0;
+  tile_of_block(p, m0, n0);
+  const int z = blockIdx.y;
+  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
+  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};       // hi*hi
+  f32x16 acx00 = {0}, acx01 = {0}, acx10 = {0}, acx11 = {0};       // hi*lo + lo*hi, scaled by 2^11
+  const int nk = p.K / BK16;
+  const bool want_cs = !AKC && p.colsum && n0 == 0;
+  float cs = 0.f;
+  const float sca = p.a_scale, scb = p.b_scale;
+  const int fa_off = h * KG_STRIDE + (wm * 64 + r) * 16;
+  const int fb_off = 2 * OPER16 + h * KG_STRIDE + (wn * 64 + r) * 16;
+
+  HalfStager16<AKC> a0s, a1s;
+  HalfStager16<BKC> b0s, b1s;
+  a0s.load(A, p.lda, m0, p.M, 0, t); b0s.load(B, p.ldb, n0, p.N, 0, t);
+  if constexpr (!AKC) { if (want_cs) cs += a0s.tile_sum(); }
+  a0s.template store_part<0>(lds, t, sca); a0s.template store_part<1>(lds, t, sca);
+  b0s.template store_part<0>(lds + 2 * OPER16, t, scb); b0s.template store_part<1>(lds + 2 * OPER16, t, scb);
+  { const int k1 = min(BK16, p.K - BK16); a0s.load(A, p.lda, m0, p.M, k1, t); b0s.load(B, p.ldb, n0, p.N, k1, t); }
+  __syncthreads();
+
+#define NPVP_H3_STEP(KT, SA_CUR, SB_CUR, SA_NXT, SB_NXT)                                                        \
+  {                                                                                                             \
+    const char* st = lds + ((KT) & 1) * STAGE;                                                                  \
+    char* nx = lds + (((KT) + 1) & 1) * STAGE;                                                                  \
+    const int k2 = min(((KT) + 2) * BK16, p.K - BK16);                                                          \
+    SA_NXT.load(A, p.lda, m0, p.M, k2, t);                                                                      \
+    SB_NXT.load(B, p.ldb, n0, p.N, k2, t);                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    f16x8 fa0[2], fa1[2], fb0[2], fb1[2];                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                             \
+      fa0[s] = *reinterpret_cast<const f16x8*>(st + fa_off + s * OPER16);                                       \
+      fa1[s] = *reinterpret_cast<const f16x8*>(st + fa_off + s * OPER16 + 32 * 16);                             \
+      fb0[s] = *reinterpret_cast<const f16x8*>(st + fb_off + s * OPER16);                                       \
+      fb1[s] = *reinterpret_cast<const f16x8*>(st + fb_off + s * OPER16 + 32 * 16);                             \
+    }                                                                                                           \
+    if constexpr (!AKC) { if (want_cs && (KT) + 1 < nk) cs += SA_CUR.tile_sum(); }                              \
+    SA_CUR.template store_part<0>(nx, t, sca);                                                                  \
+    NPVP_HMFMA4(acx, fa0[0], fa1[0], fb0[1], fb1[1])                                                            \
+    SA_CUR.template store_part<1>(nx, t, sca);                                                                  \
+    SB_CUR.template store_part<0>(nx + 2 * OPER16, t, scb);                                                     \
+    NPVP_HMFMA4(acc, fa0[0], fa1[0], fb0[0], fb1[0])                                                            \
+    SB_CUR.template store_part<1>(nx + 2 * OPER16, t, scb);                                                     \
+    NPVP_HMFMA4(acx, fa0[1], fa1[1], fb0[0], fb1[0])                                                            \
+    __syncthreads();                                                                                            \
+  }
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    NPVP_H3_STEP(kt, a0s, b0s, a1s, b1s)
+    NPVP_H3_STEP(kt + 1, a1s, b1s, a0s, b0s)
+  }
+  if (kt < nk) NPVP_H3_STEP(kt, a0s, b0s, a1s, b1s)
+#undef NPVP_H3_STEP
+
+  if constexpr (!AKC) {
+    if (want_cs) {
+      float* red = reinterpret_cast<float*>(lds);
+      red[t] = cs;
+      __syncthreads();
+      if (t < 128 && m0 + t < p.M) p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+    }
+  }
+  constexpr float LO = 1.f / 2048.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    acc00[g] = fmaf(acx00[g], LO, acc00[g]); acc01[g] = fmaf(acx01[g], LO, acc01[g]);
+    acc10[g] = fmaf(acx10[g], LO, acc10[g]); acc11[g] = fmaf(acx11[g], LO, acc11[g]);
+  }
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+}
+
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
                                      long long ldc, int splits, float alpha) {
@@ -766,9 +917,9 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
   precision &= 0xff;
-  NPVP_CHECK_ARG(precision >= 0 && precision <= 5,
+  NPVP_CHECK_ARG(precision >= 0 && precision <= 6,
                  "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x6), 3 (bf16x6 producer/consumer), "
-                 "4 (bf16x6 double-buffered pipeline) or 5 (bf16x3 double-buffered pipeline)");
+                 "4 (bf16x6 double-buffered pipeline), 5 (bf16x3 double-buffered pipeline) or 6 (f16x3, experimental)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
@@ -828,6 +979,10 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);
+  } else if (precision == 6) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_h3_kernel<true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_h3_kernel<true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_h3_kernel<false, false>), grid, block, 0, stream, p);
   } else if (precision == 5) {
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true, false>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false, false>), grid, block, 0, stream, p);

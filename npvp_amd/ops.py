@@ -93,7 +93,11 @@ NO_DROP = Drop(0.0)
 #   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade; every wave stages and multiplies
 #   bf16x6pc same arithmetic, producer/consumer waves (4 MFMA waves + 4 staging waves per workgroup)
 #   bf16x6db / bf16x3db: same arithmetic, 16-deep K-steps, two LDS stages, staging interleaved with the MFMAs
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3, "bf16x6db": 4, "bf16x3db": 5}
+#   f16x3  EXPERIMENT: 2-term fp16 split, 3 MFMAs per product, ~2^-22 - fp32-grade ONLY inside fp16's exponent range
+#          (overflows above 65504, degrades below 2^-24: gradients of 1e-9 need a scaling pass it does not have).
+#          Measured 170 TF vs 151 TF for bf16x6db over the c1 shapes (tools/h3_check.py, tools/gemm_bench.py): halving
+#          the MFMA count buys 13 %, i.e. the K-step is bound by LDS traffic + staging, not by the matrix pipe.
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3, "bf16x6db": 4, "bf16x3db": 5, "f16x3": 6}
 GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6db")]
 
 

@@ -110,6 +110,27 @@ def test_gemm_full_size_against_rocblas(K):
     close(K.linear_fwd(2.5 * x1 + x2, w, None), 2.5 * K.linear_fwd(x1, w, None) + K.linear_fwd(x2, w, None), tol=5e-5)
 
 
+def test_gemm_f16x3_experimental():
+    """The experimental two-term fp16 split (precision 6): fp32-grade on operands inside fp16's exponent range,
+    ragged tile edges included.  Not used by the path (no scaling pass for 1e-9 gradients) - see npvp_amd/ops.py."""
+    from npvp_amd import ops
+    old = ops.GEMM_PRECISION
+    ops.set_gemm_precision("f16x3")
+    try:
+        for M, N, K_ in ((200, 132, 64), (4096, 512, 2048)):
+            x = O.seeded_randn((M, K_), 41).to(DEV); w = (O.seeded_randn((N, K_), 42) / math.sqrt(K_)).to(DEV)
+            b = O.seeded_randn((N,), 43).to(DEV)
+            close(ops.linear_fwd(x, w, b), (x.double() @ w.double().T + b.double()).float(), tol=1e-5, what="f16x3 fwd")
+        R, N, K_ = 4096, 512, 256
+        dy = O.seeded_randn((R, N), 44).to(DEV); x = O.seeded_randn((R, K_), 45).to(DEV); w = (O.seeded_randn((N, K_), 46) / 16).to(DEV)
+        close(ops.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=1e-5, what="f16x3 dgrad")
+        dw, db = ops.linear_wgrad(dy, x, True)
+        close(dw, (dy.double().T @ x.double()).float(), tol=1e-5, what="f16x3 wgrad")
+        close(db, dy.sum(0), tol=1e-5, what="f16x3 fused bias grad")
+    finally:
+        ops.GEMM_PRECISION = old
+
+
 def test_linear_autograd(K):
     x = O.seeded_randn((3, 64, 512), 11).requires_grad_(); w = (O.seeded_randn((256, 512), 12) / 22.0).requires_grad_()
     b = O.seeded_randn((256,), 13).requires_grad_(); r = O.seeded_randn((3, 64, 256), 14).requires_grad_()
