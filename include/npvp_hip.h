@@ -46,6 +46,9 @@ const char* npvp_last_error(void);
  * ~2^-22 - but only for operands inside fp16's exponent range (|x| < 65504, precision degrades below 2^-24).
  * colsum_a (a_kc = 0 only, nullable): receives colsum_a[m] = sum_k A[k][m] - the bias gradient falls out of the
  * weight-gradient GEMM's own operand staging (dW = dy^T x, db = column sums of dy), no extra pass over dy.
+ * accumulate = 1: C += result and colsum_a += sums - a weight / bias gradient is accumulated straight into the live
+ * .grad slice of the flat gradient buffer (no temporary, no separate add kernel); the same flag exists on the other
+ * entry points that produce parameter gradients (npvp_layernorm_bwd, npvp_frameln_act_bwd, npvp_colsum).
  * When the tile count is small and K large (weight gradients) the reduction is split over
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);
@@ -53,7 +56,7 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
-                  const void* b_pre, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                  const void* b_pre, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
 /* Weights change once per optimiser step but are staged by every tile of three GEMMs: split them ONCE into the bf16
  * term planes the split-precision kernel consumes (3 terms x N*K bf16 each, blocked like the LDS image).
  * F feeds y = x w^T (pass as b_pre with b_kc = 1), D feeds dx = dy w (b_pre with b_kc = 0).  b_pre is optional
@@ -68,8 +71,8 @@ int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y,
 long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C);
 int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                        const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
-                       const float* dres /* nullable: dx += dres, the residual branch's gradient */, void* workspace,
-                       long long ws_bytes, npvp_stream_t stream);
+                       const float* dres /* nullable: dx += dres, the residual branch's gradient */,
+                       int accumulate /* dw, db += */, void* workspace, long long ws_bytes, npvp_stream_t stream);
 
 /* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
  * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL
@@ -94,7 +97,8 @@ long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame);
 int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                          const float* b, float* dh, float* dw, float* db, int frames, int per_frame, float drop_p,
                          unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
-                         const unsigned long long* seed, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                         const unsigned long long* seed, int accumulate /* dw, db += */, void* workspace,
+                         long long ws_bytes, npvp_stream_t stream);
 /* depthwise 3x3, zero pad 1 (ref/models/VidHRFormer.py:351-358); wt is tap-major [9][Ch]; flip=1 gives the
  * input gradient.  wgrad writes one contiguous [10][Ch] buffer: 9 taps then the bias gradient. */
 int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W, int Ch,
@@ -129,8 +133,8 @@ int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, 
 
 /* out[n] = sum_r x[r][n]: bias gradients of every Linear / Conv2d on the path */
 long long npvp_colsum_workspace_bytes(long long rows, int N);
-int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, void* workspace, long long ws_bytes,
-                npvp_stream_t stream);
+int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, int accumulate /* out += */,
+                void* workspace, long long ws_bytes, npvp_stream_t stream);
 
 /* ---- optimiser step of training_step_no_gan (ref/models/Predictor.py:135-136,197): clip_grad_norm_
  * over a flat gradient range, then torch.optim.AdamW semantics on flat buffers.  hyper = {lr, step}

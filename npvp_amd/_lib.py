@@ -15,18 +15,18 @@ SIGNATURES = {
     "npvp_last_error": (ctypes.c_char_p, []),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
-                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_p, c_ll, c_p]),
+                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_split_weight": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p]),
     "npvp_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_f, c_int, c_p]),
     "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),
-    "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_p, c_ll, c_p]),
+    "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_frame_stats": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
     "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
     "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p]),
     "npvp_frameln_act_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_frameln_act_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
-                                     c_p, c_p, c_ll, c_p]),
+                                     c_p, c_int, c_p, c_ll, c_p]),
     "npvp_dwconv3x3": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_im2col3x3": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_wgrad_workspace_bytes": (c_ll, [c_int, c_int]),
@@ -40,7 +40,7 @@ SIGNATURES = {
     "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_broadcast_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_colsum_workspace_bytes": (c_ll, [c_ll, c_int]),
-    "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_p, c_ll, c_p]),
+    "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_grad_norm_clip": (c_int, [c_p, c_ll, c_f, c_p, c_p, c_ll, c_p]),
     "npvp_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_ll, c_p, c_f, c_f, c_f, c_f, c_p, c_ll, c_ll, c_int, c_p]),
 }

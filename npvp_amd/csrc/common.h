@@ -120,6 +120,9 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // out[c] = sum_b in[b*stride + c], c < ncols (defined in norm.hip)
-int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream);
+// out[c] (+)= sum_b in[b*stride + c]; columns >= split go to out_b[c - split] (two parameter gradients from one
+// partial buffer in one launch); accum = add to what the outputs already hold (gradient accumulation in place).
+int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream, int accum = 0,
+                    float* out_b = nullptr, int split = 0);
 
 }  // namespace npvp

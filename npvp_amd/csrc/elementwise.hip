@@ -193,7 +193,7 @@ static int colsum_chunks(long long rows) { return (int)(rows < 128 ? rows : 128)
 extern "C" long long npvp_colsum_workspace_bytes(long long rows, int N) { return (long long)colsum_chunks(rows) * N * 4; }
 
 // out[n] = sum_r x[r][n]
-extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, void* workspace,
+extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, int accumulate, void* workspace,
                            long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_colsum_workspace_bytes(rows, N), "colsum: workspace too small");
@@ -202,7 +202,7 @@ extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 4 + 255) / 256, nchunks), dim3(256), 0, stream, x, (float*)workspace,
                      rows, N, ld, rpc);
   NPVP_CHECK_LAUNCH();
-  const int rc = launch_sum_rows((const float*)workspace, out, nchunks, N, N, stream);
+  const int rc = launch_sum_rows((const float*)workspace, out, nchunks, N, N, stream, accumulate);
   if (rc) { npvp_set_error("colsum: reduce launch failed"); return rc; }
   return NPVP_OK;
 }

@@ -48,6 +48,7 @@ struct GemmParams {
   const void* b_pre;       // pre-split B planes (bf16, blocked [term][K/8][N][8]) or null: see split_weight kernels
   long long b_pre_plane;   // bf16 elements per term plane (= N*K)
   int colgroups;           // XCD tiling: 1 = every XCD sweeps all tile columns; G>1 = XCD x owns column group x%G (see tile_of_block)
+  int accum;               // 1: C += result and colsum += sums (gradient accumulation into a live .grad slice)
   int dbg;                 // profiling ablations (results INVALID): 1 = no global loads, 2 = no split VALU, 4 = no MFMA
 };
 
@@ -108,6 +109,10 @@ template <> struct Stager<false> {  // source [K][rows], rows contiguous
   }
 };
 
+__device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
+  p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
+}
+
 // ---- epilogue shared by both MFMA paths: C/D map of the 32x32 MFMA is col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
@@ -138,6 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
         else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
         if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
         if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+        if (p.accum) v += Cz[idx];
         Cz[idx] = v;
       }
     }
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += red[i * 128 + threadIdx.x];
-        p.colsum[(long long)z * p.M + m0 + threadIdx.x] = t;
+        store_colsum(p, (long long)z * p.M + m0 + threadIdx.x, t);
       }
     }
   }
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
       red[threadIdx.x] = cs;
       __syncthreads();
       if (threadIdx.x < 128 && m0 + (int)threadIdx.x < p.M)
-        p.colsum[(long long)z * p.M + m0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+        store_colsum(p, (long long)z * p.M + m0 + threadIdx.x, red[threadIdx.x] + red[threadIdx.x + 128]);
     }
   }
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(GemmParams p) {
     if constexpr (!AKC) {
       if (want_cs && t < 128 && m0 + t < p.M) {
         const float* red = reinterpret_cast<const float*>(lds);
-        p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+        store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
       }
     }
     return;
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       float* red = reinterpret_cast<float*>(lds);
       red[t] = cs;
       __syncthreads();
-      if (t < 128 && m0 + t < p.M) p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+      if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
   gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h3_kernel(GemmParams p) 
       float* red = reinterpret_cast<float*>(lds);
       red[t] = cs;
       __syncthreads();
-      if (t < 128 && m0 + t < p.M) p.colsum[(long long)z * p.M + m0 + t] = red[t] + red[t + 128];
+      if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
   constexpr float LO = 1.f / 2048.f;
@@ -859,7 +865,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h3_kernel(GemmParams p) 
 
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
-                                     long long ldc, int splits, float alpha) {
+                                     long long ldc, int splits, float alpha, int accum) {
   const long long total4 = (long long)M * N / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
@@ -870,6 +876,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+    if (accum) { const float4 o = ld4(out + (long long)m * ldc + n); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
     st4(out + (long long)m * ldc + n, s);
   }
 }
@@ -912,8 +919,8 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
-                             int precision, float* colsum_a, const void* b_pre, void* workspace, long long ws_bytes,
-                             hipStream_t stream) {
+                             int precision, float* colsum_a, const void* b_pre, int accumulate, void* workspace,
+                             long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
   precision &= 0xff;
@@ -942,6 +949,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (splits > 1 && (!plain || ws_bytes < npvp_gemm_workspace_bytes(M, N, K) || !workspace || (N % 4) != 0)) splits = 1;
   p.splits = splits;
   p.colsum = colsum_a;
+  p.accum = accumulate ? 1 : 0;
   p.dbg = dbg;
   // pre-split B planes are only consumed by the db bf16x6 kernel with a row-major A and an unsplit reduction
   p.b_pre = (precision == 4 && a_kc && splits == 1 && K % 16 == 0 && N % 8 == 0) ? b_pre : nullptr;
@@ -998,9 +1006,9 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     const long long total4 = (long long)M * N / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
-                       splits, alpha);
+                       splits, alpha, p.accum);
     NPVP_CHECK_LAUNCH();
-    if (colsum_a && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream)) {
+    if (colsum_a && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream, p.accum)) {
       npvp_set_error("gemm: column-sum reduce launch failed");
       return NPVP_ERR_LAUNCH;
     }

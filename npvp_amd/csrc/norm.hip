@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // out[c] = sum_b in[b*stride + c]   (second stage of the column reductions).  A block owns 64 columns and
 // splits the nb partial rows over blockDim/64 row lanes (coalesced 256-B segments, LDS tree at the end).
 __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int nb,
-                                                        int stride, int ncols) {
+                                                        int stride, int ncols, int accum, float* __restrict__ out_b,
+                                                        int split) {
   __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6, nrl = blockDim.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict_
   if (rl == 0 && c < ncols) {
     float t = 0.f;
     for (int i = 0; i < nrl; ++i) t += red[i][cx];
-    out[c] = t;
+    float* o = (out_b && c >= split) ? out_b + (c - split) : out + c;
+    *o = accum ? *o + t : t;
   }
 }
 
@@ -367,10 +369,12 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
   st4(o + p.per_frame + e, ab);
 }
 
-int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream) {
+int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream, int accum, float* out_b,
+                    int split) {
   // few partial rows (frame-LN params: 32 x 131072) -> 4 row lanes; many (bias / LN column sums) -> 16
   const int threads = nb >= 64 ? 1024 : 256;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 63) / 64), dim3(threads), 0, stream, in, out, nb, stride, ncols);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 63) / 64), dim3(threads), 0, stream, in, out, nb, stride, ncols,
+                     accum, out_b, split);
   return hipGetLastError() == hipSuccess ? NPVP_OK : NPVP_ERR_LAUNCH;
 }
 
@@ -424,7 +428,8 @@ extern "C" long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C) {
 
 extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                                   const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
-                                  const float* dres, void* workspace, long long ws_bytes, hipStream_t stream) {
+                                  const float* dres, int accumulate, void* workspace, long long ws_bytes,
+                                  hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0, "layernorm_bwd: no rows");
   NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm_bwd: C must be 256, 512, 768 or 1024");
   const int nb = ln_bwd_blocks(rows);
@@ -439,7 +444,7 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]
-  if (launch_sum_rows((const float*)part, dw, nb, 2 * C, C, stream) || launch_sum_rows((const float*)part + C, db, nb, 2 * C, C, stream)) {
+  if (launch_sum_rows((const float*)part, dw, nb, 2 * C, 2 * C, stream, accumulate, db, C)) {
     npvp_set_error("layernorm_bwd: reduce launch failed");
     return NPVP_ERR_LAUNCH;
   }
@@ -509,8 +514,8 @@ extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_fr
 extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                                     const float* b, float* dh, float* dw, float* db, int frames, int per_frame,
                                     float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt,
-                                    int frames_per_sample, const unsigned long long* seed, void* workspace,
-                                    long long ws_bytes, hipStream_t stream) {
+                                    int frames_per_sample, const unsigned long long* seed, int accumulate,
+                                    void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0, "frameln_act_bwd: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
                  "frameln_act_bwd: workspace too small");
@@ -524,8 +529,7 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
                      dout, (const float*)s1, (const float*)s2, dh, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
-  if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, per_frame, stream) ||
-      launch_sum_rows((const float*)part + per_frame, db, nchunks, 2 * per_frame, per_frame, stream)) {
+  if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
     npvp_set_error("frameln_act_bwd: reduce launch failed");
     return NPVP_ERR_LAUNCH;
   }

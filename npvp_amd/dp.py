@@ -11,6 +11,10 @@ What the reference does implicitly through Lightning's DDP strategy + sync_batch
       point-to-point: ring collectives are per-link bound, so buckets are tens of MB, not DDP's 25 MB
       default tuned for NVSwitch).  `finish()` makes the compute stream wait for the side stream before
       the decoder-only clip_grad_norm_ (ref/models/Predictor.py:135), which needs reduced gradients.
+      "Filled" = every gradient CONTRIBUTION of every parameter of the bucket has been written: the HIP backward
+      kernels accumulate most parameter gradients straight into the flat buffer (ops.GradSink) and report each
+      write, the rest arrive through autograd's post-accumulate-grad hooks.  The per-parameter contribution
+      counts of a step are learned in the first step (which reduces everything in finish()) and checked after.
   C2  SyncBatchNorm2d for the EventEncoder's three BatchNorm layers: ONE all-reduce of [sum, sum_sq, count]
       per layer forward and one of [sum_dy, sum_dy_xhat] backward.
   C3  parameter/buffer broadcast from rank 0 at construction.
@@ -76,13 +80,24 @@ class GradSync:
                 self.buckets.append({"lo": start, "hi": end, "n": members, "ready": 0, "work": None})
                 start, members = end, 0
         self._handles = []
+        self.count = {id(p): 0 for p in buf.params}     # contributions seen this step
+        self.expected = None                            # learned in the first step
         if self.world > 1:
             for p in buf.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+            from . import ops
+            ops.GradSink.listener = self._hook
         self.launched = 0
 
     def _hook(self, p):
-        b = self.buckets[self.param_bucket[id(p)]]
+        """one gradient contribution of parameter p is in the flat buffer (autograd hook or ops.GradSink)"""
+        k = id(p)
+        if k not in self.count:
+            return
+        self.count[k] += 1
+        if self.expected is None or self.count[k] != self.expected[k]:
+            return
+        b = self.buckets[self.param_bucket[k]]
         b["ready"] += 1
         if b["ready"] == b["n"]:
             self._launch(b)
@@ -106,6 +121,18 @@ class GradSync:
         order the compute stream after every reduction."""
         if self.world == 1:
             return
+        if self.expected is None:
+            self.expected = dict(self.count)
+            for b in self.buckets:                      # a bucket is complete when its CONTRIBUTING parameters are
+                b["n"] = 0
+            for p in self.buf.params:
+                if self.expected[id(p)] > 0:
+                    self.buckets[self.param_bucket[id(p)]]["n"] += 1
+        elif self.count != self.expected:
+            raise RuntimeError("GradSync: the per-parameter gradient contribution counts changed between steps "
+                               "(a bucket may have been reduced before its last contribution)")
+        for k in self.count:
+            self.count[k] = 0
         for b in self.buckets:
             if b["work"] is None:
                 self._launch(b)
@@ -122,6 +149,9 @@ class GradSync:
     def remove(self):
         for h in self._handles:
             h.remove()
+        from . import ops
+        if ops.GradSink.listener == self._hook:
+            ops.GradSink.listener = None
 
 
 class _SyncBNFn(torch.autograd.Function):

@@ -43,6 +43,7 @@ class FlatBuffers:
                 self.flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                p.__dict__["_npvp_flat"] = True          # ops.GradSink may accumulate into p.grad in place
                 self.offsets.append((off, n))
                 off += pad(n)
         self.total = total

@@ -83,12 +83,49 @@ def test_train_step(impl, variant):
 @pytest.mark.parametrize("tag", ["64", "128"])
 def test_frozen_autoencoder(impl, tag):
     """stock PyTorch-ROCm (MIOpen) run of the frozen AE restatement vs the reference's vectors"""
-    GC.compare(GC.case_ae(impl, DEV, tag), GC.load(f"ae_{tag}"), 1e-4, tag=f"ae_{tag}[{MODE}]")
+    res, gold = GC.case_ae(impl, DEV, tag), GC.load(f"ae_{tag}")
+    # forward: MIOpen convolutions vs the CPU reference.  The decoder's input gradient passes through its ReLU masks:
+    # a handful of units within rounding noise of 0 flip with MIOpen's algorithm choice (run-to-run), each flip a finite
+    # gradient change - observed 1e-5 .. 1.2e-3 rel-L2 on the 128x128 decoder, so that key gets its own bound.
+    g_res, g_gold = res.pop("g_feats"), gold.pop("g_feats")
+    GC.compare(res, gold, 1e-4, tag=f"ae_{tag}[{MODE}]")
+    GC.compare({"g_feats": g_res}, {"g_feats": g_gold}, 5e-3, tag=f"ae_{tag}.g_feats[{MODE}]")
 
 
 def test_full_step_from_pixels(impl):
     mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
     GC.compare(GC.case_full_step(impl, impl, DEV, make_opt=mk), GC.load("train_step_full_S"), TOL, tag=f"full_step[{MODE}]")
+
+
+def test_grad_sink_matches_autograd_accumulation(impl):
+    """ops.GradSink (backward kernels accumulate parameter gradients straight into the flat gradient buffer) against
+    the plain autograd route (temporaries + AccumulateGrad adds): same flat gradient, tied LayerNorm and the twice-used
+    NPVP-S encoder included."""
+    from npvp_amd import ops
+    N, To, Tp = 2, 3, 4
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+    eps = O.seeded_randn((N, 512, 8, 8), 94).to(DEV)
+    flat, old = {}, ops.GradSink.enabled
+    try:
+        for on in (True, False):
+            ops.GradSink.enabled = on
+            m = GC._small_predictor(impl, True, 101, DEV)
+            m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: eps
+            m.train()
+            opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+            opt.zero_grad()
+            pred, mu_o, lv_o, mu_p, lv_p = m(past, fut)
+            loss = impl.L1Loss(lam=0.01)(pred, fut) + impl.Div_KL(1e-6)(mu_o, lv_o, mu_p, lv_p)
+            loss.backward()
+            flat[on] = opt.flat_g.clone()
+            for p_ in m.parameters():       # every .grad is still the flat slice
+                assert p_.grad is not None and p_.grad.data_ptr() >= opt.flat_g.data_ptr()
+    finally:
+        ops.GradSink.enabled = old
+    assert float(flat[True].abs().sum()) > 0
+    err = float((flat[True] - flat[False]).norm() / flat[False].norm())
+    assert err < 2e-6, f"grad sink vs autograd accumulation: rel-L2 {err:.3e}"
 
 
 def test_predictor_full_depth(impl):
