@@ -24,14 +24,21 @@ class Predictor(nn.Module):
             norm = nn.LayerNorm(512)
         if not evt_former or learn_evt_token:
             raise NotImplementedError("evt_former=False / learn_evt_token=True are outside the hot path")
-        if rand_context:
-            raise NotImplementedError("rand_context (unified model) is a 'next' row (SURVEY 8f #2)")
         self.stochastic, self.evt_former = stochastic, evt_former
         self.h_list, self.w_list = h_list, w_list
         self.max_H, self.max_W = max_H, max_W
         self.coor_generator = CoorGenerator(max_H, max_W, max_T)
-        self.register_buffer("observed_coor", self.coor_generator(to_list, h_list, w_list))
-        self.register_buffer("predict_coor", self.coor_generator(tp_list, h_list, w_list))
+        if not rand_context:
+            self.register_buffer("observed_coor", self.coor_generator(to_list, h_list, w_list))
+            self.register_buffer("predict_coor", self.coor_generator(tp_list, h_list, w_list))
+        else:
+            # unified model (ref :281-284): the caller picks the context / target time-steps per batch and points
+            # observed_coor / predict_coor / TP at rows of `all_coor` (trainer.rand_context_batch_process); the kernels
+            # take the sequence lengths at run time (any To, Tp <= 32)
+            self.observed_coor = None
+            self.predict_coor = None
+            self.register_buffer("all_coor", self.coor_generator(torch.cat([to_list, tp_list]), h_list, w_list)
+                                 .reshape(max_T, max_H, max_W, 3))
         self.nrmlp = NRMLP(out_channels=embed_dim, fuse_method=fuse_method)
         self.fuser = PosFeatFuser(x_channels=embed_dim, param_free_norm_type=param_free_norm_type)
         self.EVT_Former = VidHRFormerEncoder(evt_former_num_layers, max_H, max_W, embed_dim, num_heads, window_size, dropout,
@@ -99,7 +106,7 @@ class Predictor(nn.Module):
         return ops.canonical_to_nchw(mem, N, T, H, W), self._nchw(evt)
 
     def reset_pos_coor(self, to_list, tp_list):
-        device = self.observed_coor.device
+        device = self.observed_coor.device if self.observed_coor is not None else self.all_coor.device
         self.predict_coor = self.coor_generator(tp_list, self.h_list, self.w_list).to(device)
         self.observed_coor = self.coor_generator(to_list, self.h_list, self.w_list).to(device)
         self.TP = tp_list.shape[0]

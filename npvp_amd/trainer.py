@@ -108,6 +108,41 @@ class FlatAdamW:
         """Total L2 norm of the clipped range measured by the last step() (device scalar)."""
         return self.clip[0]
 
+    # -- torch.optim.AdamW-format state, parameter order = `module.parameters()` (what LitPredictor's optimizer_P and a
+    # -- Lightning checkpoint's optimizer_states[0] use, ref/models/Predictor.py:197)
+    def state_dict(self, module):
+        order = [p for p in module.parameters() if p.requires_grad]
+        where = {id(p): self.offsets[i] for i, p in enumerate(self.params)}
+        step = torch.tensor(float(self.hyper[1]))
+        state = {}
+        for i, p in enumerate(order):
+            off, n = where[id(p)]
+            state[i] = {"step": step.clone(), "exp_avg": self.m[off:off + n].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.v[off:off + n].view(p.shape).detach().cpu().clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd, module):
+        order = [p for p in module.parameters() if p.requires_grad]
+        where = {id(p): self.offsets[i] for i, p in enumerate(self.params)}
+        g = sd["param_groups"][0]
+        assert len(g["params"]) == len(order), "optimizer state does not match the module's parameter list"
+        step = 0.0
+        with torch.no_grad():
+            for i, p in enumerate(order):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is None:
+                    continue
+                off, n = where[id(p)]
+                self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = float(st["step"])
+            self.hyper[1:2].fill_(step)
+        self.set_lr(g["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
+
 
 def cosine_warm_restarts_lr(base_lr, eta_min, T_0, epoch_float):
     """torch CosineAnnealingWarmRestarts(T_0, T_mult=1, eta_min).step(epoch + batch_idx/len) as the reference
@@ -121,8 +156,7 @@ def build_predictor_from_cfg(cls, P, num_past, num_future, **overrides):
     `Predictor:` section of a reference YAML config."""
     h = torch.linspace(0, P['max_H'] - 1, P['max_H'])
     w = torch.linspace(0, P['max_W'] - 1, P['max_W'])
-    to = torch.linspace(0, num_past - 1, num_past)
-    tp = torch.linspace(num_past, num_past + num_future - 1, num_future)
+    to, tp = context_lists(P, num_past, num_future)
     assert P['max_T'] == num_past + num_future, "Incompatible max_T and clip length"
     return cls(P['max_H'], P['max_W'], P['max_T'], h, w, to, tp, P['embed_dim'], P['fuse_method'],
                P['param_free_norm_type'], P['evt_hidden_channels'], 1, P['stochastic'], P['transformer_layers'],
@@ -192,3 +226,79 @@ def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF
         future_feats = enc(future_frames)
     return predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm,
                                 frozen_dec=dec, future_frames=future_frames, sync=sync, grad_sync=grad_sync)
+
+
+# ---- batch shaping of the reference's other Stage-2 modes (ref/models/Predictor.py:30-40,62-70,241-262 and the
+# ---- random-context collate ref/utils/dataset.py:162-178): SURVEY 8f "next" row #2
+def context_lists(P, num_past, num_future):
+    """(to_list, tp_list) as LitPredictor.__init__ derives them: VFI puts the context on both sides of the gap."""
+    if P.get("VFI", False):
+        cp, cf, nv = P["context_num_p"], P["context_num_f"], P["num_interpolate"]
+        n = cp + cf + nv
+        assert num_past + num_future == n, "Imcompatible VFI configurations"
+        idx = torch.linspace(0, n - 1, n, dtype=torch.int64)
+        return torch.cat([idx[0:cp], idx[-cf:]]), idx[cp:-cf]
+    return (torch.linspace(0, num_past - 1, num_past),
+            torch.linspace(num_past, num_past + num_future - 1, num_future))
+
+
+def rand_context_collate(clip_batch, min_lo, max_lo, generator=None):
+    """Split a batch of full clips (N,T,...) into a random context / target partition of the time axis: a random
+    permutation of the T steps, the first `lo` (uniform in [min_lo, max_lo]) are observed, the rest predicted."""
+    T = clip_batch.shape[1]
+    perm = torch.randperm(T, generator=generator)
+    lo = int(torch.randint(min_lo, max_lo + 1, (1,), generator=generator))
+    idx_o, idx_p = perm[:lo], perm[lo:]
+    return clip_batch[:, idx_o], clip_batch[:, idx_p], idx_o, idx_p
+
+
+def rand_context_batch_process(predictor, batch):
+    """Point the predictor's coordinate tables at this batch's context / target time-steps (ref :241-251)."""
+    clip_o, clip_p, idx_o, idx_p = batch
+    coor = predictor.all_coor
+    predictor.observed_coor = coor[idx_o.to(coor.device)].flatten(0, 2)
+    predictor.predict_coor = coor[idx_p.to(coor.device)].flatten(0, 2)
+    predictor.TP = idx_p.shape[0]
+    return clip_o, clip_p
+
+
+def vfi_batch_process(batch, to_list, tp_list):
+    """(past, future) -> (context frames on both sides, frames to interpolate)  (ref :253-259)"""
+    clip = torch.cat(batch, dim=1)
+    return clip[:, to_list], clip[:, tp_list]
+
+
+# ---- checkpoint wire format of the reference (SURVEY 8f "next" row #3): a Lightning .ckpt of LitPredictor is a
+# ---- torch.save'd dict {"state_dict": {...}, "optimizer_states": [...], "lr_schedulers": [...], "epoch", "global_step"}
+# ---- whose state_dict keys carry the attribute prefixes predictor. / VPTR_Enc. / VPTR_Dec. (ref Predictor.py:17-19,43)
+_CKPT_PREFIX = {"predictor": "predictor.", "enc": "VPTR_Enc.", "dec": "VPTR_Dec."}
+
+
+def save_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, epoch=0, global_step=0, scheduler_T0=None):
+    sd = {}
+    for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
+        if m is not None:
+            sd.update({_CKPT_PREFIX[role] + k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    ck = {"state_dict": sd, "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "1.6.5"}
+    if opt is not None:
+        ck["optimizer_states"] = [opt.state_dict(predictor)]
+        ck["lr_schedulers"] = [{"T_0": scheduler_T0, "T_i": scheduler_T0, "T_mult": 1, "T_cur": float(epoch % scheduler_T0),
+                                "last_epoch": float(epoch)}] if scheduler_T0 else []
+    torch.save(ck, path)
+
+
+def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, strict=True):
+    """Load a reference Stage-2 checkpoint (or one written by save_lightning_checkpoint).  Returns (epoch, global_step)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
+        if m is None:
+            continue
+        pre = _CKPT_PREFIX[role]
+        part = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        if not part and not strict:
+            continue
+        m.load_state_dict(part, strict=strict)
+    if opt is not None and ck.get("optimizer_states"):
+        opt.load_state_dict(ck["optimizer_states"][0], predictor)
+    return ck.get("epoch", 0), ck.get("global_step", 0)

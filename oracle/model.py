@@ -17,6 +17,7 @@ __all__ = [
     "SpatialLocalMultiheadAttention", "MlpDWBN", "VidHRFormerBlockEnc",
     "VidHRFormerEncoder", "VidHRFormerBlockDecNAR", "VidHRformerDecoderNAR",
     "Predictor", "L1Loss", "Div_KL", "predictor_train_step", "full_train_step", "build_predictor_from_cfg",
+    "rand_context_batch_process",
 ]
 
 
@@ -379,12 +380,17 @@ class Predictor(nn.Module):
         super().__init__()
         if norm is None:     # the reference default is ONE shared nn.LayerNorm(512) instance
             norm = nn.LayerNorm(512)
-        assert evt_former and not learn_evt_token and not rand_context, "VFP path only"
+        assert evt_former and not learn_evt_token, "the learned event token branch is out of scope"
         self.stochastic, self.evt_former = stochastic, evt_former
         self.h_list, self.w_list = h_list, w_list
         self.coor_generator = CoorGenerator(max_H, max_W, max_T)
-        self.register_buffer("observed_coor", self.coor_generator(to_list, h_list, w_list))
-        self.register_buffer("predict_coor", self.coor_generator(tp_list, h_list, w_list))
+        if not rand_context:
+            self.register_buffer("observed_coor", self.coor_generator(to_list, h_list, w_list))
+            self.register_buffer("predict_coor", self.coor_generator(tp_list, h_list, w_list))
+        else:       # ref :281-284: coordinates are chosen per batch from all_coor
+            self.observed_coor = self.predict_coor = None
+            self.register_buffer("all_coor", self.coor_generator(torch.cat([to_list, tp_list]), h_list, w_list)
+                                 .reshape(max_T, max_H, max_W, 3))
         self.nrmlp = NRMLP(out_channels=embed_dim, fuse_method=fuse_method)
         self.fuser = PosFeatFuser(x_channels=embed_dim, param_free_norm_type=param_free_norm_type)
         self.EVT_Former = VidHRFormerEncoder(evt_former_num_layers, max_H, max_W, embed_dim, num_heads, window_size,
@@ -429,7 +435,7 @@ class Predictor(nn.Module):
         return x, x.mean(dim=1)
 
     def reset_pos_coor(self, to_list, tp_list):
-        dev = self.observed_coor.device
+        dev = self.observed_coor.device if self.observed_coor is not None else self.all_coor.device
         self.predict_coor = self.coor_generator(tp_list, self.h_list, self.w_list).to(dev)
         self.observed_coor = self.coor_generator(to_list, self.h_list, self.w_list).to(dev)
         self.TP = tp_list.shape[0]
@@ -511,3 +517,13 @@ def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF
         past_feats, future_feats = enc(past_frames), enc(future_frames)
     return predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm,
                                 frozen_dec=dec, future_frames=future_frames)
+
+
+def rand_context_batch_process(predictor, batch):
+    """ref/models/Predictor.py:241-251: point observed_coor / predict_coor / TP at this batch's time-steps."""
+    clip_o, clip_p, idx_o, idx_p = batch
+    coor = predictor.all_coor
+    predictor.observed_coor = coor[idx_o].flatten(0, 2)
+    predictor.predict_coor = coor[idx_p].flatten(0, 2)
+    predictor.TP = idx_p.shape[0]
+    return clip_o, clip_p

@@ -459,6 +459,38 @@ def main():
          w_dec_lin1=npy(rp["transformer.layers.1.linear1.weight"].flatten()[:256]),
          w_evt_fc1=npy(rp["EVT_Former.layers.0.SpatialFFN.fc1.bias"].flatten()[:256]), meta=np.array([N, To, Tp, 131, 121, 122, 133, 134]))
 
+    # ------------------------------------------------------------------ unified model: random context
+    N, T = 2, 7
+    tl = torch.linspace(0, T - 1, T)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, rand_context=True, dropout=0.0, drop_path=0.0)
+    ref = R.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, True, 2, norm=nn.LayerNorm(512), **kw)
+    mine = oracle.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, True, 2, **kw)
+    O.key_hashed_fill(ref, 141); O.key_hashed_fill(mine, 141)
+    clip = O.synth_features((N, T, 512, 8, 8), 142)
+    idx_o, idx_p = torch.tensor([4, 0, 6, 2]), torch.tensor([5, 1, 3])          # unsorted on purpose
+    batch = (clip[:, idx_o], clip[:, idx_p], idx_o, idx_p)
+    # reference side of rand_context_batch_process (Predictor.py:241-251) on the reference module
+    ref.observed_coor = ref.all_coor[idx_o, ...].flatten(0, 2)
+    ref.predict_coor = ref.all_coor[idx_p, ...].flatten(0, 2)
+    ref.TP = idx_p.shape[0]
+    xo_m, xp_m = oracle.rand_context_batch_process(mine, batch)
+    eps = O.seeded_randn((N, 512, 8, 8), 143)
+    cot = O.seeded_randn((N, 3, 512, 8, 8), 144)
+    mine.evt_prior.eps_fn = mine.evt_posterior.eps_fn = lambda shape: eps
+    ref.train(); mine.train()
+    xr = batch[0].clone().requires_grad_(); xm = xo_m.clone().requires_grad_()
+    torch.randn = lambda *a, **k: eps
+    try:
+        yr = ref(xr, batch[1])
+    finally:
+        torch.randn = real_randn
+    ym = mine(xm, xp_m)
+    (yr[0] * yr[0] * cot).sum().backward(); (ym[0] * ym[0] * cot).sum().backward()
+    check("randctx.out", ym[0], yr[0]); check("randctx.mu_p", ym[3], yr[3]); check("randctx.g_obs", xm.grad, xr.grad)
+    check("randctx.gB", mine.nrmlp.B.grad, ref.nrmlp.B.grad)
+    save("predictor_randctx_S", out=npy(yr[0]), mu_o=npy(yr[1]), mu_p=npy(yr[3]), g_obs=npy(xr.grad), gB=npy(ref.nrmlp.B.grad),
+         g_tied=npy(ref.transformer.norm.weight.grad), meta=np.array([N, T, 141, 142, 143, 144]))
+
     with open(os.path.join(HERE, "ORACLE_VS_REFERENCE.txt"), "w") as f:
         f.write("# oracle (CPU restatement) vs imported reference, rel-L2, torch %s, generated by make_golden.py\n" % torch.__version__)
         for n_, e in REPORT:

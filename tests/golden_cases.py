@@ -288,3 +288,25 @@ def case_full_step(pred_impl, ae_impl, dev, make_opt=None):
                 kl=torch.tensor(s["KL"]), grad_norm=torch.tensor(s["grad_norm"]),
                 w_dec_lin1=sd["transformer.layers.1.linear1.weight"].flatten()[:256].clone(),
                 w_evt_fc1=sd["EVT_Former.layers.0.SpatialFFN.fc1.bias"].flatten()[:256].clone())
+
+
+def case_randctx(impl, dev):
+    """Unified model: Predictor(rand_context=True) with an unsorted random context / target split of T=7 steps."""
+    N, T = 2, 7
+    h = torch.linspace(0, 7, 8)
+    tl = torch.linspace(0, T - 1, T)
+    m = impl.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, True, 2, evt_former=True,
+                       learn_evt_token=False, evt_former_num_layers=2, rand_context=True, dropout=0.0, drop_path=0.0)
+    O.key_hashed_fill(m, 141)
+    m = m.to(dev)
+    clip = O.synth_features((N, T, 512, 8, 8), 142).to(dev)
+    idx_o, idx_p = torch.tensor([4, 0, 6, 2]), torch.tensor([5, 1, 3])
+    xo, xp = impl.rand_context_batch_process(m, (clip[:, idx_o.to(dev)], clip[:, idx_p.to(dev)], idx_o.to(dev), idx_p.to(dev)))
+    eps = O.seeded_randn((N, 512, 8, 8), 143).to(dev)
+    cot = O.seeded_randn((N, 3, 512, 8, 8), 144).to(dev)
+    m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: eps
+    m.train()
+    x = xo.clone().requires_grad_()
+    y = m(x, xp)
+    (y[0] * y[0] * cot).sum().backward()
+    return dict(out=y[0], mu_o=y[1], mu_p=y[3], g_obs=x.grad, gB=m.nrmlp.B.grad, g_tied=m.transformer.norm.weight.grad)

@@ -76,3 +76,64 @@ def test_lr_schedule_matches_torch():
     for e in (0.0, 0.37, 12.5, 149.99, 150.0, 151.25, 449.5):
         sch.step(e)
         assert abs(opt.param_groups[0]["lr"] - npvp_amd.cosine_warm_restarts_lr(1e-4, 1e-7, 150, e)) < 1e-12
+
+
+def test_context_modes_host_logic():
+    """VFI / random-context batch shaping (ref/models/Predictor.py:30-40,241-259, ref/utils/dataset.py:162-178)."""
+    import npvp_amd
+    P = {"VFI": True, "context_num_p": 2, "context_num_f": 2, "num_interpolate": 3}
+    to, tp = npvp_amd.context_lists(P, 4, 3)
+    assert to.tolist() == [0, 1, 5, 6] and tp.tolist() == [2, 3, 4]
+    to2, tp2 = npvp_amd.context_lists({"VFI": False}, 3, 2)
+    assert to2.tolist() == [0.0, 1.0, 2.0] and tp2.tolist() == [3.0, 4.0]
+    past, fut = torch.arange(4).view(1, 4, 1).float(), torch.arange(4, 7).view(1, 3, 1).float()
+    ctx, tgt = npvp_amd.vfi_batch_process((past, fut), to, tp)
+    assert ctx.flatten().tolist() == [0, 1, 5, 6] and tgt.flatten().tolist() == [2, 3, 4]
+    clip = torch.arange(10).view(1, 10, 1).float().repeat(3, 1, 1)
+    g = torch.Generator().manual_seed(5)
+    co, cp, io, ip = npvp_amd.rand_context_collate(clip, 4, 6, generator=g)
+    assert 4 <= io.numel() <= 6 and io.numel() + ip.numel() == 10
+    assert sorted(io.tolist() + ip.tolist()) == list(range(10))
+    assert co[0].flatten().tolist() == [float(i) for i in io.tolist()] and cp.shape == (3, ip.numel(), 1)
+    # the unified predictor keeps every (t,h,w) coordinate and lets the harness choose rows per batch
+    h = torch.linspace(0, 7, 8)
+    tl = torch.linspace(0, 6, 7)
+    m = npvp_amd.Predictor(8, 8, 7, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, False, 1, evt_former_num_layers=1,
+                           rand_context=True)
+    assert m.observed_coor is None and m.all_coor.shape == (7, 8, 8, 3)
+    npvp_amd.rand_context_batch_process(m, (None, None, torch.tensor([6, 1]), torch.tensor([0, 3, 2])))
+    assert m.observed_coor.shape == (2 * 64, 3) and m.predict_coor.shape == (3 * 64, 3) and m.TP == 3
+    assert torch.equal(m.observed_coor[:64], m.all_coor[6].flatten(0, 1))
+
+
+def test_lightning_checkpoint_wire_format(tmp_path):
+    """A checkpoint in the reference's layout (state_dict keys prefixed predictor. / VPTR_Enc. / VPTR_Dec.,
+    ref/models/Predictor.py:17-19,43) written by torch.save loads into the HIP-backed modules and round-trips."""
+    import npvp_amd
+    import oracle
+    from oracle import ops as O
+    h = torch.linspace(0, 7, 8)
+    mk = lambda cls: cls(8, 8, 5, h, h, torch.linspace(0, 1, 2), torch.linspace(2, 4, 3), 512, 'Add', 'layer', 256, 1, True, 1,
+                         evt_former_num_layers=1)
+    src = mk(oracle.Predictor)                       # stands in for a reference-trained predictor (same 603-key layout rules)
+    O.key_hashed_fill(src, 7)
+    enc, dec = npvp_amd.build_frozen_autoencoder({"ngf": 8, "n_downsampling": 3, "num_res_blocks": 1, "out_layer": "Tanh",
+                                                  "learn_3d": False}, 1)
+    sd = {"predictor." + k: v for k, v in src.state_dict().items()}
+    sd.update({"VPTR_Enc." + k: v for k, v in enc.state_dict().items()})
+    sd.update({"VPTR_Dec." + k: v for k, v in dec.state_dict().items()})
+    path = str(tmp_path / "ref_style.ckpt")
+    torch.save({"state_dict": sd, "epoch": 12, "global_step": 3400}, path)
+    dst = mk(npvp_amd.Predictor)
+    enc2, dec2 = npvp_amd.build_frozen_autoencoder({"ngf": 8, "n_downsampling": 3, "num_res_blocks": 1, "out_layer": "Tanh",
+                                                    "learn_3d": False}, 1)
+    assert npvp_amd.load_lightning_checkpoint(path, dst, enc2, dec2) == (12, 3400)
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    assert dst.EVT_Former.norm.weight is dst.transformer.norm.weight          # still tied after loading
+    path2 = str(tmp_path / "ours.ckpt")
+    npvp_amd.save_lightning_checkpoint(path2, dst, enc2, dec2, epoch=13, global_step=3500)
+    ck = torch.load(path2, weights_only=False)
+    assert set(ck["state_dict"]) == set(sd) and ck["epoch"] == 13
+    back = mk(oracle.Predictor)
+    back.load_state_dict({k[len("predictor."):]: v for k, v in ck["state_dict"].items() if k.startswith("predictor.")})

@@ -128,6 +128,37 @@ def test_grad_sink_matches_autograd_accumulation(impl):
     assert err < 2e-6, f"grad sink vs autograd accumulation: rel-L2 {err:.3e}"
 
 
+def test_unified_random_context(impl):
+    GC.compare(GC.case_randctx(impl, DEV), GC.load("predictor_randctx_S"), TOL, tag=f"randctx[{MODE}]")
+
+
+def test_optimizer_state_is_torch_adamw_format(impl, tmp_path):
+    """FlatAdamW.state_dict() is what torch.optim.AdamW / a Lightning checkpoint's optimizer_states[0] hold
+    (parameter order = predictor.parameters()): it loads into a stock AdamW and round-trips through a .ckpt."""
+    m = GC._small_predictor(impl, False, 171, DEV, evt_layers=1, dec_layers=1)
+    m.train()
+    opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+    past = O.synth_features((1, 3, 512, 8, 8), 172).to(DEV); fut = O.synth_features((1, 4, 512, 8, 8), 173).to(DEV)
+    for _ in range(2):
+        impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0)
+    sd = opt.state_dict(m)
+    stock = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    stock.load_state_dict(sd)
+    p0 = next(m.parameters())
+    assert float(stock.state[p0]["step"]) == 2.0 and stock.state[p0]["exp_avg"].shape == p0.shape
+    assert float(stock.state[p0]["exp_avg"].abs().sum()) > 0
+    path = str(tmp_path / "step2.ckpt")
+    impl.save_lightning_checkpoint(path, m, opt=opt, epoch=1, global_step=2, scheduler_T0=150)
+    m2 = GC._small_predictor(impl, False, 999, DEV, evt_layers=1, dec_layers=1)
+    opt2 = impl.FlatAdamW(m2, lr=3e-4, clip_module=m2.transformer, max_grad_norm=1.0)
+    assert impl.load_lightning_checkpoint(path, m2, opt=opt2) == (1, 2)
+    assert torch.equal(opt2.flat_p, opt.flat_p) and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    assert float(opt2.hyper[1]) == 2.0 and opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    a = impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0)
+    b = impl.predictor_train_step(m2, opt2, past, fut, 0.01, 1e-6, 1.0)
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and torch.equal(opt2.flat_p, opt.flat_p)
+
+
 def test_predictor_full_depth(impl):
     GC.compare(GC.case_predictor_full(impl, DEV), GC.load("predictor_full_D"), TOL, tag=f"predictor_full[{MODE}]")
 

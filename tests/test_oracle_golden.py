@@ -85,6 +85,10 @@ def test_frozen_autoencoder_restatement(tag):
     GC.compare(GC.case_ae(npvp_amd, "cpu", tag), GC.load(f"ae_{tag}"), TOL)
 
 
+def test_unified_random_context():
+    GC.compare(GC.case_randctx(oracle, "cpu"), GC.load("predictor_randctx_S"), TOL)
+
+
 def test_full_step_from_pixels():
     import npvp_amd
     GC.compare(GC.case_full_step(oracle, npvp_amd, "cpu"), GC.load("train_step_full_S"), TOL)
