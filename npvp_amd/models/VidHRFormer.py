@@ -88,6 +88,50 @@ class SpatialLocalMultiheadAttention(nn.Module):
         return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
 
 
+class FrameLayerNorm(nn.Module):
+    """Parameter holder for MlpDWBN's nn.LayerNorm((Ch,H,W)) (ref/models/VidHRFormer.py:347,359,366).  The activations
+    on this path are channels-last [frame][H*W][Ch], so the per-element affine is STORED channels-last ([H*W*Ch] flat):
+    the kernels read it coalesced, its gradient is accumulated in place in the flat gradient buffer, and the 352
+    transpose launches per step of the first version (parameter re-layout forward, gradient re-layout backward) are
+    gone.  AdamW / weight decay / the gradient norm are element-wise, i.e. layout independent.  The state-dict still
+    shows the reference's (Ch,H,W) tensors - as strided VIEWS of the same storage, so checkpoints load / save
+    unchanged and in-place fills through state_dict() reach the parameter."""
+
+    def __init__(self, normalized_shape, eps=1e-5):
+        super().__init__()
+        self.normalized_shape = tuple(normalized_shape)
+        self.eps = eps
+        n = self.normalized_shape[0] * self.normalized_shape[1] * self.normalized_shape[2]
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+
+    def ref_view(self, flat):
+        """channels-last flat [H*W*Ch] -> the reference's (Ch,H,W) as a view"""
+        Ch, H, W = self.normalized_shape
+        return flat.view(H, W, Ch).permute(2, 0, 1)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for name in ("weight", "bias"):
+            p = getattr(self, name)
+            destination[prefix + name] = self.ref_view(p if keep_vars else p.detach())
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        for name in ("weight", "bias"):
+            k = prefix + name
+            if k in state_dict and tuple(state_dict[k].shape) == self.normalized_shape:
+                state_dict[k] = state_dict[k].permute(1, 2, 0).reshape(-1)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def forward(self, h, residual=None, frames=None, p_drop=0.0, p_dp=0.0, frames_per_sample=1):
+        """GELU(LayerNorm(h)) (+dropout, +residual, +drop-path) on channels-last h [frames, H*W*Ch] - the form the
+        reference uses it in (always followed by the activation, ref :381-390)."""
+        frames = h.shape[0] if frames is None else frames
+        return ops.frameln_act(h, self.weight, self.bias, residual, frames, p_drop, p_dp, frames_per_sample)
+
+    def extra_repr(self):
+        return "{}, eps={}, storage=channels-last".format(self.normalized_shape, self.eps)
+
+
 class MlpDWBN(nn.Module):
     """ref/models/VidHRFormer.py:326-392 (AR_model=True: LayerNorm((C,H,W)) variant).
     fc1/fc2 are GEMMs over the channels-last rows; each LayerNorm((Ch,H,W))+GELU(+dropout) is one
@@ -103,21 +147,15 @@ class MlpDWBN(nn.Module):
         self.encH, self.encW = encH, encW
         self.fc1 = nn.Conv2d(in_features, hidden_features, kernel_size=1)
         self.act1 = act_layer()
-        self.norm1 = nn.LayerNorm((hidden_features, encH, encW))
+        self.norm1 = FrameLayerNorm((hidden_features, encH, encW))
         self.dw3x3 = nn.Conv2d(hidden_features, hidden_features, kernel_size=3, stride=1, groups=hidden_features, padding=1)
         self.act2 = dw_act_layer()
-        self.norm2 = nn.LayerNorm((hidden_features, encH, encW))
+        self.norm2 = FrameLayerNorm((hidden_features, encH, encW))
         self.fc2 = nn.Conv2d(hidden_features, out_features, kernel_size=1)
         self.act3 = act_layer()
-        self.norm3 = nn.LayerNorm((out_features, encH, encW))
+        self.norm3 = FrameLayerNorm((out_features, encH, encW))
         self.drop = nn.Dropout(drop)
         self.out_features = out_features
-
-    @staticmethod
-    def _cl(p):
-        """(Ch,H,W) parameter -> channels-last [H*W*Ch] (differentiable: a transpose kernel both ways)."""
-        Ch = p.shape[0]
-        return ops._Transpose.apply(p.reshape(1, Ch, -1)).reshape(-1)
 
     def fused(self, x, residual, p_dp):
         N, T, H, W, C = x.shape
@@ -125,13 +163,13 @@ class MlpDWBN(nn.Module):
         pd = self.drop.p if self.training else 0.0
         hid = self.fc1.out_channels
         h = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias)
-        a = ops.frameln_act(h, self._cl(self.norm1.weight), self._cl(self.norm1.bias), None, F_)
+        a = ops.frameln_act(h, self.norm1.weight, self.norm1.bias, None, F_)
         wtb = torch.cat([ops._Transpose.apply(self.dw3x3.weight.reshape(1, hid, 9)).reshape(9, hid),
                          self.dw3x3.bias.reshape(1, hid)], dim=0)
         h = ops.dwconv3x3(a, wtb, F_, H, W)
-        a = ops.frameln_act(h, self._cl(self.norm2.weight), self._cl(self.norm2.bias), None, F_, pd)
+        a = ops.frameln_act(h, self.norm2.weight, self.norm2.bias, None, F_, pd)
         h = ops.linear(a.reshape(R, hid), self.fc2.weight.flatten(1), self.fc2.bias)
-        out = ops.frameln_act(h, self._cl(self.norm3.weight), self._cl(self.norm3.bias),
+        out = ops.frameln_act(h, self.norm3.weight, self.norm3.bias,
                               None if residual is None else residual.reshape(R, self.out_features), F_, pd, p_dp, T)
         return out.view(N, T, H, W, self.out_features)
 

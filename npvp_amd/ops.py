@@ -666,6 +666,7 @@ class _FrameLnAct(torch.autograd.Function):
               "npvp_frameln_act_fwd")
         ctx.save_for_backward(h, mean, rstd, w_cl, b_cl)
         ctx.cfg = (frames, PF, d, dp, frames_per_sample, res is not None)
+        ctx.sink = _ln_sink(w_cl, b_cl)
         return out
 
     @staticmethod
@@ -675,12 +676,16 @@ class _FrameLnAct(torch.autograd.Function):
         dout = _c(dout)
         L = lib()
         dh = torch.empty_like(h)
-        dw, db = torch.empty_like(w_cl), torch.empty_like(b_cl)
+        sk = ctx.sink
+        dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w_cl), torch.empty_like(b_cl))
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), h.device)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
         check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(dh), _ptr(dw),
-                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), 0, _ptr(ws), wsn,
-                                     _stream()), "npvp_frameln_act_bwd")
+                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), int(bool(sk)), _ptr(ws),
+                                     wsn, _stream()), "npvp_frameln_act_bwd")
+        if sk:
+            GradSink.wrote(*sk)
+            dw = db = None
         return dh, dw, db, (dout if has_res else None), None, None, None, None
 
 

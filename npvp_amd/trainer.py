@@ -110,15 +110,28 @@ class FlatAdamW:
 
     # -- torch.optim.AdamW-format state, parameter order = `module.parameters()` (what LitPredictor's optimizer_P and a
     # -- Lightning checkpoint's optimizer_states[0] use, ref/models/Predictor.py:197)
+    @staticmethod
+    def _ref_layouts(module):
+        """id(param) -> function(flat state slice) -> tensor in the reference's layout, for parameters this build
+        stores differently from the reference (FrameLayerNorm keeps its (Ch,H,W) affine channels-last)."""
+        from .models.VidHRFormer import FrameLayerNorm
+        out = {}
+        for mod in module.modules():
+            if isinstance(mod, FrameLayerNorm):
+                out[id(mod.weight)] = out[id(mod.bias)] = mod
+        return out
+
     def state_dict(self, module):
         order = [p for p in module.parameters() if p.requires_grad]
         where = {id(p): self.offsets[i] for i, p in enumerate(self.params)}
+        layouts = self._ref_layouts(module)
         step = torch.tensor(float(self.hyper[1]))
         state = {}
         for i, p in enumerate(order):
             off, n = where[id(p)]
-            state[i] = {"step": step.clone(), "exp_avg": self.m[off:off + n].view(p.shape).detach().cpu().clone(),
-                        "exp_avg_sq": self.v[off:off + n].view(p.shape).detach().cpu().clone()}
+            shape = (lambda t: layouts[id(p)].ref_view(t)) if id(p) in layouts else (lambda t: t.view(p.shape))
+            state[i] = {"step": step.clone(), "exp_avg": shape(self.m[off:off + n]).detach().cpu().contiguous().clone(),
+                        "exp_avg_sq": shape(self.v[off:off + n]).detach().cpu().contiguous().clone()}
         group = {"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "params": list(range(len(order)))}
@@ -129,6 +142,8 @@ class FlatAdamW:
         where = {id(p): self.offsets[i] for i, p in enumerate(self.params)}
         g = sd["param_groups"][0]
         assert len(g["params"]) == len(order), "optimizer state does not match the module's parameter list"
+        layouts = self._ref_layouts(module)
+        t_is_ref = lambda t, mod: tuple(t.shape) == mod.normalized_shape
         step = 0.0
         with torch.no_grad():
             for i, p in enumerate(order):
@@ -136,8 +151,10 @@ class FlatAdamW:
                 if st is None:
                     continue
                 off, n = where[id(p)]
-                self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
-                self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                to_flat = (lambda t: t.permute(1, 2, 0).reshape(-1)) if (id(p) in layouts and t_is_ref(st["exp_avg"], layouts[id(p)])) \
+                    else (lambda t: t.reshape(-1))
+                self.m[off:off + n].copy_(to_flat(st["exp_avg"]))
+                self.v[off:off + n].copy_(to_flat(st["exp_avg_sq"]))
                 step = float(st["step"])
             self.hyper[1:2].fill_(step)
         self.set_lr(g["lr"])

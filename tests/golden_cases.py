@@ -100,6 +100,12 @@ def case_slmhsa(impl, dev):
     return dict(y=y, gx=gx, gv=gv, gW_rows=gw[::64])
 
 
+def _fg(norm_module, g):
+    """gradient of a frame-LayerNorm parameter in the reference's (Ch,H,W) layout (the HIP modules store that
+    parameter channels-last and expose `ref_view`)"""
+    return norm_module.ref_view(g) if hasattr(norm_module, "ref_view") else g
+
+
 def case_mlpdwbn(impl, dev):
     N, T = 1, 2
     m = impl.MlpDWBN(8, 8, 512, 2048, 512, drop=0.0)
@@ -110,8 +116,8 @@ def case_mlpdwbn(impl, dev):
     y = m(x)
     ps = [m.norm1.weight, m.dw3x3.weight, m.norm3.bias, m.fc2.weight, m.fc1.bias, m.dw3x3.bias, m.norm2.weight]
     g = _g(y, cot, [x] + ps)
-    return dict(y=y, gx=g[0], g_norm1_w=g[1][::16], g_dw_w=g[2], g_norm3_b=g[3][::8],
-                g_fc2_w_rows=g[4].flatten(1)[::32], g_fc1_b=g[5], g_dw_b=g[6], g_norm2_w=g[7][::16])
+    return dict(y=y, gx=g[0], g_norm1_w=_fg(m.norm1, g[1])[::16], g_dw_w=g[2], g_norm3_b=_fg(m.norm3, g[3])[::8],
+                g_fc2_w_rows=g[4].flatten(1)[::32], g_fc1_b=g[5], g_dw_b=g[6], g_norm2_w=_fg(m.norm2, g[7])[::16])
 
 
 def case_block_enc(impl, dev):
@@ -207,7 +213,8 @@ def case_predictor(impl, dev, variant="D"):
     sd = dict(m.named_parameters())
     res.update(y_train=yt, g_past=p.grad, g_tied_norm_w=m.transformer.norm.weight.grad,
                g_tied_norm_b=m.transformer.norm.bias.grad, g_nrmlp_B=m.nrmlp.B.grad,
-               g_sffn1_norm2_w=sd["transformer.layers.1.SpatialFFN1.norm2.weight"].grad[::16],
+               g_sffn1_norm2_w=_fg(m.transformer.layers[1].SpatialFFN1.norm2,
+                                   sd["transformer.layers.1.SpatialFFN1.norm2.weight"].grad)[::16],
                g_evt_tmhsa_W_rows=sd["EVT_Former.layers.0.temporal_MHSA.in_proj_weight"].grad[::64],
                g_encdec_out_W_rows=sd["transformer.layers.0.EncDecAttn.out_proj.weight"].grad[::32],
                g_post_conv2_w=sd["evt_posterior.conv2.0.weight"].grad[::8, ::8])
