@@ -36,6 +36,100 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ a, const float* __res
   }
 }
 
+
+// ---- 8x8 feature grid (every shipped config): register-window forms.  The generic kernel above issues 9 activation +
+// 9 weight loads per output float4 - it is bound by the L1/TA request rate (2.3 TB/s effective), not by HBM.  Here a
+// thread owns one (frame, 4 channels) column and slides a 3-row window through registers: each input element is
+// loaded ONCE, the 9 taps stay in registers, lanes = consecutive channel quads (1 KB contiguous per pixel and wave).
+template <int HH, int WW>
+__global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restrict__ a, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int Ch, long long nthreads, int flip) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nthreads) return;
+  const int c4n = Ch / 4;
+  const int c = (int)(i % c4n) * 4;
+  const long long f = i / c4n;
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = ld4(wt + (flip ? 8 - t : t) * Ch + c);
+  const float4 bv = bias ? ld4(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* af = a + f * (HH * WW) * Ch + c;
+  float* of = out + f * (HH * WW) * Ch + c;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 r0[WW], r1[WW], r2[WW];
+#pragma unroll
+  for (int w = 0; w < WW; ++w) { r0[w] = z; r1[w] = ld4(af + (long long)w * Ch); }
+#pragma unroll
+  for (int h = 0; h < HH; ++h) {
+#pragma unroll
+    for (int w = 0; w < WW; ++w) r2[w] = (h + 1 < HH) ? ld4(af + (long long)((h + 1) * WW + w) * Ch) : z;
+#pragma unroll
+    for (int w = 0; w < WW; ++w) {
+      float4 acc = bv;
+#pragma unroll
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int ww = w + kx;
+        if (ww < 0 || ww >= WW) continue;
+        const float4 w0 = wv[kx + 1], w1 = wv[3 + kx + 1], w2 = wv[6 + kx + 1];
+        const float4 x0 = r0[ww], x1 = r1[ww], x2 = r2[ww];
+        acc.x += w0.x * x0.x + w1.x * x1.x + w2.x * x2.x; acc.y += w0.y * x0.y + w1.y * x1.y + w2.y * x2.y;
+        acc.z += w0.z * x0.z + w1.z * x1.z + w2.z * x2.z; acc.w += w0.w * x0.w + w1.w * x1.w + w2.w * x2.w;
+      }
+      st4(of + (long long)(h * WW + w) * Ch, acc);
+    }
+#pragma unroll
+    for (int w = 0; w < WW; ++w) { r0[w] = r1[w]; r1[w] = r2[w]; }
+  }
+}
+
+// weight / bias gradient, same window: thread = (4 channels, frame chunk); per frame one load of a and of dout.
+template <int HH, int WW>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_win_kernel(const float* __restrict__ a, const float* __restrict__ dout,
+                                                                  float* __restrict__ part, int Ch, int frames,
+                                                                  int frames_per_chunk) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= Ch) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 aw[9], ab = z;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) aw[t] = z;
+  const int f0 = blockIdx.y * frames_per_chunk, f1 = min(frames, f0 + frames_per_chunk);
+  for (long long f = f0; f < f1; ++f) {
+    const float* af = a + f * (HH * WW) * Ch + c;
+    const float* df = dout + f * (HH * WW) * Ch + c;
+    float4 r0[WW], r1[WW], r2[WW];
+#pragma unroll
+    for (int w = 0; w < WW; ++w) { r0[w] = z; r1[w] = ld4(af + (long long)w * Ch); }
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+#pragma unroll
+      for (int w = 0; w < WW; ++w) r2[w] = (h + 1 < HH) ? ld4(af + (long long)((h + 1) * WW + w) * Ch) : z;
+#pragma unroll
+      for (int w = 0; w < WW; ++w) {
+        const float4 d = ld4(df + (long long)(h * WW + w) * Ch);
+        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+#pragma unroll
+        for (int kx = -1; kx <= 1; ++kx) {
+          const int ww = w + kx;
+          if (ww < 0 || ww >= WW) continue;
+          const float4 x0 = r0[ww], x1 = r1[ww], x2 = r2[ww];
+          float4& t0 = aw[kx + 1]; float4& t1 = aw[3 + kx + 1]; float4& t2 = aw[6 + kx + 1];
+          t0.x += d.x * x0.x; t0.y += d.y * x0.y; t0.z += d.z * x0.z; t0.w += d.w * x0.w;
+          t1.x += d.x * x1.x; t1.y += d.y * x1.y; t1.z += d.z * x1.z; t1.w += d.w * x1.w;
+          t2.x += d.x * x2.x; t2.y += d.y * x2.y; t2.z += d.z * x2.z; t2.w += d.w * x2.w;
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < WW; ++w) { r0[w] = r1[w]; r1[w] = r2[w]; }
+    }
+  }
+  float* o = part + (long long)blockIdx.y * 10 * Ch;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) st4(o + t * Ch + c, aw[t]);
+  st4(o + 9 * Ch + c, ab);
+}
+
 // part[chunk][tap 0..8 | bias][Ch]:  dW[tap][c] = sum_{f,p} dout[f,p,c] * a[f, p + tap, c];  db[c] = sum dout.
 // Block = 64 channel-quads x 4 pixel groups (pixel p handled by group p & 3): 4x the loads in flight of the first
 // version (one thread per channel-quad walking all 64 pixels), fixed-order LDS reduction over the 4 groups.
@@ -137,6 +231,13 @@ using namespace npvp;
 extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W,
                               int Ch, int flip, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv: bad shape");
+  if (H == 8 && W == 8) {
+    const long long nthreads = (long long)frames * (Ch / 4);
+    hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a, wt,
+                       bias, out, Ch, nthreads, flip);
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
+  }
   const long long total4 = (long long)frames * H * W * Ch / 4;
   long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
@@ -163,8 +264,12 @@ extern "C" int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dw
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv_wgrad: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), "dwconv_wgrad: workspace too small");
   const int chunks = dw_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 63) / 64, nchunks), dim3(256), 0, stream, a, dout,
-                     (float*)workspace, H, W, Ch, frames, fpc);
+  if (H == 8 && W == 8)
+    hipLaunchKernelGGL((dwconv3x3_wgrad_win_kernel<8, 8>), dim3((Ch / 4 + 255) / 256, nchunks), dim3(256), 0, stream, a, dout,
+                       (float*)workspace, Ch, frames, fpc);
+  else
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 63) / 64, nchunks), dim3(256), 0, stream, a, dout,
+                       (float*)workspace, H, W, Ch, frames, fpc);
   NPVP_CHECK_LAUNCH();
   const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream);
   if (rc) { npvp_set_error("dwconv_wgrad: reduce launch failed"); return rc; }

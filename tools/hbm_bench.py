@@ -1,0 +1,56 @@
+"""Achieved HBM bandwidth of the non-GEMM kernels at the c1 size (one encoder pass: 320 frames = 20480 token rows),
+against their ALGORITHMIC bytes (each input read once, each output written once, fp32) - SURVEY 8(d).
+Usage: python tools/hbm_bench.py [--frames 320]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from npvp_amd import ops
+from npvp_amd._lib import lib
+
+dev = "cuda:0"
+F_ = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 320
+R, C, HID, P = F_ * 64, 512, 2048, 64
+PEAK = 8000.0
+torch.manual_seed(0)
+
+
+def timeit(fn, iters=20):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def report(name, nbytes, t):
+    print(f"{name:44s} {t*1e6:8.1f} us  {nbytes/1e6:8.1f} MB algorithmic  {nbytes/t/1e9:7.0f} GB/s  {100*nbytes/t/1e9/PEAK:5.1f} % of 8 TB/s", flush=True)
+
+
+h = torch.randn(F_, P * HID, device=dev)
+g = torch.randn(F_, P * HID, device=dev)
+w = torch.randn(P * HID, device=dev); b = torch.randn(P * HID, device=dev)
+nb = h.numel() * 4
+L = lib()
+mean = torch.empty(F_, device=dev); rstd = torch.empty(F_, device=dev)
+report("frame_stats [F, 64*2048]", nb, timeit(lambda: ops.check(L.npvp_frame_stats(ops._ptr(h), ops._p(0), ops._ptr(mean), ops._ptr(rstd), F_, 1, P * HID, 1e-5, ops._stream()), "s")))
+hh = h.clone().requires_grad_()
+report("frame-LN+GELU fwd (stats + apply)", 3 * nb, timeit(lambda: ops.frameln_act(hh.detach(), w, b, None, F_)))
+out = ops.frameln_act(hh, w, b, None, F_)
+report("frame-LN+GELU bwd (stats + dh,dw,db)", 5 * nb, timeit(lambda: torch.autograd.grad(out, hh, g, retain_graph=True)))
+wtb = torch.randn(10, HID, device=dev)
+a = h.view(F_, P, HID)
+report("depthwise 3x3 fwd", 2 * nb, timeit(lambda: ops.dwconv3x3(a, wtb, F_, 8, 8)))
+ar = a.clone().requires_grad_(); wr = wtb.clone().requires_grad_()
+o2 = ops.dwconv3x3(ar, wr, F_, 8, 8)
+go = g.view(F_, P, HID)
+report("depthwise 3x3 bwd (dgrad + wgrad)", 4 * nb, timeit(lambda: torch.autograd.grad(o2, [ar, wr], go, retain_graph=True)))
+x = torch.randn(R, C, device=dev); lw = torch.randn(C, device=dev); lb = torch.randn(C, device=dev)
+nx = x.numel() * 4
+report("LayerNorm(512) fwd", 2 * nx, timeit(lambda: ops.layernorm(x, lw, lb)))
+xr = x.clone().requires_grad_()
+y = ops.layernorm(xr, lw, lb)
+gy = torch.randn_like(y)
+report("LayerNorm(512) bwd", 3 * nx, timeit(lambda: torch.autograd.grad(y, xr, gy, retain_graph=True)))
