@@ -108,6 +108,9 @@ class GradSync:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
+            from . import ops
+            if ops.WgradStream._pending is not None:        # weight gradients are accumulated on their own stream
+                self.side.wait_stream(ops.WgradStream._pending[1])
             with torch.cuda.stream(self.side):
                 g.mul_(1.0 / self.world)
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

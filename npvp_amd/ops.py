@@ -198,6 +198,47 @@ class GradSink:
                     cls.listener(s[1])
 
 
+class WgradStream:
+    """Weight-gradient GEMMs run on a SECOND HIP stream.  In backward a layer's dgrad feeds the next layer, but its
+    wgrad feeds nobody until the optimiser: when it is accumulated in place (GradSink) it has no consumer in the
+    autograd graph at all.  Launched on a side stream (ordered after the producer of dy), the MFMA-bound wgrad GEMMs
+    overlap the HBM-bound backward kernels of the following layers (LayerNorm / frame-LN / depthwise / attention
+    backward, ~35 ms of a c1 step) and fill the tail of the dgrad GEMMs.  The main stream re-joins the side stream when
+    the backward pass finishes (autograd engine callback), so .grad is complete wherever it is read."""
+    enabled = os.environ.get("NPVP_WGRAD_STREAM", "1") == "1"
+    _side = {}
+    _pending = None          # (main stream, side stream) of the backward pass in flight
+
+    @classmethod
+    def stream(cls, dev):
+        key = (dev.type, dev.index)
+        if key not in cls._side:
+            cls._side[key] = torch.cuda.Stream(device=dev)
+        return cls._side[key]
+
+    @classmethod
+    def run(cls, fn, *keep_alive):
+        """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors
+        are protected from allocator reuse until the side stream has consumed them."""
+        dev = keep_alive[0].device
+        main, side = torch.cuda.current_stream(dev), cls.stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        for t in keep_alive:
+            t.record_stream(side)
+        if cls._pending is None:
+            cls._pending = (main, side)
+            torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+
+    @classmethod
+    def join(cls):
+        if cls._pending is not None:
+            main, side = cls._pending
+            main.wait_stream(side)
+            cls._pending = None
+
+
 # --------------------------------------------------------------------------- raw kernel wrappers
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False):
@@ -492,8 +533,7 @@ class _Linear(torch.autograd.Function):
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         sk = ctx.sink
         if sk and ctx.needs_input_grad[1] and want_b == (sk[1] is not None):
-            linear_wgrad(dz, x2, want_b, into=sk[0][0], into_b=sk[1][0] if want_b else None)
-            GradSink.wrote(*sk)
+            _sunk_wgrad(dz, x2, want_b, sk)
         elif ctx.needs_input_grad[1]:
             dw = linear_wgrad(dz, x2, want_b)
             if want_b:
@@ -502,6 +542,16 @@ class _Linear(torch.autograd.Function):
             db = colsum(dz)
         dres = dy if ctx.has_r else None
         return dx, dw, db, dres, None
+
+
+def _sunk_wgrad(dy, x, with_b, sk):
+    """accumulate dW (and db) of one linear into its gradient slots - on the wgrad stream when enabled"""
+    fn = lambda: linear_wgrad(dy, x, with_b, into=sk[0][0], into_b=sk[1][0] if with_b else None)
+    if WgradStream.enabled:
+        WgradStream.run(fn, dy, x)
+    else:
+        fn()
+    GradSink.wrote(*sk)
 
 
 def _wb_sink(w, b):
@@ -548,12 +598,10 @@ class _FFN(torch.autograd.Function):
         dz2 = drop_apply(dy2, ctx.d3) if ctx.d3.on else dy2
         sk = ctx.sink
         if sk:
-            (sw1, sb1), (sw2, sb2) = sk
-            linear_wgrad(dz2, a, True, into=sw2[0], into_b=sb2[0])
             dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)
-            linear_wgrad(dh, xn2, True, into=sw1[0], into_b=sb1[0])
+            _sunk_wgrad(dz2, a, True, sk[1])
             dxn = linear_dgrad(dh, w1)
-            GradSink.wrote(sw1, sb1, sw2, sb2)
+            _sunk_wgrad(dh, xn2, True, sk[0])
             return dxn.reshape(ctx.shape), dy, None, None, None, None, None
         dw2, db2 = linear_wgrad(dz2, a, True)
         dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)

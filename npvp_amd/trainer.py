@@ -89,6 +89,7 @@ class FlatAdamW:
         self.param_groups[0]["lr"] = lr
 
     def step(self):
+        ops.WgradStream.join()               # no-op after a finished backward pass (the engine callback joined already)
         L, P = lib(), ops._p
         s = P(torch.cuda.current_stream().cuda_stream)
         self.hyper[1:2].add_(1.0)
