@@ -179,10 +179,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
+    t_host = time.perf_counter() - t0          # Python + launch time: the host must stay ahead of the GPU
     fence()
     dt = time.perf_counter() - t0
     ops.GemmProbe.disarm()
-    log(f"{args.steps} timed steps: {1000.0 * dt / args.steps:.2f} ms/step")
+    log(f"{args.steps} timed steps: {1000.0 * dt / args.steps:.2f} ms/step (host enqueue {1000.0 * t_host / args.steps:.2f} ms/step)")
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
 
@@ -217,7 +218,8 @@ def main():
                                       + f", {B} clips/GPU, To={To}, "
                                       f"Tp={Tp}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * B, "frames_per_clip": To + Tp, "parallelism": f"dp{world}",
-                          "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6)},
+                          "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6),
+                          "host_enqueue_ms_per_step": round(1000.0 * t_host / args.steps, 2)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")

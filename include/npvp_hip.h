@@ -72,7 +72,11 @@ long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C);
 int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                        const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
                        const float* dres /* nullable: dx += dres, the residual branch's gradient */,
-                       int accumulate /* dw, db += */, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                       int accumulate /* 1: dw, db +=; 2: leave the partial sums in workspace */, void* workspace,
+                       long long ws_bytes, npvp_stream_t stream);
+/* second stage of npvp_layernorm_bwd(accumulate = 2), on a stream of the caller's choice (the gradient stream) */
+int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate,
+                              npvp_stream_t stream);
 
 /* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
  * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL
@@ -97,8 +101,10 @@ long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame);
 int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                          const float* b, float* dh, float* dw, float* db, int frames, int per_frame, float drop_p,
                          unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
-                         const unsigned long long* seed, int accumulate /* dw, db += */, void* workspace,
-                         long long ws_bytes, npvp_stream_t stream);
+                         const unsigned long long* seed, int accumulate /* 1: dw, db +=; 2: leave partials */,
+                         void* workspace, long long ws_bytes, npvp_stream_t stream);
+int npvp_frameln_act_bwd_reduce(const void* workspace, float* dw, float* db, int frames, int per_frame, int accumulate,
+                                npvp_stream_t stream);
 /* depthwise 3x3, zero pad 1 (ref/models/VidHRFormer.py:351-358); wt is tap-major [9][Ch]; flip=1 gives the
  * input gradient.  wgrad writes one contiguous [10][Ch] buffer: 9 taps then the bias gradient. */
 int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W, int Ch,

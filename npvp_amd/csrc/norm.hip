@@ -444,8 +444,21 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]
+  if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_layernorm_bwd_reduce)
   if (launch_sum_rows((const float*)part, dw, nb, 2 * C, 2 * C, stream, accumulate, db, C)) {
     npvp_set_error("layernorm_bwd: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
+  return NPVP_OK;
+}
+
+// second stage of npvp_layernorm_bwd(accumulate = 2) on a stream of the caller's choice: dw, db (+)= column sums of the
+// partial rows left in `workspace`
+extern "C" int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate,
+                                         hipStream_t stream) {
+  NPVP_CHECK_ARG(workspace && dw && db && rows > 0, "layernorm_bwd_reduce: bad arguments");
+  if (launch_sum_rows((const float*)workspace, dw, ln_bwd_blocks(rows), 2 * C, 2 * C, stream, accumulate ? 1 : 0, db, C)) {
+    npvp_set_error("layernorm_bwd_reduce: launch failed");
     return NPVP_ERR_LAUNCH;
   }
   return NPVP_OK;
@@ -529,8 +542,21 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
                      dout, (const float*)s1, (const float*)s2, dh, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
+  if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
     npvp_set_error("frameln_act_bwd: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
+  return NPVP_OK;
+}
+
+extern "C" int npvp_frameln_act_bwd_reduce(const void* workspace, float* dw, float* db, int frames, int per_frame,
+                                           int accumulate, hipStream_t stream) {
+  NPVP_CHECK_ARG(workspace && dw && db && frames > 0, "frameln_act_bwd_reduce: bad arguments");
+  const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  const float* part = (const float*)workspace + 2 * (long long)frames;
+  if (launch_sum_rows(part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate ? 1 : 0, db, per_frame)) {
+    npvp_set_error("frameln_act_bwd_reduce: launch failed");
     return NPVP_ERR_LAUNCH;
   }
   return NPVP_OK;

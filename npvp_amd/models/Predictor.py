@@ -81,12 +81,35 @@ class Predictor(nn.Module):
         H, W = observed_features.shape[-2:]
         op = self._pos(self.observed_coor)
         pp = self._pos(self.predict_coor)
-        memory, obs_evt = self._encode(observed_features, op)
+        dual = (self.stochastic and predict_features_gt is not None and ops.AuxStream.enabled
+                and observed_features.is_cuda and torch.is_grad_enabled())
+        if dual:
+            # the target pass (posterior) is independent of the context pass (prior): second HIP stream
+            dev = observed_features.device
+            main, aux = torch.cuda.current_stream(dev), ops.AuxStream.stream(dev)
+            aux.wait_stream(main)
+            ops.AuxStream.active = True
+            try:
+                with torch.cuda.stream(aux):
+                    _, pred_evt = self._encode(predict_features_gt, pp)
+                    zp, mu_p, logvar_p = self.evt_posterior.forward_canonical(pred_evt, H, W)
+                for t in (predict_features_gt, pp[0]) + ((pp[1],) if pp[1] is not None else ()):
+                    t.record_stream(aux)
+                memory, obs_evt = self._encode(observed_features, op)
+                zo, mu_o, logvar_o = self.evt_prior.forward_canonical(obs_evt, H, W)
+            finally:
+                ops.AuxStream.active = False
+            main.wait_stream(aux)
+            for t in (zp, mu_p, logvar_p):
+                t.record_stream(main)
+        else:
+            memory, obs_evt = self._encode(observed_features, op)
         if self.stochastic:
-            zo, mu_o, logvar_o = self.evt_prior.forward_canonical(obs_evt, H, W)
-            if predict_features_gt is not None:
-                _, pred_evt = self._encode(predict_features_gt, pp)
-                zp, mu_p, logvar_p = self.evt_posterior.forward_canonical(pred_evt, H, W)
+            if not dual:
+                zo, mu_o, logvar_o = self.evt_prior.forward_canonical(obs_evt, H, W)
+                if predict_features_gt is not None:
+                    _, pred_evt = self._encode(predict_features_gt, pp)
+                    zp, mu_p, logvar_p = self.evt_posterior.forward_canonical(pred_evt, H, W)
             if self.training:
                 assert predict_features_gt is not None, \
                     "please input groundtruth predict features for storchastic model training/val"

@@ -198,6 +198,22 @@ class GradSink:
                     cls.listener(s[1])
 
 
+class AuxStream:
+    """A second compute stream for INDEPENDENT sub-graphs of the forward pass (the two encoder passes of NPVP-S
+    training).  autograd runs each backward node on the stream of its forward, so the two backward chains overlap
+    as well; MFMA-bound GEMMs of one chain fill the gaps of the HBM-bound kernels of the other."""
+    enabled = os.environ.get("NPVP_DUAL_ENCODER", "1") == "1"
+    active = False           # inside a two-stream region (GemmProbe skips launches there: their durations overlap)
+    _streams = {}
+
+    @classmethod
+    def stream(cls, dev):
+        key = (dev.type, dev.index)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=dev)
+        return cls._streams[key]
+
+
 class WgradStream:
     """Weight-gradient GEMMs run on a SECOND HIP stream.  In backward a layer's dgrad feeds the next layer, but its
     wgrad feeds nobody until the optimiser: when it is accumulated in place (GradSink) it has no consumer in the
@@ -207,7 +223,7 @@ class WgradStream:
     the backward pass finishes (autograd engine callback), so .grad is complete wherever it is read."""
     enabled = os.environ.get("NPVP_WGRAD_STREAM", "1") == "1"
     _side = {}
-    _pending = None          # (main stream, side stream) of the backward pass in flight
+    _pending = None          # (device, side stream) while a backward pass has work in flight on the side stream
 
     @classmethod
     def stream(cls, dev):
@@ -228,14 +244,16 @@ class WgradStream:
         for t in keep_alive:
             t.record_stream(side)
         if cls._pending is None:
-            cls._pending = (main, side)
+            cls._pending = (dev, side)
             torch.autograd.Variable._execution_engine.queue_callback(cls.join)
 
     @classmethod
     def join(cls):
+        """the caller's current stream waits for the gradient stream (the autograd engine runs its final callbacks
+        under the streams that were current when backward() was called)"""
         if cls._pending is not None:
-            main, side = cls._pending
-            main.wait_stream(side)
+            dev, side = cls._pending
+            torch.cuda.current_stream(dev).wait_stream(side)
             cls._pending = None
 
 
@@ -249,7 +267,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
     seed = rng.seed_tensor(A.device) if drop.on else None
-    probe = GemmProbe.armed == (a_kc, b_kc)
+    probe = GemmProbe.armed == (a_kc, b_kc) and not AuxStream.active
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -393,10 +411,10 @@ class _LayerNorm(torch.autograd.Function):
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
         ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
-                                   _ptr(db), rows, C, ctx.relu, _p(0), int(bool(sk)), _ptr(ws), wsn, _stream()),
+                                   _ptr(db), rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(ws), wsn, _stream()),
               "npvp_layernorm_bwd")
         if sk:
-            GradSink.wrote(*sk)
+            _sunk_ln_reduce(sk, ws, rows, C)
             return dx.reshape(ctx.shape), None, None, None, None
         return dx.reshape(ctx.shape), dw, db, None, None
 
@@ -404,6 +422,20 @@ class _LayerNorm(torch.autograd.Function):
 def _ln_sink(w, b):
     sw, sb = GradSink.slot(w), GradSink.slot(b)
     return (sw, sb) if (sw is not None and sb is not None) else None
+
+
+def _sink_mode(sk):
+    """`accumulate` argument of the norm backward entry points: 0 plain outputs, 1 accumulate into the gradient slots
+    on this stream, 2 leave the partial sums in the workspace - their reduction into the slots then runs on the
+    gradient stream (WgradStream), where EVERY in-place gradient write is serialised."""
+    return 0 if not sk else (2 if WgradStream.enabled else 1)
+
+
+def _sunk_ln_reduce(sk, ws, rows, C):
+    if WgradStream.enabled:
+        WgradStream.run(lambda: check(lib().npvp_layernorm_bwd_reduce(_ptr(ws), _ptr(sk[0][0]), _ptr(sk[1][0]), rows, C, 1,
+                                                                      _stream()), "npvp_layernorm_bwd_reduce"), ws)
+    GradSink.wrote(*sk)
 
 
 def layernorm(x, w, b, eps=1e-5, relu=False):
@@ -445,10 +477,10 @@ class _LayerNormRes(torch.autograd.Function):
         dy2 = _c(dy).reshape(rows, C)
         dr2 = None if dres is None else _c(dres).reshape(rows, C)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
-                                   _ptr(db), rows, C, 0, _ptr(dr2), int(bool(sk)), _ptr(ws), wsn, _stream()),
+                                   _ptr(db), rows, C, 0, _ptr(dr2), _sink_mode(sk), _ptr(ws), wsn, _stream()),
               "npvp_layernorm_bwd")
         if sk:
-            GradSink.wrote(*sk)
+            _sunk_ln_reduce(sk, ws, rows, C)
             return dx.reshape(ctx.shape), None, None, None
         return dx.reshape(ctx.shape), dw, db, None
 
@@ -729,9 +761,12 @@ class _FrameLnAct(torch.autograd.Function):
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), h.device)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
         check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(dh), _ptr(dw),
-                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), int(bool(sk)), _ptr(ws),
+                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), _sink_mode(sk), _ptr(ws),
                                      wsn, _stream()), "npvp_frameln_act_bwd")
         if sk:
+            if WgradStream.enabled:
+                WgradStream.run(lambda: check(L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1,
+                                                                            _stream()), "npvp_frameln_act_bwd_reduce"), ws)
             GradSink.wrote(*sk)
             dw = db = None
         return dh, dw, db, (dout if has_res else None), None, None, None, None
