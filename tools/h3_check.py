@@ -7,7 +7,7 @@ from npvp_amd import ops
 
 dev = "cuda:0"
 torch.manual_seed(0)
-R, N, K = 4096, 512, 2048
+R, N, K = 4096 + 64, 512 + 128, 2048       # ragged tile edges on purpose
 
 
 def rel(a, ref):
@@ -24,7 +24,7 @@ for scale_x in (1.0, 1e-2, 1e-4, 1e-5, 1e-6, 1e-8, 1e3):
     ref_d = dy.double() @ w.double()
     ref_w = dy.double().t() @ x.double()
     line = f"scale {scale_x:8.0e}: "
-    for mode in ("bf16x6db", "f16x3"):
+    for mode in ([a for a in sys.argv[1:] if not a.startswith("-")] or ["bf16x6db", "f16x3"]):
         ops.set_gemm_precision(mode)
         yf = ops.linear_fwd(x, w, None); yd = ops.linear_dgrad(dy, w); yw = ops.linear_wgrad(dy, x)
         yw = yw[0] if isinstance(yw, tuple) else yw
