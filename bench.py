@@ -201,9 +201,17 @@ def main():
         if n:
             ach = pfl / (pms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.gemm]
+            # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command
+            # (profiles/r01_hbm_traffic_c1.*: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule)
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_c1.json")
+            if args.workload == "c1" and args.gemm == "bf16x6db" and args.flavour == "predictor" and os.path.exists(tj):
+                ent = json.load(open(tj)).get("pooled", {}).get("npvp::gemm_split_db_kernel<3, true, true, false>")
+                traffic = None if ent is None else round(ent["hbm_bytes_per_dispatch"])
             roof = {"bound": "mfma", "kernel": KERNEL_NAME[args.gemm],
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(ops.GemmProbe.bytes / n),
                     "launches": n, "avg_launch_us": round(1000.0 * pms / n, 2),
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
 

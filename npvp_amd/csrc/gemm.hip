@@ -156,7 +156,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
 // resident, and the 4 MiB weights of the 512<->2048 layers do not fit next to the streaming A panels (rocprofv3:
 // FETCH_SIZE 2.5x the algorithmic bytes).  colgroups = G > 1: XCD x owns column group x % G (a B slice <= 2 MB that stays
 // L2 resident) and row group x / G; A panels are then read by G XCDs.  Placement only changes speed, never results.
-__device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int& n0) {
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int& n0, int& z) {
+  if (p.splits > 1) {
+    // split-K (weight gradients): all tiles of one K-chunk z read the same rows of dy and x.  Dealt round-robin, the tiles
+    // of a chunk land on all 8 XCDs and every L2 fetches the whole chunk (rocprofv3 FETCH_SIZE 1.9x the operand bytes,
+    // ~2.9 TB/s of fabric traffic that the HBM-bound kernels on the other stream compete with).  With splits % 8 == 0
+    // chunk z is owned by XCD z % 8: its tiles march through K together and share each row block in ONE L2.
+    const int tiles = gridDim.x;
+    if ((p.splits & 7) == 0) {
+      const int lin = blockIdx.x + tiles * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+      const int g = slot / tiles, tl = slot - g * tiles;
+      z = g * 8 + xcd;
+      const int tile_m = tl / p.tiles_n;
+      m0 = tile_m * BM; n0 = (tl - tile_m * p.tiles_n) * BN;
+    } else {
+      z = blockIdx.y;
+      const int tile_m = blockIdx.x / p.tiles_n;
+      m0 = tile_m * BM; n0 = (blockIdx.x - tile_m * p.tiles_n) * BN;
+    }
+    return;
+  }
+  z = 0;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, loc = bid >> 3;
   int tile_m, tile_n;
@@ -181,8 +201,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   int m0, n0;
-  tile_of_block(p, m0, n0);
-  const int z = blockIdx.y;
+  int z;
+  tile_of_block(p, m0, n0, z);
 
   // split-K: this block reduces k in [z*K, (z+1)*K)
   const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
@@ -350,8 +370,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams 
   // [A term 0..NS-1 | B term 0..NS-1]
   __shared__ __attribute__((aligned(16))) char lds[2 * NS * OPER_BYTES];
   int m0, n0;
-  tile_of_block(p, m0, n0);
-  const int z = blockIdx.y;
+  int z;
+  tile_of_block(p, m0, n0, z);
   const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
   const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -432,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(GemmParams p) {
   constexpr int STAGE = 2 * NS * OPER_BYTES;                 // [A term 0..NS-1 | B term 0..NS-1]
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
   int m0, n0;
-  tile_of_block(p, m0, n0);
-  const int z = blockIdx.y;
+  int z;
+  tile_of_block(p, m0, n0, z);
   const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
   const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
   const int nk = p.K / BK;
@@ -637,8 +657,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   constexpr int BK16 = 16;
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
   int m0, n0;
-  tile_of_block(p, m0, n0);
-  const int z = blockIdx.y;
+  int z;
+  tile_of_block(p, m0, n0, z);
   const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
   const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -788,8 +808,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h3_kernel(GemmParams p) 
   constexpr int BK16 = 16;
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
   int m0, n0;
-  tile_of_block(p, m0, n0);
-  const int z = blockIdx.y;
+  int z;
+  tile_of_block(p, m0, n0, z);
   const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
   const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

@@ -158,8 +158,9 @@ class GemmProbe:
     @classmethod
     def summary(cls):
         """(launches, total_ms, total_flops) - call after torch.cuda.synchronize()."""
-        ms = sum(a.elapsed_time(b) for a, b, _ in cls.records)
-        return len(cls.records), ms, sum(f for _, _, f in cls.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in cls.records)
+        cls.bytes = sum(r[3] for r in cls.records)          # algorithmic operand + result bytes of the probed launches
+        return len(cls.records), ms, sum(r[2] for r in cls.records)
 
 
 class GradSink:
@@ -278,7 +279,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
           "npvp_gemm_f32")
     if probe:
         e1.record()
-        GemmProbe.records.append((e0, e1, 2.0 * M * N * K))
+        GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
     return out
 
 
