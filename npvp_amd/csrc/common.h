@@ -58,14 +58,32 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// exact-erf GELU (nn.GELU default) and its derivative
+// erf-GELU (nn.GELU default) and its derivative.  libm's erff costs ~45 VALU instructions with divergent branches and
+// made the frame-LN kernels VALU bound (frame-LN backward statistics: 94 us for 336 MB = 3.6 TB/s).  Phi(x) is
+// evaluated branch-free from ONE exponential shared with the density:
+//     E = exp(-x^2/2),  t = 1/(1 + p|x|/sqrt2),  1 - erf(|x|/sqrt2) = (a1 t + ... + a5 t^5) E      (A&S 7.1.26)
+//     Phi(x) = x >= 0 ? 1 - q/2 : q/2,   gelu = x Phi,   gelu' = Phi + x E / sqrt(2 pi)
+// measured in fp32: max abs error of Phi 3.0e-7, of gelu 4.2e-7 over [-12,12] (torch.nn.functional.gelu in fp32: 1.2e-6);
+// the negative branch has no cancellation.
+__device__ __forceinline__ float gelu_phi(float x, float& E) {
+  const float au = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, au, 1.0f));
+  E = __expf(-0.5f * x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float hq = 0.5f * p * t * E;
+  return x >= 0.f ? 1.0f - hq : hq;
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float E;
+  return x * gelu_phi(x, E);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float E;
+  const float phi = gelu_phi(x, E);
+  return fmaf(x * 0.39894228040143267794f, E, phi);
 }
 
 // Counter-based RNG for dropout masks: stateless, so backward replays the mask of
