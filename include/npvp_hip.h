@@ -27,6 +27,10 @@ typedef void* npvp_stream_t; /* hipStream_t */
 
 int npvp_version(void);
 const char* npvp_last_error(void);
+/* A stream of the lowest priority the device offers, for work nothing on the critical path waits for (the in-place
+ * weight-gradient writes); least / greatest receive the device's priority range (nullable). */
+void* npvp_stream_create_low_priority(int* least, int* greatest);
+int npvp_stream_destroy(void* stream);
 
 /* ---- GEMM (every nn.Linear / 1x1 Conv2d / MHA in- and out-projection and their backward:
  * ref/models/VidHRFormer.py:71-72,111,184-185,225 (token FFN), :345,364,380,387 (MlpDWBN fc1/fc2),

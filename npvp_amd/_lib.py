@@ -13,6 +13,8 @@ c_int, c_ll, c_f, c_u, c_p = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 SIGNATURES = {
     "npvp_version": (c_int, []),
     "npvp_last_error": (ctypes.c_char_p, []),
+    "npvp_stream_create_low_priority": (c_p, [c_p, c_p]),
+    "npvp_stream_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
                               c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_ll, c_p]),

@@ -10,3 +10,23 @@ extern "C" void npvp_set_error(const char* msg) {
 }
 extern "C" const char* npvp_last_error(void) { return g_err; }
 extern "C" int npvp_version(void) { return 100; }
+
+// A HIP stream of the LOWEST priority the device offers (PyTorch only hands out normal / high).  The gradient stream
+// (npvp_amd.ops.WgradStream) is created with it so that, whenever CUs free up, the kernels of the critical
+// forward/backward chain are dispatched before the queued weight-gradient workgroups.  *least / *greatest receive the
+// device's priority range (nullable).  The stream lives until npvp_stream_destroy.
+extern "C" void* npvp_stream_create_low_priority(int* least, int* greatest) {
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+  if (least) *least = lo;
+  if (greatest) *greatest = hi;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) {
+    npvp_set_error("stream_create_low_priority: hipStreamCreateWithPriority failed");
+    return nullptr;
+  }
+  return (void*)s;
+}
+extern "C" int npvp_stream_destroy(void* s) {
+  return hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : -3;
+}

@@ -17,7 +17,13 @@ def _ptr(t):
     return _p(0) if t is None else _p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the calling thread's current HIP stream as a raw handle (one C call: this runs once per kernel launch)"""
+    if _raw_stream is not None:
+        return _p(_raw_stream(torch.cuda.current_device()))
     return _p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -230,7 +236,14 @@ class WgradStream:
     def stream(cls, dev):
         key = (dev.type, dev.index)
         if key not in cls._side:
-            cls._side[key] = torch.cuda.Stream(device=dev)
+            st = None
+            if os.environ.get("NPVP_WGRAD_PRIORITY", "low") == "low":
+                # lowest device priority (torch only offers normal / high): critical-path kernels are dispatched first
+                with torch.cuda.device(dev):
+                    h = lib().npvp_stream_create_low_priority(None, None)
+                if h:
+                    st = torch.cuda.ExternalStream(h, device=dev)
+            cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return cls._side[key]
 
     @classmethod
