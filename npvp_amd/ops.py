@@ -218,6 +218,11 @@ class AuxStream:
         key = (dev.type, dev.index)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=dev)
+            # gradients of the few parameters that still go through autograd's AccumulateGrad are produced on two
+            # streams on purpose; the engine synchronises them, the advisory warning about it is noise here
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         return cls._streams[key]
 
 

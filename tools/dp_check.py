@@ -35,9 +35,14 @@ def build(sync):
 
 def run(m, p, f, e, gsync):
     m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: e
-    opt = npvp_amd.FlatAdamW(m, lr=1e-4, clip_module=m.transformer)
+    # lr = 0: the parameters stay put, so the gradients of the LATER (overlapped) steps are comparable to 1e-6 -
+    # with lr > 0 AdamW's first updates are ~lr*sign(g) and amplify rounding-level gradient differences
+    opt = npvp_amd.FlatAdamW(m, lr=0.0, clip_module=m.transformer)
     gs = dp.GradSync(opt.buf, bucket_bytes=8 << 20) if gsync else None
-    out = npvp_amd.predictor_train_step(m, opt, p, f, 0.01, 1e-6, 1.0, grad_sync=gs)
+    # 3 steps: the first one teaches GradSync the per-parameter contribution counts (everything reduced in finish()),
+    # the next ones take the overlapped path (buckets reduced while backward is still running)
+    for _ in range(3):
+        out = npvp_amd.predictor_train_step(m, opt, p, f, 0.01, 1e-6, 1.0, grad_sync=gs)
     return opt, out, gs
 
 
@@ -57,6 +62,7 @@ if rank == 0:
     print(f"[dp_check] world={world} backend={dist.get_backend()} buckets={len(gs.buckets)} launched={gs.launched} "
           f"grad rel-L2 {rel:.3e}  mean-loss {float(loss) / world:.6f} vs single {rout['loss']:.6f}  "
           f"BN running_mean max diff {rm:.2e}  param max diff after step {pe:.2e}", flush=True)
+    assert pe == 0.0, "lr = 0: parameters must not move"
     assert rel < 1e-4 and abs(float(loss) / world - rout["loss"]) < 1e-5 * abs(rout["loss"]) + 1e-8 and rm < 1e-5, "DP != single"
     print("[dp_check] OK", flush=True)
 dist.barrier()
