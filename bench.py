@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--flavour", default="predictor", choices=["predictor", "full"],
                     help="predictor: feature grids resident in HBM (the BASELINE metric's step); full: SURVEY 8d's second "
                          "flavour, pixels -> frozen encoder -> predictor -> frozen decoder -> image L1 (AE = stock PyTorch-ROCm)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from one captured HIP graph (N=1, predictor flavour; no per-kernel probe: roofline null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     args = ap.parse_args()
@@ -162,6 +164,14 @@ def main():
                                             P["max_grad_norm"], sync=False, grad_sync=gsync)
         return npvp_amd.predictor_train_step(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"],
                                              sync=False, grad_sync=gsync)
+
+    if args.graph:
+        assert world == 1 and args.flavour == "predictor", "--graph: single process, predictor-only flavour"
+        args.no_probe = True
+        opt.set_lr(P["predictor_lr"])
+        gstep = npvp_amd.GraphedTrainStep(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"])
+        log("step captured into a HIP graph")
+        step = lambda i: gstep(lr=cosine_warm_restarts_lr(P["predictor_lr"], P["scheduler_eta_min"], P["scheduler_T0"], i / iters_per_epoch))
 
     def fence():
         torch.cuda.synchronize()
@@ -223,7 +233,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"{name} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
                                                      else "FULL train step from pixels (frozen AE enc/dec in stock PyTorch-ROCm)")
-                                      + f", {B} clips/GPU, To={To}, "
+                                      + (" [HIP-graph replay]" if args.graph else "") + f", {B} clips/GPU, To={To}, "
                                       f"Tp={Tp}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * B, "frames_per_clip": To + Tp, "parallelism": f"dp{world}",
                           "algorithmic_tflop_per_step_per_gpu": round(flops_step / 1e12, 3), "final_loss": round(loss, 6),

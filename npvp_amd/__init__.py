@@ -10,12 +10,12 @@ from .models import (Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, VidHR
                      EventEncoder, L1Loss, Div_KL, DropPath, ResnetEncoder, ResnetDecoder, build_frozen_autoencoder)
 from .trainer import (FlatAdamW, predictor_train_step, full_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg,
                       context_lists, rand_context_collate, rand_context_batch_process, vfi_batch_process,
-                      save_lightning_checkpoint, load_lightning_checkpoint)
+                      save_lightning_checkpoint, load_lightning_checkpoint, GraphedTrainStep)
 from . import ops
 
 __all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
            "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
            "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "FlatAdamW", "predictor_train_step", "full_train_step", "context_lists",
            "rand_context_collate", "rand_context_batch_process", "vfi_batch_process",
-           "save_lightning_checkpoint", "load_lightning_checkpoint",
+           "save_lightning_checkpoint", "load_lightning_checkpoint", "GraphedTrainStep",
            "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops"]

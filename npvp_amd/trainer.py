@@ -320,3 +320,37 @@ def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, str
     if opt is not None and ck.get("optimizer_states"):
         opt.load_state_dict(ck["optimizer_states"][0], predictor)
     return ck.get("epoch", 0), ck.get("global_step", 0)
+
+
+class GraphedTrainStep:
+    """The whole optimisation step (forward, losses, backward incl. the gradient / auxiliary streams, clip, AdamW) captured
+    ONCE into a HIP graph and replayed per step: the host side of a step (~70 ms of Python and ~3500 launches at any
+    batch size) shrinks to one graph launch, which is what small per-GPU batches (c0: 4 clips, c3/c4: 8 clips per GPU) are
+    bound by.  Everything a replay must see differently lives in device memory: the input batch (copied into static
+    buffers), the dropout seed (bumped by a kernel inside the graph), lr / step count / clip coefficient.
+    Single-process only: collectives are not captured (use the eager step with GradSync for N > 1)."""
+
+    def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3):
+        self.opt = opt
+        self.past, self.fut = past_feats.clone(), future_feats.clone()
+        args = (predictor, opt, self.past, self.fut, lam_PF_L1, KL_beta, max_grad_norm)
+        side = torch.cuda.Stream(device=self.past.device)
+        side.wait_stream(torch.cuda.current_stream(self.past.device))
+        with torch.cuda.stream(side):               # eager warm-up on a side stream (lazy streams / workspaces get created)
+            for _ in range(warmup):
+                predictor_train_step(*args, sync=False)
+        torch.cuda.current_stream(self.past.device).wait_stream(side)
+        torch.cuda.synchronize(self.past.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = predictor_train_step(*args, sync=False)
+
+    def __call__(self, past_feats=None, future_feats=None, lr=None):
+        if lr is not None:
+            self.opt.set_lr(lr)
+        if past_feats is not None:
+            self.past.copy_(past_feats)
+        if future_feats is not None:
+            self.fut.copy_(future_feats)
+        self.graph.replay()
+        return self.out
