@@ -13,6 +13,7 @@
 // 256-B row segments, softmax in registers, attention dropout replayed in backward from a
 // counter hash.  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
 #include "common.h"
+#include <cstdlib>
 
 namespace npvp {
 
@@ -299,6 +300,201 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
 }
 
+// =====================================================================================================
+// MFMA form for L, S <= 16 (spatial 4x4 windows; temporal / enc-dec with T <= 16): no LDS at all.
+// The LDS kernels above spend their time on ds_reads (every lane re-reads whole K / V rows for its dot products:
+// ~400 KB of LDS traffic per wave in backward, 21.6 KB of LDS per wave -> 6 waves per CU).  Here every 16x16 product
+// runs on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) with operands loaded from global memory
+// straight into the MFMA operand layout.  With lane = 16*c + n the instruction takes A[m=n][k=c], B[k=c][col=n] and
+// returns D[4c+i][n] in register i.  Two tricks make every load a coalesced float4 and remove all transposes:
+//   * a reduction index may be permuted freely if both operands use the same permutation:
+//       "R" tiles  X_R[s]      = X[n][16c + s]      (s = 0..15, one 64-byte chunk of row n)  for products over d,
+//       "G" tiles  X_G[i].blk  = X[4c+i][4n + blk]  (four float4 of rows 4c..4c+3)           for products over rows;
+//     the output column of the row-reducing products is likewise d = 4n + blk, so results leave as float4 stores;
+//   * the score matrix is computed in BOTH orientations (16 extra MFMAs, 4 extra exps per lane):
+//       orientation A: register i = S[query n][key 4c+i]   - feeds P V and dS K     (reduction over keys)
+//       orientation B: register i = S[query 4c+i][key n]   - feeds P^T dO, dS^T Q   (reduction over queries)
+//     so no 16x16 transpose is ever needed; the per-query softmax statistics move by three __shfl per query.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define NPVP_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+struct AttnTileR { float v[16]; };
+struct AttnTileG { float4 v[4]; };
+
+__device__ __forceinline__ void attn_load_r(AttnTileR& t, const float* src, long long ld, const AttnParams& p, long long g,
+                                            int nrows, int Tn, int head, int n, int c) {
+  const int r = n < nrows ? n : nrows - 1;
+  const float* q = src + attn_row(p, g, r, Tn) * ld + head * HD + 16 * c;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const float4 x = ld4(q + 4 * s4);
+    t.v[4 * s4 + 0] = x.x; t.v[4 * s4 + 1] = x.y; t.v[4 * s4 + 2] = x.z; t.v[4 * s4 + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void attn_load_g(AttnTileG& t, const float* src, long long ld, const AttnParams& p, long long g,
+                                            int nrows, int Tn, int head, int n, int c) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * c + i < nrows ? 4 * c + i : nrows - 1;
+    t.v[i] = ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n);
+  }
+}
+// D rows 4c+i, columns d = 4n + blk: one float4 per row
+__device__ __forceinline__ void attn_store_d(const f32x4_t (&acc)[4], float* dst, long long ld, const AttnParams& p, long long g,
+                                             int nrows, int Tn, int head, int n, int c) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * c + i;
+    if (r < nrows) st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n, make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]));
+  }
+}
+__device__ __forceinline__ float blk_of(const float4& x, int b) { return b == 0 ? x.x : b == 1 ? x.y : b == 2 ? x.z : x.w; }
+
+// out[blk] = sum_i A[i] (x) G[i].blk : the row-reducing product (reduction index = 4c+i on both sides)
+__device__ __forceinline__ void attn_mm_rows(f32x4_t (&acc)[4], const float (&a)[4], const AttnTileG& gt) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[b] = NPVP_MFMA16(a[i], blk_of(gt.v[i], b), acc[b]);
+  }
+}
+__device__ __forceinline__ f32x4_t attn_mm_d(const AttnTileR& a, const AttnTileR& b) {
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = NPVP_MFMA16(a.v[s], b.v[s], acc);
+  return acc;
+}
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
+  const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= p.total) return;                      // waves are independent: no barriers in this kernel
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  AttnTileR qr, kr;
+  AttnTileG vg;
+  attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c);
+  attn_load_r(kr, p.k, p.ld_k, p, g, S, Tk, head, n, c);
+  attn_load_g(vg, p.v, p.ld_v, p, g, S, Tk, head, n, c);
+  // orientation A: sa[i] = S[query n][key 4c+i]
+  const f32x4_t sa = attn_mm_d(kr, qr);
+  float sc[4], mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * c + i;
+    float s = sa[i] * p.scale;
+    if (j >= S || (p.mask_mode == 1 && j == S - 1 && n < L - 1)) s = -INFINITY;
+    sc[i] = s; mx = fmaxf(mx, s);
+  }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { sc[i] = (sc[i] == -INFINITY) ? 0.f : __expf(sc[i] - mx); sum += sc[i]; }
+  sum = quad_sum(sum);
+  const float inv = 1.f / sum;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  const int qn = n < L ? n : L - 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * c + i;
+    sc[i] *= inv;
+    if (p.drop_thresh && j < S)
+      sc[i] *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+  }
+  f32x4_t o[4];
+  attn_mm_rows(o, sc, vg);
+  attn_store_d(o, p.o, p.ld_o, p, g, L, Tq, head, n, c);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
+  const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= p.total) return;
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  AttnTileR qr, kr, vr, gr;
+  attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c);
+  attn_load_r(kr, p.k, p.ld_k, p, g, S, Tk, head, n, c);
+  attn_load_r(vr, p.v, p.ld_v, p, g, S, Tk, head, n, c);
+  attn_load_r(gr, p.go, p.ld_o, p, g, L, Tq, head, n, c);
+
+  // ---- orientation A: register i <-> (query n, key 4c+i): softmax statistics, dS for dQ
+  float mx, inv, rs;
+  {
+    const f32x4_t sa = attn_mm_d(kr, qr), da = attn_mm_d(vr, gr);
+    const int qn = n < L ? n : L - 1;
+    float sc[4], dp[4];
+    mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * c + i;
+      float s = sa[i] * p.scale;
+      if (j >= S || (p.mask_mode == 1 && j == S - 1 && n < L - 1)) s = -INFINITY;
+      sc[i] = s; mx = fmaxf(mx, s);
+    }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc[i] = (sc[i] == -INFINITY) ? 0.f : __expf(sc[i] - mx); sum += sc[i]; }
+    sum = quad_sum(sum);
+    inv = 1.f / sum;
+    rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * c + i;
+      float m = 1.f;
+      if (p.drop_thresh && j < S)
+        m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+      sc[i] *= inv;
+      dp[i] = da[i] * m;
+      rs += dp[i] * sc[i];
+    }
+    rs = quad_sum(rs);
+    float ds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ds[i] = sc[i] * (dp[i] - rs) * p.scale;
+    AttnTileG kg;
+    attn_load_g(kg, p.k, p.ld_k, p, g, S, Tk, head, n, c);
+    f32x4_t dq[4];
+    attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] = sum_j dS[q][j] K[j][d]
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c);
+  }
+  // ---- orientation B: register i <-> (query 4c+i, key n): dK, dV
+  {
+    const f32x4_t sb = attn_mm_d(qr, kr), db = attn_mm_d(gr, vr);
+    float pd[4], ds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 4 * c + i, qc = q < L ? q : L - 1;
+      const float mxq = __shfl(mx, qc, 64), invq = __shfl(inv, qc, 64), rsq = __shfl(rs, qc, 64);
+      float s = sb[i] * p.scale;
+      const bool dead = n >= S || q >= L || (p.mask_mode == 1 && n == S - 1 && q < L - 1);
+      const float pr = dead ? 0.f : __expf(s - mxq) * invq;
+      float m = 1.f;
+      if (p.drop_thresh && !dead)
+        m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + n, p.drop_thresh, p.drop_inv_keep);
+      pd[i] = pr * m;
+      ds[i] = pr * (db[i] * m - rsq) * p.scale;
+    }
+    AttnTileG gg, qg;
+    attn_load_g(gg, p.go, p.ld_o, p, g, L, Tq, head, n, c);
+    attn_load_g(qg, p.q, p.ld_q, p, g, L, Tq, head, n, c);
+    f32x4_t dv[4], dk[4];
+    attn_mm_rows(dv, pd, gg);                                  // dV[j][d] = sum_q Pd[q][j] dO[q][d]
+    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c);
+    attn_mm_rows(dk, ds, qg);                                  // dK[j][d] = sum_q dS[q][j] Q[q][d]
+    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c);
+  }
+}
+
 static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
                       int Tk, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, bool bwd) {
   if (head_dim != HD) { npvp_set_error("attn: head_dim must be 64"); return NPVP_ERR_ARG; }
@@ -348,7 +544,10 @@ extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, lon
   const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
   const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
   const int L = p.L > p.S ? p.L : p.S;
-  if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;       // keep the LDS kernels reachable for A/B runs
+  if (L <= 16 && !use_lds)
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)((p.total + 3) / 4)), dim3(256), 0, stream, p);
+  else if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -370,7 +569,10 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
   const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
   const int L = p.L > p.S ? p.L : p.S;
-  if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;
+  if (L <= 16 && !use_lds)
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)((p.total + 3) / 4)), dim3(256), 0, stream, p);
+  else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;

@@ -54,3 +54,15 @@ xr = x.clone().requires_grad_()
 y = ops.layernorm(xr, lw, lb)
 gy = torch.randn_like(y)
 report("LayerNorm(512) bwd", 3 * nx, timeit(lambda: torch.autograd.grad(y, xr, gy, retain_graph=True)))
+# attention cores at the c1 size: spatial 4x4 windows over 320 frames; temporal T=10 over 32 clips
+from npvp_amd.ops import AttnCfg
+qk = torch.randn(R, 2 * C, device=dev, requires_grad=True); vv = torch.randn(R, C, device=dev, requires_grad=True)
+cfg_s = AttnCfg(0, F_, 64, 8, 4, 0, 0, 8, 0, 0.1)
+report("attention spatial fwd (q,k,v read + o write)", 4 * nx, timeit(lambda: ops.attn_packed(qk.detach(), vv.detach(), cfg_s)))
+ya = ops.attn_packed(qk, vv, cfg_s); ga = torch.randn_like(ya)
+report("attention spatial bwd (7 tensor passes)", 7 * nx, timeit(lambda: torch.autograd.grad(ya, [qk, vv], ga, retain_graph=True)))
+T_ = 10
+cfg_t = AttnCfg(1, F_ // T_, 64, 8, 0, T_, T_, 8, 1, 0.1)
+report("attention temporal fwd (T=10, masked)", 4 * nx, timeit(lambda: ops.attn_packed(qk.detach(), vv.detach(), cfg_t)))
+yt = ops.attn_packed(qk, vv, cfg_t)
+report("attention temporal bwd (T=10, masked)", 7 * nx, timeit(lambda: torch.autograd.grad(yt, [qk, vv], ga, retain_graph=True)))
