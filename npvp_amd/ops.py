@@ -226,6 +226,39 @@ class AuxStream:
         return cls._streams[key]
 
 
+class Fork:
+    """Run an independent piece of the forward graph on the companion stream of the current stream (the value
+    projection next to the query/key projection of an attention layer: a 640-workgroup GEMM alone leaves a sixth of the
+    768 workgroup slots idle and has a one-wave tail; two GEMMs in flight fill both).  autograd replays each node on its
+    forward stream, so the two backward GEMM chains overlap as well."""
+    enabled = os.environ.get("NPVP_FORK", "1") == "1"
+
+    @classmethod
+    def available(cls, t):
+        """only outside a two-stream region: the companion IS the auxiliary stream.  (More than ~4 streams per process
+        share hardware queues on this stack and the step slows down by 40 % - measured.)"""
+        return cls.enabled and t.is_cuda and not AuxStream.active
+
+    @classmethod
+    def run(cls, fn, *inputs):
+        dev = inputs[0].device
+        cur = torch.cuda.current_stream(dev)
+        comp = AuxStream.stream(dev)
+        comp.wait_stream(cur)
+        with torch.cuda.stream(comp):
+            out = fn()
+        for t in inputs:
+            t.record_stream(comp)
+        return out, (cur, comp)
+
+    @staticmethod
+    def join(token, *outs):
+        cur, comp = token
+        cur.wait_stream(comp)
+        for t in outs:
+            t.record_stream(cur)
+
+
 class WgradStream:
     """Weight-gradient GEMMs run on a SECOND HIP stream.  In backward a layer's dgrad feeds the next layer, but its
     wgrad feeds nobody until the optimiser: when it is accumulated in place (GradSink) it has no consumer in the
