@@ -51,7 +51,10 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
-    if force or jobs or not os.path.exists(LIB):
+    stale = [f for f in os.listdir(OBJ) if f.endswith(".o") and os.path.join(OBJ, f) not in objs]
+    for f in stale:                      # a source file was removed: its object must not linger in the library
+        os.remove(os.path.join(OBJ, f))
+    if force or jobs or stale or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         # --no-undefined: a symbol dropped from one translation unit must fail HERE, not at first call on the GPU box
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--no-undefined", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
