@@ -43,32 +43,17 @@ class MultiheadAttention(nn.Module):
         """q = k source x_qk [R,C], value source x_v [R,C] -> residual + drop(out_proj(core))."""
         C = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        if ops.Fork.available(x_v):
-            was, ops.AuxStream.active = ops.AuxStream.active, True          # overlapped GEMMs: not probed
-            v, tok = ops.Fork.run(lambda: ops.linear(x_v, w[2 * C:], b[2 * C:]), x_v)
-            qk = ops.linear(x_qk, w[:2 * C], b[:2 * C])
-            ops.AuxStream.active = was
-            ops.Fork.join(tok, v)
-        else:
-            qk = ops.linear(x_qk, w[:2 * C], b[:2 * C])
-            v = ops.linear(x_v, w[2 * C:], b[2 * C:])
+        qk = ops.linear(x_qk, w[:2 * C], b[:2 * C])
+        v = ops.linear(x_v, w[2 * C:], b[2 * C:])
         o = ops.attn_packed(qk, v, cfg)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, drop=drop)
 
     def cross_attention(self, x_q, x_k, x_v, cfg, residual=None, drop=ops.NO_DROP):
         C = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        if ops.Fork.available(x_v):
-            was, ops.AuxStream.active = ops.AuxStream.active, True
-            (k, v), tok = ops.Fork.run(lambda: (ops.linear(x_k, w[C:2 * C], b[C:2 * C]), ops.linear(x_v, w[2 * C:], b[2 * C:])),
-                                       x_k, x_v)
-            q = ops.linear(x_q, w[:C], b[:C])
-            ops.AuxStream.active = was
-            ops.Fork.join(tok, k, v)
-        else:
-            q = ops.linear(x_q, w[:C], b[:C])
-            k = ops.linear(x_k, w[C:2 * C], b[C:2 * C])
-            v = ops.linear(x_v, w[2 * C:], b[2 * C:])
+        q = ops.linear(x_q, w[:C], b[:C])
+        k = ops.linear(x_k, w[C:2 * C], b[C:2 * C])
+        v = ops.linear(x_v, w[2 * C:], b[2 * C:])
         o = ops.attn(q, k, v, cfg)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, drop=drop)
 
