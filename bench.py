@@ -224,7 +224,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(ops.GemmProbe.bytes / n),
                     # NPVP-S runs its two encoder passes on two streams: those GEMMs share the device pairwise and look
                     # slower one by one (same as in a rocprofv3 trace); the decoder's launches have the device alone
-                    "unshared": None if not ops.GemmProbe.unshared[0] else {
+                    "unshared": None if ops.GemmProbe.unshared[0] in (0, n) else {
                         "launches": ops.GemmProbe.unshared[0],
                         "achieved": round(ops.GemmProbe.unshared[2] / (ops.GemmProbe.unshared[1] * 1e-3) / 1e12, 2),
                         "avg_launch_us": round(1000.0 * ops.GemmProbe.unshared[1] / ops.GemmProbe.unshared[0], 2)},

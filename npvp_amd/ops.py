@@ -213,7 +213,11 @@ class AuxStream:
     """A second compute stream for INDEPENDENT sub-graphs of the forward pass (the two encoder passes of NPVP-S
     training).  autograd runs each backward node on the stream of its forward, so the two backward chains overlap
     as well; MFMA-bound GEMMs of one chain fill the gaps of the HBM-bound kernels of the other."""
-    enabled = os.environ.get("NPVP_DUAL_ENCODER", "1") == "1"
+    # opt-in (NPVP_DUAL_ENCODER=1): measured -2.6 ms (2 %) on a c1 step.  Off by default so that (a) every kernel has
+    # the device to itself in the forward pass and per-kernel timings agree between bench.py's live probe and a
+    # rocprofv3 trace (which serialises the two streams), and (b) under data parallelism the SyncBatchNorm collectives
+    # of the two passes are issued from ONE stream in program order.
+    enabled = os.environ.get("NPVP_DUAL_ENCODER", "0") == "1"
     active = False           # inside a two-stream region (GemmProbe skips launches there: their durations overlap)
     _streams = {}
 
