@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 }
 
 // =====================================================================================================
-// MFMA form for L, S <= 16 (spatial 4x4 windows; temporal / enc-dec with T <= 16): no LDS at all.
+// MFMA form (sequences up to 32 = one or two 16-row blocks per side): no LDS at all.
 // The LDS kernels above spend their time on ds_reads (every lane re-reads whole K / V rows for its dot products:
 // ~400 KB of LDS traffic per wave in backward, 21.6 KB of LDS per wave -> 6 waves per CU).  Here every 16x16 product
 // runs on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) with operands loaded from global memory
@@ -321,9 +321,11 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 struct AttnTileR { float v[16]; };
 struct AttnTileG { float4 v[4]; };
 
+// blk = 16-row block of the sequence (sequences up to 32 = two blocks); rows past the end are clamped (finite data,
+// their contributions are masked or never stored)
 __device__ __forceinline__ void attn_load_r(AttnTileR& t, const float* src, long long ld, const AttnParams& p, long long g,
-                                            int nrows, int Tn, int head, int n, int c) {
-  const int r = n < nrows ? n : nrows - 1;
+                                            int nrows, int Tn, int head, int n, int c, int blk) {
+  const int r = min(16 * blk + n, nrows - 1);
   const float* q = src + attn_row(p, g, r, Tn) * ld + head * HD + 16 * c;
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
@@ -332,32 +334,35 @@ __device__ __forceinline__ void attn_load_r(AttnTileR& t, const float* src, long
   }
 }
 __device__ __forceinline__ void attn_load_g(AttnTileG& t, const float* src, long long ld, const AttnParams& p, long long g,
-                                            int nrows, int Tn, int head, int n, int c) {
+                                            int nrows, int Tn, int head, int n, int c, int blk) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = 4 * c + i < nrows ? 4 * c + i : nrows - 1;
+    const int r = min(16 * blk + 4 * c + i, nrows - 1);
     t.v[i] = ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n);
   }
 }
-// D rows 4c+i, columns d = 4n + blk: one float4 per row
+// D rows 16 blk + 4c+i, columns d = 4n + b: one float4 per row
 __device__ __forceinline__ void attn_store_d(const f32x4_t (&acc)[4], float* dst, long long ld, const AttnParams& p, long long g,
-                                             int nrows, int Tn, int head, int n, int c) {
+                                             int nrows, int Tn, int head, int n, int c, int blk) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = 4 * c + i;
+    const int r = 16 * blk + 4 * c + i;
     if (r < nrows) st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n, make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]));
   }
 }
 __device__ __forceinline__ float blk_of(const float4& x, int b) { return b == 0 ? x.x : b == 1 ? x.y : b == 2 ? x.z : x.w; }
 
-// out[blk] = sum_i A[i] (x) G[i].blk : the row-reducing product (reduction index = 4c+i on both sides)
+// acc[b] += sum_i A[i] (x) G[i].b : the row-reducing product (reduction index = 4c+i on both sides)
 __device__ __forceinline__ void attn_mm_rows(f32x4_t (&acc)[4], const float (&a)[4], const AttnTileG& gt) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[b] = NPVP_MFMA16(a[i], blk_of(gt.v[i], b), acc[b]);
   }
+}
+__device__ __forceinline__ void attn_zero(f32x4_t (&acc)[4]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 __device__ __forceinline__ f32x4_t attn_mm_d(const AttnTileR& a, const AttnTileR& b) {
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -368,6 +373,8 @@ __device__ __forceinline__ f32x4_t attn_mm_d(const AttnTileR& a, const AttnTileR
 __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// NQ / NK = number of 16-row blocks of the query / key sequence (1 or 2)
+template <int NQ, int NK>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -376,41 +383,59 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const long long g = wid / p.heads;
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
-  AttnTileR qr, kr;
-  AttnTileG vg;
-  attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c);
-  attn_load_r(kr, p.k, p.ld_k, p, g, S, Tk, head, n, c);
-  attn_load_g(vg, p.v, p.ld_v, p, g, S, Tk, head, n, c);
-  // orientation A: sa[i] = S[query n][key 4c+i]
-  const f32x4_t sa = attn_mm_d(kr, qr);
-  float sc[4], mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * c + i;
-    float s = sa[i] * p.scale;
-    if (j >= S || (p.mask_mode == 1 && j == S - 1 && n < L - 1)) s = -INFINITY;
-    sc[i] = s; mx = fmaxf(mx, s);
-  }
-  mx = quad_max(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { sc[i] = (sc[i] == -INFINITY) ? 0.f : __expf(sc[i] - mx); sum += sc[i]; }
-  sum = quad_sum(sum);
-  const float inv = 1.f / sum;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
-  const int qn = n < L ? n : L - 1;
+  AttnTileR kr[NK];
+  AttnTileG vg[NK];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * c + i;
-    sc[i] *= inv;
-    if (p.drop_thresh && j < S)
-      sc[i] *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+  for (int kb = 0; kb < NK; ++kb) {
+    attn_load_r(kr[kb], p.k, p.ld_k, p, g, S, Tk, head, n, c, kb);
+    attn_load_g(vg[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
   }
-  f32x4_t o[4];
-  attn_mm_rows(o, sc, vg);
-  attn_store_d(o, p.o, p.ld_o, p, g, L, Tq, head, n, c);
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    AttnTileR qr;
+    attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c, qb);
+    __builtin_amdgcn_sched_barrier(0);      // all tile loads in flight before the first MFMA waits for one of them
+    const int q = 16 * qb + n, qn = min(q, L - 1);
+    // orientation A: sc[kb][i] = S[query q][key 16kb + 4c+i]
+    float sc[NK][4], mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      const f32x4_t sa = attn_mm_d(kr[kb], qr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float s = sa[i] * p.scale;
+        if (j >= S || (p.mask_mode == 1 && j == S - 1 && q < L - 1)) s = -INFINITY;
+        sc[kb][i] = s; mx = fmaxf(mx, s);
+      }
+    }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[kb][i] = (sc[kb][i] == -INFINITY) ? 0.f : __expf(sc[kb][i] - mx); sum += sc[kb][i]; }
+    sum = quad_sum(sum);
+    const float inv = 1.f / sum;
+    f32x4_t o[4];
+    attn_zero(o);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        sc[kb][i] *= inv;
+        if (p.drop_thresh && j < S)
+          sc[kb][i] *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+      }
+      attn_mm_rows(o, sc[kb], vg[kb]);
+    }
+    attn_store_d(o, p.o, p.ld_o, p, g, L, Tq, head, n, c, qb);
+  }
 }
 
+template <int NQ, int NK>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -420,78 +445,105 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
-  AttnTileR qr, kr, vr, gr;
-  attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c);
-  attn_load_r(kr, p.k, p.ld_k, p, g, S, Tk, head, n, c);
-  attn_load_r(vr, p.v, p.ld_v, p, g, S, Tk, head, n, c);
-  attn_load_r(gr, p.go, p.ld_o, p, g, L, Tq, head, n, c);
-
-  // ---- orientation A: register i <-> (query n, key 4c+i): softmax statistics, dS for dQ
-  float mx, inv, rs;
-  {
-    const f32x4_t sa = attn_mm_d(kr, qr), da = attn_mm_d(vr, gr);
-    const int qn = n < L ? n : L - 1;
-    float sc[4], dp[4];
-    mx = -INFINITY;
+  AttnTileR kr[NK], vr[NK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * c + i;
-      float s = sa[i] * p.scale;
-      if (j >= S || (p.mask_mode == 1 && j == S - 1 && n < L - 1)) s = -INFINITY;
-      sc[i] = s; mx = fmaxf(mx, s);
+  for (int kb = 0; kb < NK; ++kb) {
+    attn_load_r(kr[kb], p.k, p.ld_k, p, g, S, Tk, head, n, c, kb);
+    attn_load_r(vr[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
+  }
+  // ---- orientation A per query block: softmax statistics of query 16qb+n (kept for phase B), dQ
+  float mxs[NQ], invs[NQ], rss[NQ];
+  AttnTileR qr, gr;               // with a single query block the tiles of phase A are reused by phase B
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c, qb);
+    attn_load_r(gr, p.go, p.ld_o, p, g, L, Tq, head, n, c, qb);
+    AttnTileG kg[NK];
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) attn_load_g(kg[kb], p.k, p.ld_k, p, g, S, Tk, head, n, c, kb);
+    __builtin_amdgcn_sched_barrier(0);      // all tile loads in flight before the first MFMA waits for one of them
+    const int q = 16 * qb + n, qn = min(q, L - 1);
+    float sc[NK][4], dp[NK][4], mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      const f32x4_t sa = attn_mm_d(kr[kb], qr), da = attn_mm_d(vr[kb], gr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float s = sa[i] * p.scale;
+        if (j >= S || (p.mask_mode == 1 && j == S - 1 && q < L - 1)) s = -INFINITY;
+        sc[kb][i] = s; dp[kb][i] = da[i]; mx = fmaxf(mx, s);
+      }
     }
     mx = quad_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sc[i] = (sc[i] == -INFINITY) ? 0.f : __expf(sc[i] - mx); sum += sc[i]; }
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[kb][i] = (sc[kb][i] == -INFINITY) ? 0.f : __expf(sc[kb][i] - mx); sum += sc[kb][i]; }
     sum = quad_sum(sum);
-    inv = 1.f / sum;
-    rs = 0.f;
+    const float inv = 1.f / sum;
+    float rs = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * c + i;
-      float m = 1.f;
-      if (p.drop_thresh && j < S)
-        m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
-      sc[i] *= inv;
-      dp[i] = da[i] * m;
-      rs += dp[i] * sc[i];
-    }
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float m = 1.f;
+        if (p.drop_thresh && j < S)
+          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+        sc[kb][i] *= inv;
+        dp[kb][i] *= m;
+        rs += dp[kb][i] * sc[kb][i];
+      }
     rs = quad_sum(rs);
-    float ds[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ds[i] = sc[i] * (dp[i] - rs) * p.scale;
-    AttnTileG kg;
-    attn_load_g(kg, p.k, p.ld_k, p, g, S, Tk, head, n, c);
+    mxs[qb] = mx; invs[qb] = inv; rss[qb] = rs;
     f32x4_t dq[4];
-    attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] = sum_j dS[q][j] K[j][d]
-    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c);
-  }
-  // ---- orientation B: register i <-> (query 4c+i, key n): dK, dV
-  {
-    const f32x4_t sb = attn_mm_d(qr, kr), db = attn_mm_d(gr, vr);
-    float pd[4], ds[4];
+    attn_zero(dq);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = 4 * c + i, qc = q < L ? q : L - 1;
-      const float mxq = __shfl(mx, qc, 64), invq = __shfl(inv, qc, 64), rsq = __shfl(rs, qc, 64);
-      float s = sb[i] * p.scale;
-      const bool dead = n >= S || q >= L || (p.mask_mode == 1 && n == S - 1 && q < L - 1);
-      const float pr = dead ? 0.f : __expf(s - mxq) * invq;
-      float m = 1.f;
-      if (p.drop_thresh && !dead)
-        m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + n, p.drop_thresh, p.drop_inv_keep);
-      pd[i] = pr * m;
-      ds[i] = pr * (db[i] * m - rsq) * p.scale;
+    for (int kb = 0; kb < NK; ++kb) {
+      float ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ds[i] = sc[kb][i] * (dp[kb][i] - rs) * p.scale;
+      attn_mm_rows(dq, ds, kg[kb]);                              // dQ[q][d] += sum_j dS[q][j] K[j][d]
     }
-    AttnTileG gg, qg;
-    attn_load_g(gg, p.go, p.ld_o, p, g, L, Tq, head, n, c);
-    attn_load_g(qg, p.q, p.ld_q, p, g, L, Tq, head, n, c);
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb);
+  }
+  // ---- orientation B per key block: register i <-> (query 16qb + 4c+i, key 16kb + n): dK, dV
+#pragma unroll
+  for (int kb = 0; kb < NK; ++kb) {
     f32x4_t dv[4], dk[4];
-    attn_mm_rows(dv, pd, gg);                                  // dV[j][d] = sum_q Pd[q][j] dO[q][d]
-    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c);
-    attn_mm_rows(dk, ds, qg);                                  // dK[j][d] = sum_q dS[q][j] Q[q][d]
-    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c);
+    attn_zero(dv); attn_zero(dk);
+    const int key = 16 * kb + n;
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+      if constexpr (NQ > 1) {
+        attn_load_r(qr, p.q, p.ld_q, p, g, L, Tq, head, n, c, qb);
+        attn_load_r(gr, p.go, p.ld_o, p, g, L, Tq, head, n, c, qb);
+      }
+      AttnTileG gg, qg;
+      attn_load_g(gg, p.go, p.ld_o, p, g, L, Tq, head, n, c, qb);
+      attn_load_g(qg, p.q, p.ld_q, p, g, L, Tq, head, n, c, qb);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4_t sb = attn_mm_d(qr, kr[kb]), db = attn_mm_d(gr, vr[kb]);
+      float pd[4], ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ql = 4 * c + i, q = 16 * qb + ql;             // statistics of query q live in lane ql of block qb
+        const float mxq = __shfl(mxs[qb], ql, 64), invq = __shfl(invs[qb], ql, 64), rsq = __shfl(rss[qb], ql, 64);
+        const bool dead = key >= S || q >= L || (p.mask_mode == 1 && key == S - 1 && q < L - 1);
+        const float pr = dead ? 0.f : __expf(sb[i] * p.scale - mxq) * invq;
+        float m = 1.f;
+        if (p.drop_thresh && !dead)
+          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + key, p.drop_thresh, p.drop_inv_keep);
+        pd[i] = pr * m;
+        ds[i] = pr * (db[i] * m - rsq) * p.scale;
+      }
+      attn_mm_rows(dv, pd, gg);                                  // dV[j][d] += sum_q Pd[q][j] dO[q][d]
+      attn_mm_rows(dk, ds, qg);                                  // dK[j][d] += sum_q dS[q][j] Q[q][d]
+    }
+    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb);
+    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb);
   }
 }
 
@@ -545,9 +597,14 @@ extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, lon
   const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
   const int L = p.L > p.S ? p.L : p.S;
   static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;       // keep the LDS kernels reachable for A/B runs
-  if (L <= 16 && !use_lds)
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)((p.total + 3) / 4)), dim3(256), 0, stream, p);
-  else if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
+  const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
+  if (!use_lds) {
+    if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+    else if (nq == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+    else if (nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
+  } else if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -570,9 +627,14 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
   const int L = p.L > p.S ? p.L : p.S;
   static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;
-  if (L <= 16 && !use_lds)
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)((p.total + 3) / 4)), dim3(256), 0, stream, p);
-  else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
+  const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
+  if (!use_lds) {
+    if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+    else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
+    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
+  } else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;

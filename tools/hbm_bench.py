@@ -66,3 +66,12 @@ cfg_t = AttnCfg(1, F_ // T_, 64, 8, 0, T_, T_, 8, 1, 0.1)
 report("attention temporal fwd (T=10, masked)", 4 * nx, timeit(lambda: ops.attn_packed(qk.detach(), vv.detach(), cfg_t)))
 yt = ops.attn_packed(qk, vv, cfg_t)
 report("attention temporal bwd (T=10, masked)", 7 * nx, timeit(lambda: torch.autograd.grad(yt, [qk, vv], ga, retain_graph=True)))
+T2_ = 28
+F2 = (F_ // T2_) * T2_ if F_ >= T2_ else T2_
+R2 = F2 * 64
+qk2 = torch.randn(R2, 2 * C, device=dev, requires_grad=True); vv2 = torch.randn(R2, C, device=dev, requires_grad=True)
+cfg_t2 = AttnCfg(1, F2 // T2_, 64, 8, 0, T2_, T2_, 8, 0, 0.1)
+nx2 = R2 * C * 4
+report("attention temporal fwd (T=28)", 4 * nx2, timeit(lambda: ops.attn_packed(qk2.detach(), vv2.detach(), cfg_t2)))
+yt2 = ops.attn_packed(qk2, vv2, cfg_t2); ga2 = torch.randn_like(yt2)
+report("attention temporal bwd (T=28)", 7 * nx2, timeit(lambda: torch.autograd.grad(yt2, [qk2, vv2], ga2, retain_graph=True)))
