@@ -159,6 +159,35 @@ def test_optimizer_state_is_torch_adamw_format(impl, tmp_path):
     assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and torch.equal(opt2.flat_p, opt.flat_p)
 
 
+def test_graphed_step_equals_eager(impl):
+    """GraphedTrainStep (the whole optimisation step captured into a HIP graph, gradient stream included) replays to the
+    same parameters as the eager step; the dropout seed, lr and step count live in device memory."""
+    past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
+    runs = {}
+    for graphed in (False, True):
+        m = GC._small_predictor(impl, False, 181, DEV, evt_layers=1, dec_layers=2, dropout=0.1, drop_path=0.1)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        impl.ops.rng.manual_seed(77, torch.device(DEV))
+        if graphed:
+            step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1)
+            # the warm-up and the capture executed steps of their own: rewind to the same starting point
+            O.key_hashed_fill(m, 181)
+            opt.m.zero_(); opt.v.zero_(); opt.hyper[1:2].zero_()
+            impl.ops.rng.manual_seed(77, torch.device(DEV))
+            for _ in range(3):
+                out = step(past, fut, lr=1e-4)
+        else:
+            for _ in range(3):
+                out = impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0, sync=False)
+        torch.cuda.synchronize()
+        runs[graphed] = (opt.flat_p.clone(), float(out["loss"]))
+    (pe, le), (pg, lg) = runs[False], runs[True]
+    assert abs(le - lg) <= 1e-5 * abs(le), (le, lg)
+    err = float((pe - pg).norm() / pe.norm())
+    assert err < 1e-6, f"graph replay vs eager parameters after 3 steps: rel-L2 {err:.3e}"
+
+
 def test_predictor_full_depth(impl):
     GC.compare(GC.case_predictor_full(impl, DEV), GC.load("predictor_full_D"), TOL, tag=f"predictor_full[{MODE}]")
 
