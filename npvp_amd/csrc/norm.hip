@@ -298,14 +298,19 @@ __global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out) {
 }
 
 // dy_ln = dout * scale * gelu'(y);  g = dy_ln * w;  s1 = mean(g), s2 = mean(g*hhat)
+constexpr int FLN_PARTS = 4;     // blocks per frame in the backward statistics pass
 __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p, const float* __restrict__ dout,
-                                                                    float* __restrict__ s1o, float* __restrict__ s2o) {
+                                                                    float* __restrict__ psum) {
+  // grid (frames, FLN_PARTS): one block per frame left 64 of the 256 CUs with two 1-MB streams and the rest with one
+  // (320 frames at c1) at 8 waves per CU; a quarter frame per block balances the device and lets the GELU' / dropout-hash
+  // VALU work overlap the loads.  psum[f][part] = (sum g, sum g*hhat), summed in fixed order by the consumer.
   __shared__ float red[8];
   const long long f = blockIdx.x;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
   const float mu = p.mean[f], rs = p.rstd[f];
   float s1 = 0.f, s2 = 0.f;
-  for (int e = threadIdx.x * 4; e < p.per_frame; e += 512 * 4) {
+  const int span = p.per_frame / FLN_PARTS, e0 = blockIdx.y * span, e1 = blockIdx.y == FLN_PARTS - 1 ? p.per_frame : e0 + span;
+  for (int e = e0 + threadIdx.x * 4; e < e1; e += 512 * 4) {
     const long long g0 = f * p.per_frame + e;
     const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
@@ -316,40 +321,18 @@ __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p,
     s1 += gx + gy + gz + gw;
     s2 += gx * hx + gy * hy + gz * hz + gw * hw;
   }
-  s1 = block_sum<8>(s1, red) / p.per_frame;
-  s2 = block_sum<8>(s2, red) / p.per_frame;
-  if (threadIdx.x == 0) { s1o[f] = s1; s2o[f] = s2; }
-}
-
-__global__ void frameln_act_bwd_apply_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ s1,
-                                             const float* __restrict__ s2, float* __restrict__ dh) {
-  const int pf4 = p.per_frame / 4;
-  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.total4; i += (long long)gridDim.x * blockDim.x) {
-    const long long f = i / pf4;
-    const int e = (int)(i - f * pf4) * 4;
-    const long long g0 = f * p.per_frame + e;
-    const float mu = p.mean[f], rs = p.rstd[f], a1 = s1[f], a2 = s2[f];
-    const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e), d = ld4(dout + g0);
-    const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
-    const float gx = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x) * ww.x;
-    const float gy = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y) * ww.y;
-    const float gz = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z) * ww.z;
-    const float gw = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w) * ww.w;
-    float4 o;
-    o.x = rs * (gx - a1 - hx * a2); o.y = rs * (gy - a1 - hy * a2);
-    o.z = rs * (gz - a1 - hz * a2); o.w = rs * (gw - a1 - hw * a2);
-    st4(dh + g0, o);
-  }
+  s1 = block_sum<8>(s1, red);
+  s2 = block_sum<8>(s2, red);
+  if (threadIdx.x == 0) { psum[(f * FLN_PARTS + blockIdx.y) * 2] = s1; psum[(f * FLN_PARTS + blockIdx.y) * 2 + 1] = s2; }
 }
 
 // One pass for BOTH the input gradient and the parameter gradients: thread = 4 consecutive elements e of the frame,
 // loop over the frames of a chunk:  dh[f][e] = rstd (g - s1[f] - hhat s2[f]),  dw[e] += dy_ln*hhat,  db[e] += dy_ln.
 // grid.x covers e (float4), grid.y = frame chunks whose partial sums go to part[chunk][2][per_frame]
 // (summed by sum_rows_kernel).  Saves the separate apply pass of the first version (a full re-read of dout and h).
-__global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ s1,
-                                             const float* __restrict__ s2, float* __restrict__ dh,
-                                             float* __restrict__ part, int frames, int frames_per_chunk) {
+__global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ psum,
+                                             float* __restrict__ dh, float* __restrict__ part, int frames,
+                                             int frames_per_chunk) {
   const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e >= p.per_frame) return;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
@@ -359,7 +342,11 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
   const int f1 = min(frames, f0 + frames_per_chunk);
   for (long long f = f0; f < f1; ++f) {
     const long long g0 = f * p.per_frame + e;
-    const float mu = p.mean[f], rs = p.rstd[f], a1 = s1[f], a2 = s2[f];
+    const float mu = p.mean[f], rs = p.rstd[f];
+    float a1 = 0.f, a2 = 0.f;              // s1 = mean(g), s2 = mean(g*hhat) from the FLN_PARTS partial sums, fixed order
+#pragma unroll
+    for (int j = 0; j < FLN_PARTS; ++j) { a1 += psum[(f * FLN_PARTS + j) * 2]; a2 += psum[(f * FLN_PARTS + j) * 2 + 1]; }
+    a1 /= p.per_frame; a2 /= p.per_frame;
     const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
     const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
@@ -529,7 +516,7 @@ extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const flo
 static int fln_chunks(int frames) { return frames < 32 ? frames : 32; }
 
 extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
-  return ((long long)frames * 2 + (long long)fln_chunks(frames) * 2 * per_frame) * 4;
+  return ((long long)frames * 2 * FLN_PARTS + (long long)fln_chunks(frames) * 2 * per_frame) * 4;
 }
 
 // dh [frames, per_frame]; dw, db [per_frame]
@@ -543,13 +530,14 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
                  "frameln_act_bwd: workspace too small");
   FlnParams p;
   fill_fln(p, h, mean, rstd, w, b, nullptr, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
-  float* s1 = (float*)workspace; float* s2 = s1 + frames; float* part = s2 + frames;
-  hipLaunchKernelGGL(frameln_act_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, p, dout, s1, s2);
+  NPVP_CHECK_ARG(per_frame % (4 * FLN_PARTS) == 0, "frameln_act_bwd: per_frame must be a multiple of 16");
+  float* psum = (float*)workspace; float* part = psum + (long long)frames * 2 * FLN_PARTS;
+  hipLaunchKernelGGL(frameln_act_bwd_stats_kernel, dim3(frames, FLN_PARTS), dim3(512), 0, stream, p, dout, psum);
   NPVP_CHECK_LAUNCH();
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
-                     dout, (const float*)s1, (const float*)s2, dh, part, frames, fpc);
+                     dout, (const float*)psum, dh, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
@@ -563,7 +551,7 @@ extern "C" int npvp_frameln_act_bwd_reduce(const void* workspace, float* dw, flo
                                            int accumulate, hipStream_t stream) {
   NPVP_CHECK_ARG(workspace && dw && db && frames > 0, "frameln_act_bwd_reduce: bad arguments");
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
-  const float* part = (const float*)workspace + 2 * (long long)frames;
+  const float* part = (const float*)workspace + 2 * FLN_PARTS * (long long)frames;
   if (launch_sum_rows(part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate ? 1 : 0, db, per_frame)) {
     npvp_set_error("frameln_act_bwd_reduce: launch failed");
     return NPVP_ERR_LAUNCH;
