@@ -120,20 +120,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // out[c] = sum_b in[b*stride + c]   (second stage of the column reductions).  A block owns 64 columns and
 // splits the nb partial rows over blockDim/64 row lanes (coalesced 256-B segments, LDS tree at the end).
+template <int CW>     // columns per block: 64 (wide outputs) or 16 (few columns, many partial rows: more blocks, more row lanes)
 __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int nb,
                                                         int stride, int ncols, int accum, float* __restrict__ out_b,
                                                         int split) {
-  __shared__ float red[16][64];
-  const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6, nrl = blockDim.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ float red[1024];
+  const int cx = threadIdx.x % CW, rl = threadIdx.x / CW, nrl = blockDim.x / CW;
+  const int c = blockIdx.x * CW + cx;
   float s = 0.f;
   if (c < ncols)
     for (int b = rl; b < nb; b += nrl) s += in[(long long)b * stride + c];
-  red[rl][cx] = s;
+  red[rl * CW + cx] = s;
   __syncthreads();
   if (rl == 0 && c < ncols) {
     float t = 0.f;
-    for (int i = 0; i < nrl; ++i) t += red[i][cx];
+    for (int i = 0; i < nrl; ++i) t += red[i * CW + cx];
     float* o = (out_b && c >= split) ? out_b + (c - split) : out + c;
     *o = accum ? *o + t : t;
   }
@@ -367,10 +368,14 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
 
 int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream, int accum, float* out_b,
                     int split) {
-  // few partial rows (frame-LN params: 32 x 131072) -> 4 row lanes; many (bias / LN column sums) -> 16
-  const int threads = nb >= 64 ? 1024 : 256;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((ncols + 63) / 64), dim3(threads), 0, stream, in, out, nb, stride, ncols,
-                     accum, out_b, split);
+  // few partial rows (frame-LN params: 32 x 262144) -> 4 row lanes of 64 columns; many partial rows over few columns
+  // (bias / LayerNorm / split-K column sums: 512 x 1024) -> 16-column blocks with 64 row lanes: 4x the blocks
+  if (nb >= 64 && ncols <= 8192)
+    hipLaunchKernelGGL(sum_rows_kernel<16>, dim3((ncols + 15) / 16), dim3(1024), 0, stream, in, out, nb, stride, ncols, accum,
+                       out_b, split);
+  else
+    hipLaunchKernelGGL(sum_rows_kernel<64>, dim3((ncols + 63) / 64), dim3(nb >= 64 ? 1024 : 256), 0, stream, in, out, nb, stride,
+                       ncols, accum, out_b, split);
   return hipGetLastError() == hipSuccess ? NPVP_OK : NPVP_ERR_LAUNCH;
 }
 
