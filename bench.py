@@ -151,7 +151,7 @@ def main():
     if args.flavour == "full":
         D = cfg["Dataset"]
         enc, dec = npvp_amd.build_frozen_autoencoder(cfg["AE"], D["img_channels"])
-        enc, dec = enc.to(dev), dec.to(dev)
+        enc, dec = npvp_amd.to_device_layout(enc, dec, dev)
         S = D["img_size"]
         past_px = torch.rand(B, To, D["img_channels"], S, S, generator=g).to(dev)
         fut_px = torch.rand(B, Tp, D["img_channels"], S, S, generator=g).to(dev)

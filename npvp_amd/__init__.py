@@ -7,7 +7,7 @@ anywhere, but calling an op without the built library or without a GPU raises - 
 """
 from .models import (Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, VidHRFormerBlockEnc, VidHRFormerBlockDecNAR,
                      SpatialLocalMultiheadAttention, MlpDWBN, MultiheadAttention, CoorGenerator, NRMLP, PosFeatFuser,
-                     EventEncoder, L1Loss, Div_KL, DropPath, ResnetEncoder, ResnetDecoder, build_frozen_autoencoder)
+                     EventEncoder, L1Loss, Div_KL, DropPath, ResnetEncoder, ResnetDecoder, build_frozen_autoencoder, to_device_layout)
 from .trainer import (FlatAdamW, predictor_train_step, full_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg,
                       context_lists, rand_context_collate, rand_context_batch_process, vfi_batch_process,
                       save_lightning_checkpoint, load_lightning_checkpoint, GraphedTrainStep)
@@ -15,7 +15,7 @@ from . import ops
 
 __all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
            "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
-           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "FlatAdamW", "predictor_train_step", "full_train_step", "context_lists",
+           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "to_device_layout", "FlatAdamW", "predictor_train_step", "full_train_step", "context_lists",
            "rand_context_collate", "rand_context_batch_process", "vfi_batch_process",
            "save_lightning_checkpoint", "load_lightning_checkpoint", "GraphedTrainStep",
            "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops"]

@@ -4,4 +4,4 @@ from .VidHRFormer import (VidHRformerDecoderNAR, VidHRFormerEncoder, VidHRFormer
                           SpatialLocalMultiheadAttention, MlpDWBN, MultiheadAttention, DropPath)
 from .submodules import CoorGenerator, NRMLP, PosFeatFuser, EventEncoder
 from .Predictor import Predictor
-from .ResNetAutoEncoder import ResnetEncoder, ResnetDecoder, ResnetBlock, Factorized3DConvAttn, NonLocalAttenion2D, build_frozen_autoencoder
+from .ResNetAutoEncoder import ResnetEncoder, ResnetDecoder, ResnetBlock, Factorized3DConvAttn, NonLocalAttenion2D, build_frozen_autoencoder, to_device_layout

@@ -866,6 +866,15 @@ def im2col3x3(x, frames, H, W):
 
 
 def nchw_to_canonical(x):
+    """(N,T,C,H,W) -> canonical [N*T, H*W, C].  A channels-last feature tensor (what the frozen encoder emits when it
+    runs in torch.channels_last) already IS the canonical layout: it is viewed, not transposed."""
+    if x.dim() == 5 and x.permute(0, 1, 3, 4, 2).is_contiguous() and not x.requires_grad:
+        N, T, C, H, W = x.shape
+        return x.permute(0, 1, 3, 4, 2).reshape(N * T, H * W, C)
+    return _nchw_to_canonical(x)
+
+
+def _nchw_to_canonical(x):
     """(N,T,C,H,W) -> canonical [N*T, H*W, C]"""
     N, T, C, H, W = x.shape
     return _Transpose.apply(x.reshape(N * T, C, H * W))

@@ -273,14 +273,15 @@ def case_ae(impl, dev, tag="64"):
     return dict(feats=feats, frames=y, g_feats=f.grad)
 
 
-def case_full_step(pred_impl, ae_impl, dev, make_opt=None):
+def case_full_step(pred_impl, ae_impl, dev, make_opt=None, device_layout=None):
     """One complete Stage-2 step from pixels: frozen enc -> predictor -> frozen dec -> L1(img) + 0.01 L1(feat) + KL."""
     N, To, Tp = 2, 3, 4
     m = _small_predictor(pred_impl, True, 131, dev)
     enc = ae_impl.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
     dec = ae_impl.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
     O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122)
-    enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+    enc, dec = (enc.to(dev), dec.to(dev)) if device_layout is None else device_layout(enc, dec, dev)
+    enc, dec = enc.eval(), dec.eval()
     for q in list(enc.parameters()) + list(dec.parameters()):
         q.requires_grad_(False)
     g_ = torch.Generator().manual_seed(133)

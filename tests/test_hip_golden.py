@@ -92,9 +92,13 @@ def test_frozen_autoencoder(impl, tag):
     GC.compare({"g_feats": g_res}, {"g_feats": g_gold}, 5e-3, tag=f"ae_{tag}.g_feats[{MODE}]")
 
 
-def test_full_step_from_pixels(impl):
+@pytest.mark.parametrize("layout", ["nchw", "encoder_channels_last"])
+def test_full_step_from_pixels(impl, layout):
+    """layout = encoder_channels_last: the frozen encoder runs NHWC and hands the predictor its canonical layout directly"""
     mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
-    GC.compare(GC.case_full_step(impl, impl, DEV, make_opt=mk), GC.load("train_step_full_S"), TOL, tag=f"full_step[{MODE}]")
+    dl = impl.to_device_layout if layout == "encoder_channels_last" else None
+    GC.compare(GC.case_full_step(impl, impl, DEV, make_opt=mk, device_layout=dl), GC.load("train_step_full_S"), TOL,
+               tag=f"full_step[{MODE},{layout}]")
 
 
 def test_grad_sink_matches_autograd_accumulation(impl):
