@@ -33,7 +33,7 @@ class FlatBuffers:
         total = sum(pad(p.numel()) for p in ordered)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.params, self.offsets = ordered, []
+        self.params, self.offsets, self.views = ordered, [], []
         off, tail_begin = 0, None
         with torch.no_grad():
             for p in ordered:
@@ -43,6 +43,7 @@ class FlatBuffers:
                 self.flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                self.views.append(p.grad)
                 p.__dict__["_npvp_flat"] = True          # ops.GradSink may accumulate into p.grad in place
                 self.offsets.append((off, n))
                 off += pad(n)
@@ -52,9 +53,25 @@ class FlatBuffers:
 
     def zero_grad(self):
         self.flat_g.zero_()
-        for p, (off, n) in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
-                p.grad = self.flat_g[off:off + n].view(p.shape)
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def gather_stray_grads(self):
+        """A caller that clears gradients with `module.zero_grad()` (set_to_none, as LitPredictor does, ref
+        Predictor.py:126) detaches .grad from the flat buffer: autograd then allocates fresh gradient tensors.  Before
+        the optimiser reads the flat buffer, copy such gradients into their slices (None -> zeros) and re-attach the
+        views.  One identity check per parameter when nothing strayed."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is v:
+                continue
+            with torch.no_grad():
+                if g is None:
+                    v.zero_()
+                else:
+                    v.copy_(g)
+            p.grad = v
 
 
 class FlatAdamW:
@@ -90,6 +107,7 @@ class FlatAdamW:
 
     def step(self):
         ops.WgradStream.join()               # no-op after a finished backward pass (the engine callback joined already)
+        self.buf.gather_stray_grads()
         L, P = lib(), ops._p
         s = P(torch.cuda.current_stream().cuda_stream)
         self.hyper[1:2].add_(1.0)

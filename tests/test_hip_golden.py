@@ -163,6 +163,31 @@ def test_optimizer_state_is_torch_adamw_format(impl, tmp_path):
     assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and torch.equal(opt2.flat_p, opt.flat_p)
 
 
+def test_module_zero_grad_set_to_none_flow(impl):
+    """LitPredictor clears gradients with predictor.zero_grad() (ref Predictor.py:126; set_to_none in current torch),
+    which detaches .grad from the flat buffer.  FlatAdamW.step() must still see the gradients: same update as the
+    trainer's own flow."""
+    past = O.synth_features((2, 3, 512, 8, 8), 192).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 193).to(DEV)
+    res = {}
+    for flow in ("flat", "set_to_none"):
+        m = GC._small_predictor(impl, False, 191, DEV, evt_layers=1, dec_layers=1)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        for _ in range(2):
+            if flow == "flat":
+                opt.zero_grad()
+            else:
+                m.zero_grad(set_to_none=True)
+            loss = impl.L1Loss(lam=0.01)(m(past), fut)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        res[flow] = opt.flat_p.clone()
+        assert all(p_.grad is v_ for p_, v_ in zip(opt.buf.params, opt.buf.views))
+    err = float((res["flat"] - res["set_to_none"]).norm() / res["flat"].norm())
+    assert err < 1e-6, f"set_to_none flow vs flat flow: rel-L2 {err:.3e}"
+
+
 def test_graphed_step_equals_eager(impl):
     """GraphedTrainStep (the whole optimisation step captured into a HIP graph, gradient stream included) replays to the
     same parameters as the eager step; the dropout seed, lr and step count live in device memory."""
