@@ -518,7 +518,7 @@ extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const flo
   return NPVP_OK;
 }
 
-static int fln_chunks(int frames) { return frames < 32 ? frames : 32; }
+static int fln_chunks(int frames) { return frames < 8 ? frames : 8; }
 
 extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
   return ((long long)frames * 2 * FLN_PARTS + (long long)fln_chunks(frames) * 2 * per_frame) * 4;
