@@ -191,15 +191,27 @@ class GradSink:
         if not cls.enabled or t is None or not t.requires_grad:
             return None
         base = t if t.is_leaf else t._base
-        if base is None or not base.is_leaf or not base.__dict__.get("_npvp_flat", False):
+        if base is None or not base.is_leaf:
+            return None
+        d = base.__dict__
+        if not d.get("_npvp_flat", False):
             return None
         g = base.grad
-        if g is None or not t.is_contiguous() or not g.is_contiguous():
+        if g is None or not t.is_contiguous():
             return None
+        # the slot of a given (offset, shape) view never changes while .grad is the same flat-buffer view: cache it on
+        # the parameter (this runs ~750 times per step)
         off = t.storage_offset() - base.storage_offset()
-        if off < 0 or off + t.numel() > g.numel():
-            return None
-        return g.view(-1)[off:off + t.numel()].view(t.shape), base
+        key = (off, t.shape)
+        cache = d.get("_npvp_slots")
+        if cache is None or cache[0] is not g:
+            cache = d["_npvp_slots"] = (g, {})
+        hit = cache[1].get(key)
+        if hit is None:
+            if not g.is_contiguous() or off < 0 or off + t.numel() > g.numel():
+                return None
+            hit = cache[1][key] = (g.view(-1)[off:off + t.numel()].view(t.shape), base)
+        return hit
 
     @classmethod
     def wrote(cls, *slots):
