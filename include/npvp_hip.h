@@ -113,6 +113,10 @@ int npvp_frameln_act_bwd_reduce(const void* workspace, float* dw, float* db, int
  * input gradient.  wgrad writes one contiguous [10][Ch] buffer: 9 taps then the bias gradient. */
 int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* out, int frames, int H, int W, int Ch,
                    int flip, npvp_stream_t stream);
+/* the same forward convolution, also returning the frame-LayerNorm statistics (mean, rstd over H*W*Ch per frame) of its
+ * output, so that MlpDWBN's norm2 needs no statistics pass (8x8 grid, Ch % 1024 == 0; workspace >= frames*Ch/1024*8 B) */
+int npvp_dwconv3x3_stats(const float* a, const float* wt, const float* bias, float* out, float* mean, float* rstd, int frames,
+                         int H, int W, int Ch, float eps, void* workspace, long long ws_bytes, npvp_stream_t stream);
 /* im2col / col2im of the EventEncoder's dense 3x3 conv (ref/models/submodules.py:376), channels-last:
  * col2im=0: in [F][H*W][C] -> out [F*H*W][9*C] (tap-major columns); col2im=1: the adjoint. */
 int npvp_im2col3x3(const float* in, float* out, int frames, int H, int W, int C, int col2im, npvp_stream_t stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "npvp_frameln_act_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
                                      c_p, c_int, c_p, c_ll, c_p]),
     "npvp_dwconv3x3": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+    "npvp_dwconv3x3_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_ll, c_p]),
     "npvp_im2col3x3": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_wgrad_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_dwconv3x3_wgrad": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),

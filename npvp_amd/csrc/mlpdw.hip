@@ -41,12 +41,18 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ a, const float* __res
 // 9 weight loads per output float4 - it is bound by the L1/TA request rate (2.3 TB/s effective), not by HBM.  Here a
 // thread owns one (frame, 4 channels) column and slides a 3-row window through registers: each input element is
 // loaded ONCE, the 9 taps stay in registers, lanes = consecutive channel quads (1 KB contiguous per pixel and wave).
-template <int HH, int WW>
+// STATS: the kernel also emits, per block, the (mean, M2) of its 256 threads x 256 outputs (Chan combination of per-thread
+// sums taken about the thread's first output) - with Ch % 1024 == 0 a block lies inside one frame, so the frame
+// LayerNorm that follows the convolution in MlpDWBN gets its statistics without a pass over the output
+// (frame_stats_finalize_kernel merges the Ch/1024 partials of a frame).
+template <int HH, int WW, bool STATS>
 __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restrict__ a, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int Ch, long long nthreads, int flip) {
+                                                            int Ch, long long nthreads, int flip, float* __restrict__ part) {
+  __shared__ float red[4];
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nthreads) return;
+  if (!STATS && i >= nthreads) return;          // (with STATS the grid is exact: frames * Ch/4 is a multiple of 256)
+  float shift = 0.f, s1 = 0.f, s2 = 0.f;
   const int c4n = Ch / 4;
   const int c = (int)(i % c4n) * 4;
   const long long f = i / c4n;
@@ -77,10 +83,37 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
         acc.z += w0.z * x0.z + w1.z * x1.z + w2.z * x2.z; acc.w += w0.w * x0.w + w1.w * x1.w + w2.w * x2.w;
       }
       st4(of + (long long)(h * WW + w) * Ch, acc);
+      if constexpr (STATS) {
+        if (h == 0 && w == 0) shift = acc.x;
+        const float a0 = acc.x - shift, a1 = acc.y - shift, a2 = acc.z - shift, a3 = acc.w - shift;
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
     }
 #pragma unroll
     for (int w = 0; w < WW; ++w) { r0[w] = r1[w]; r1[w] = r2[w]; }
   }
+  if constexpr (STATS) {
+    const float n = (float)(HH * WW * 4), m1 = s1 / n, mean_t = shift + m1, m2_t = s2 - s1 * m1;
+    const float mean_b = block_sum<4>(mean_t, red) / 256.f;
+    const float d = mean_t - mean_b;
+    const float m2_b = block_sum<4>(m2_t + n * d * d, red);
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = mean_b; part[blockIdx.x * 2 + 1] = m2_b; }
+  }
+}
+
+// per frame: J partials (mean_j, M2_j) over nb values each -> mean, rstd
+__global__ void frame_stats_finalize_kernel(const float* __restrict__ part, int J, float nb, float* __restrict__ mean,
+                                            float* __restrict__ rstd, int frames, float eps) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= frames) return;
+  float m = 0.f;
+  for (int j = 0; j < J; ++j) m += part[(f * J + j) * 2];
+  m /= J;
+  float m2 = 0.f;
+  for (int j = 0; j < J; ++j) { const float d = part[(f * J + j) * 2] - m; m2 += part[(f * J + j) * 2 + 1] + nb * d * d; }
+  mean[f] = m;
+  rstd[f] = rsqrtf(m2 / (nb * J) + eps);
 }
 
 // weight / bias gradient, same window: thread = (4 channels, frame chunk); per frame one load of a and of dout.
@@ -233,14 +266,32 @@ extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv: bad shape");
   if (H == 8 && W == 8) {
     const long long nthreads = (long long)frames * (Ch / 4);
-    hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a, wt,
-                       bias, out, Ch, nthreads, flip);
+    hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a,
+                       wt, bias, out, Ch, nthreads, flip, (float*)nullptr);
     NPVP_CHECK_LAUNCH();
     return NPVP_OK;
   }
   const long long total4 = (long long)frames * H * W * Ch / 4;
   long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// forward convolution that also returns the per-frame LayerNorm statistics (mean, rstd over the frame's H*W*Ch outputs)
+// of its result.  8x8 grid, Ch % 1024 == 0; workspace >= frames * (Ch/1024) * 8 bytes.
+extern "C" int npvp_dwconv3x3_stats(const float* a, const float* wt, const float* bias, float* out, float* mean, float* rstd,
+                                    int frames, int H, int W, int Ch, float eps, void* workspace, long long ws_bytes,
+                                    hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 1024 == 0, "dwconv_stats: needs an 8x8 grid and Ch % 1024 == 0");
+  const int J = Ch / 1024;
+  NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * J * 8, "dwconv_stats: workspace too small");
+  const long long nthreads = (long long)frames * (Ch / 4);
+  hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8, true>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, a, wt, bias, out,
+                     Ch, nthreads, 0, (float*)workspace);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
+                     65536.f, mean, rstd, frames, eps);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -769,16 +769,17 @@ class _FrameLnAct(torch.autograd.Function):
     """out = res + droppath_n(drop(GELU(LayerNorm((Ch,H,W))(h))))   (ref VidHRFormer.py:381-382,384-386,388-390)"""
 
     @staticmethod
-    def forward(ctx, h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample):
+    def forward(ctx, h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample, mean=None, rstd=None):
         _chk(h, w_cl, b_cl, res)
         h = _c(h)
         PF = h.numel() // frames
         w_cl, b_cl = _c(w_cl), _c(b_cl)
         res_c = None if res is None else _c(res)
         L = lib()
-        mean = torch.empty(frames, dtype=torch.float32, device=h.device)
-        rstd = torch.empty_like(mean)
-        check(L.npvp_frame_stats(_ptr(h), _p(0), _ptr(mean), _ptr(rstd), frames, 1, PF, 1e-5, _stream()), "npvp_frame_stats")
+        if mean is None:        # statistics not supplied by the producer of h (dwconv3x3(..., want_stats=True) emits them)
+            mean = torch.empty(frames, dtype=torch.float32, device=h.device)
+            rstd = torch.empty_like(mean)
+            check(L.npvp_frame_stats(_ptr(h), _p(0), _ptr(mean), _ptr(rstd), frames, 1, PF, 1e-5, _stream()), "npvp_frame_stats")
         d, dp = Drop(p_drop), Drop(p_dp, 1)
         out = torch.empty_like(h)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
@@ -810,30 +811,40 @@ class _FrameLnAct(torch.autograd.Function):
                                                                             _stream()), "npvp_frameln_act_bwd_reduce"), ws)
             GradSink.wrote(*sk)
             dw = db = None
-        return dh, dw, db, (dout if has_res else None), None, None, None, None
+        return dh, dw, db, (dout if has_res else None), None, None, None, None, None, None
 
 
-def frameln_act(h, w_cl, b_cl, res, frames, p_drop=0.0, p_dp=0.0, frames_per_sample=1):
-    return _FrameLnAct.apply(h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample)
+def frameln_act(h, w_cl, b_cl, res, frames, p_drop=0.0, p_dp=0.0, frames_per_sample=1, stats=None):
+    """stats = (mean, rstd) per frame when the producer of h already has them"""
+    mean, rstd = stats if stats is not None else (None, None)
+    return _FrameLnAct.apply(h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample, mean, rstd)
 
 
 class _DwConv(torch.autograd.Function):
     """Depthwise 3x3 on [F, H*W, Ch]; wtb = [10, Ch]: 9 tap-major weight rows + the bias row."""
 
     @staticmethod
-    def forward(ctx, a, wtb, frames, H, W):
+    def forward(ctx, a, wtb, frames, H, W, want_stats):
         _chk(a, wtb)
         a, wtb = _c(a), _c(wtb)
         Ch = wtb.shape[1]
         out = torch.empty_like(a)
-        check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), frames, H, W, Ch, 0, _stream()),
-              "npvp_dwconv3x3")
         ctx.save_for_backward(a, wtb)
         ctx.cfg = (frames, H, W, Ch)
+        if want_stats:
+            mean = torch.empty(frames, dtype=torch.float32, device=a.device)
+            rstd = torch.empty_like(mean)
+            ws, wsn = _ws(frames * (Ch // 1024) * 8, a.device)
+            check(lib().npvp_dwconv3x3_stats(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), _ptr(mean), _ptr(rstd), frames, H, W,
+                                             Ch, 1e-5, _ptr(ws), wsn, _stream()), "npvp_dwconv3x3_stats")
+            ctx.mark_non_differentiable(mean, rstd)
+            return out, mean, rstd
+        check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), frames, H, W, Ch, 0, _stream()),
+              "npvp_dwconv3x3")
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         a, wtb = ctx.saved_tensors
         frames, H, W, Ch = ctx.cfg
         dout = _c(dout)
@@ -844,11 +855,12 @@ class _DwConv(torch.autograd.Function):
         ws, wsn = _ws(L.npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), a.device)
         check(L.npvp_dwconv3x3_wgrad(_ptr(a), _ptr(dout), _ptr(dwtb), frames, H, W, Ch, _ptr(ws), wsn, _stream()),
               "npvp_dwconv3x3_wgrad")
-        return da, dwtb, None, None, None
+        return da, dwtb, None, None, None, None
 
 
-def dwconv3x3(a, wtb, frames, H, W):
-    return _DwConv.apply(a, wtb, frames, H, W)
+def dwconv3x3(a, wtb, frames, H, W, want_stats=False):
+    """want_stats (8x8 grid, Ch % 1024 == 0): returns (out, mean, rstd) - the frame-LayerNorm statistics of the output"""
+    return _DwConv.apply(a, wtb, frames, H, W, bool(want_stats))
 
 
 class _Im2Col(torch.autograd.Function):

@@ -230,6 +230,23 @@ def test_dwconv(K):
     close(gwtb[:9].t().reshape(Ch, 3, 3), rw, what="dw"); close(gwtb[9], rb, what="db")
 
 
+def test_dwconv_emits_frame_statistics(K):
+    """dwconv3x3(want_stats=True): same output and gradients, plus the frame-LayerNorm statistics of the output (what
+    MlpDWBN's norm2 consumes instead of a statistics pass), also for frames with a large common offset."""
+    F_, H, W, Ch = 5, 8, 8, 2048
+    a = (O.seeded_randn((F_, H * W, Ch), 65) + torch.arange(F_).view(F_, 1, 1) * 3.0).to(DEV).requires_grad_()
+    wtb = torch.cat([0.3 * O.seeded_randn((9, Ch), 66), 0.1 * O.seeded_randn((1, Ch), 67) + 5.0], 0).to(DEV).requires_grad_()
+    cot = O.seeded_randn((F_, H * W, Ch), 68).to(DEV)
+    y0 = K.dwconv3x3(a, wtb, F_, H, W)
+    y1, mean, rstd = K.dwconv3x3(a, wtb, F_, H, W, want_stats=True)
+    close(y1, y0, tol=1e-6, what="output")       # (two template instantiations: fma contraction may differ in the last bit)
+    flat = y1.detach().double().reshape(F_, -1)
+    close(mean, flat.mean(1).float(), tol=1e-6, what="mean")
+    close(rstd, (1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-5)).float(), tol=1e-6, what="rstd")
+    g0 = torch.autograd.grad((y0 * cot).sum(), [a, wtb]); g1 = torch.autograd.grad((y1 * cot).sum(), [a, wtb])
+    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1])
+
+
 # ------------------------------------------------------------------------------- attention cores
 def _attn_ref(q, k, v, rows_q, rows_k, mask):
     return O.attn_core(q, k, v, rows_q, rows_k, 8, mask)
