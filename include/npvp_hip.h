@@ -60,7 +60,13 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
-                  const void* b_pre, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                  const void* b_pre, int accumulate, float* rowstats, void* workspace, long long ws_bytes,
+                  npvp_stream_t stream);
+/* rowstats (nullable; default precision, a_kc = b_kc = 1, bias-only epilogue, M % 64 == 0, N % 128 == 0): receives
+ * [M/64][N/64][2] partial (mean, M2) statistics of the output per frame of 64 rows and block of 64 columns;
+ * npvp_frame_stats_finalize turns them into the frame LayerNorm's (mean, rstd): no statistics pass over C. */
+int npvp_frame_stats_finalize(const float* part, int parts_per_frame, float values_per_part, float* mean, float* rstd,
+                              int frames, float eps, npvp_stream_t stream);
 /* Weights change once per optimiser step but are staged by every tile of three GEMMs: split them ONCE into the bf16
  * term planes the split-precision kernel consumes (3 terms x N*K bf16 each, blocked like the LDS image).
  * F feeds y = x w^T (pass as b_pre with b_kc = 1), D feeds dx = dy w (b_pre with b_kc = 0).  b_pre is optional

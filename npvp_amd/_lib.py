@@ -17,7 +17,8 @@ SIGNATURES = {
     "npvp_stream_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
-                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_ll, c_p]),
+                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_p, c_ll, c_p]),
+    "npvp_frame_stats_finalize": (c_int, [c_p, c_int, c_f, c_p, c_p, c_int, c_f, c_p]),
     "npvp_split_weight": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p]),
     "npvp_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_f, c_int, c_p]),
     "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),

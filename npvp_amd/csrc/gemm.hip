@@ -36,6 +36,7 @@ struct GemmParams {
   const float* residual;   // [M][ldr] or null (added last)
   float* aux_out;          // [M][ldc] pre-activation copy (after bias) or null
   const float* aux_in;     // [M][ldc] for act 3/4 (activation gradients)
+  float* rowstats;         // frame-statistics partials of the output (see gemm_epilogue_rowstats), or null
   float* colsum;           // a_kc==0 only: colsum[z][m] = sum over this split's k of A[k][m] (bias gradient), or null
   const unsigned long long* seed;  // device seed for dropout or null
   long long lda, ldb, ldc, ldr;
@@ -147,6 +148,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
         Cz[idx] = v;
       }
     }
+  }
+}
+
+// Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
+// plus, per wave, the (mean, M2) of its 64 x 64 block of outputs.  Token rows come in frames of 64 and a wave's 64 rows
+// are exactly one frame (BM = 128, M % 64 == 0), so rowstats[frame][column block of 64] = (mean, M2) are the partials of
+// the frame statistics (merged by frame_stats_finalize): the LayerNorm needs no pass over C.  Sums are taken about the
+// lane's first value and combined across the wave in Chan's form; fixed order, deterministic.
+__device__ __forceinline__ void gemm_epilogue_rowstats(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
+                                                       const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm, int wn,
+                                                       int r, int h) {
+  // M % 64 == 0 and N % 128 == 0 (checked by the launcher): a wave's 64 x 64 block is either completely inside the
+  // matrix or completely outside it (the lower half of the last 128-row tile when M % 128 == 64)
+  if (m0 + wm * 64 >= p.M) return;
+  float shift = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
+      const int col = n0 + wn * 64 + tn * 32 + r;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        const float v = acc[g] * p.alpha + bv;
+        p.C[(long long)row * p.ldc + col] = v;
+        if (tm == 0 && tn == 0 && g == 0) shift = v;
+        const float d = v - shift;
+        s1 += d; s2 += d * d;
+      }
+    }
+  }
+  const float n = 64.f, m1 = s1 / n, mean_l = shift + m1, m2_l = s2 - s1 * m1;       // this lane's 64 values
+  const float mean_w = wave_sum(mean_l) * (1.f / 64.f);
+  const float dl = mean_l - mean_w;
+  const float m2_w = wave_sum(m2_l + n * dl * dl);
+  if ((threadIdx.x & 63) == 0) {
+    const long long frame = (m0 + wm * 64) >> 6;
+    const int cb = (n0 >> 6) + wn, ncb = p.N >> 6;
+    p.rowstats[(frame * ncb + cb) * 2] = mean_w;
+    p.rowstats[(frame * ncb + cb) * 2 + 1] = m2_w;
   }
 }
 
@@ -651,7 +694,7 @@ __global__ void split_weight_dgrad_kernel(const float* __restrict__ w, long long
   }
 }
 
-template <int NS, bool AKC, bool BKC, bool BPRE>
+template <int NS, bool AKC, bool BKC, bool BPRE, bool ROWSTATS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmParams p) {
   constexpr int STAGE = 2 * NS * OPER16;                      // [A term 0..NS-1 | B term 0..NS-1]
   constexpr int BK16 = 16;
@@ -730,7 +773,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
-  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+  if constexpr (ROWSTATS) gemm_epilogue_rowstats(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h);
+  else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -942,8 +986,8 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              long long ldb, float* C, long long ldc, const float* bias, int act, const float* aux_in,
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
-                             int precision, float* colsum_a, const void* b_pre, int accumulate, void* workspace,
-                             long long ws_bytes, hipStream_t stream) {
+                             int precision, float* colsum_a, const void* b_pre, int accumulate, float* rowstats,
+                             void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
   precision &= 0xff;
@@ -972,6 +1016,10 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (splits > 1 && (!plain || ws_bytes < npvp_gemm_workspace_bytes(M, N, K) || !workspace || (N % 4) != 0)) splits = 1;
   p.splits = splits;
   p.colsum = colsum_a;
+  p.rowstats = rowstats;
+  NPVP_CHECK_ARG(!rowstats || (precision == 4 && a_kc && b_kc && M % 64 == 0 && N % 128 == 0 && act == 0 && !aux_out && !residual &&
+                               drop_p == 0.f && !accumulate),
+                 "gemm: rowstats needs the default (bf16x6db) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");
   p.accum = accumulate ? 1 : 0;
   p.dbg = dbg;
   // pre-split B planes are only consumed by the db bf16x6 kernel with a row-major A and an unsplit reduction
@@ -1006,7 +1054,8 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
   } else if (precision == 4) {
-    if (b_pre && a_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
+    if (rowstats) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false, true>), grid, block, 0, stream, p);
+    else if (b_pre && a_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
     else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);

@@ -278,6 +278,15 @@ extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias
   return NPVP_OK;
 }
 
+extern "C" int npvp_frame_stats_finalize(const float* part, int parts_per_frame, float values_per_part, float* mean,
+                                         float* rstd, int frames, float eps, hipStream_t stream) {
+  NPVP_CHECK_ARG(part && mean && rstd && frames > 0 && parts_per_frame > 0, "frame_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, part, parts_per_frame,
+                     values_per_part, mean, rstd, frames, eps);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
 // forward convolution that also returns the per-frame LayerNorm statistics (mean, rstd over the frame's H*W*Ch outputs)
 // of its result.  8x8 grid, Ch % 1024 == 0; workspace >= frames * (Ch/1024) * 8 bytes.
 extern "C" int npvp_dwconv3x3_stats(const float* a, const float* wt, const float* bias, float* out, float* mean, float* rstd,

@@ -162,8 +162,13 @@ class MlpDWBN(nn.Module):
         F_, R = N * T, N * T * H * W
         pd = self.drop.p if self.training else 0.0
         hid = self.fc1.out_channels
-        h = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias)
-        a = ops.frameln_act(h, self.norm1.weight, self.norm1.bias, None, F_)
+        # fc1 / the depthwise conv / fc2 hand the frame LayerNorm that follows them its statistics (no pass over h)
+        if ops.linear_frame_stats_supported(R, hid) and H * W == 64:
+            h, m1, r1 = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias, frame_stats=True)
+            a = ops.frameln_act(h, self.norm1.weight, self.norm1.bias, None, F_, stats=(m1, r1))
+        else:
+            h = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias)
+            a = ops.frameln_act(h, self.norm1.weight, self.norm1.bias, None, F_)
         wtb = torch.cat([ops._Transpose.apply(self.dw3x3.weight.reshape(1, hid, 9)).reshape(9, hid),
                          self.dw3x3.bias.reshape(1, hid)], dim=0)
         if H == 8 and W == 8 and hid % 1024 == 0:      # the convolution hands norm2 its frame statistics
@@ -172,9 +177,14 @@ class MlpDWBN(nn.Module):
         else:
             h = ops.dwconv3x3(a, wtb, F_, H, W)
             a = ops.frameln_act(h, self.norm2.weight, self.norm2.bias, None, F_, pd)
-        h = ops.linear(a.reshape(R, hid), self.fc2.weight.flatten(1), self.fc2.bias)
+        st3 = None
+        if ops.linear_frame_stats_supported(R, self.out_features) and H * W == 64:
+            h, m3, r3 = ops.linear(a.reshape(R, hid), self.fc2.weight.flatten(1), self.fc2.bias, frame_stats=True)
+            st3 = (m3, r3)
+        else:
+            h = ops.linear(a.reshape(R, hid), self.fc2.weight.flatten(1), self.fc2.bias)
         out = ops.frameln_act(h, self.norm3.weight, self.norm3.bias,
-                              None if residual is None else residual.reshape(R, self.out_features), F_, pd, p_dp, T)
+                              None if residual is None else residual.reshape(R, self.out_features), F_, pd, p_dp, T, stats=st3)
         return out.view(N, T, H, W, self.out_features)
 
     def forward(self, x):

@@ -298,7 +298,7 @@ class WgradStream:
 
 # --------------------------------------------------------------------------- raw kernel wrappers
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False):
+         drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None):
     _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
     wsb = L.npvp_gemm_workspace_bytes(M, N, K)
@@ -315,7 +315,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
                           drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, GEMM_PRECISION, _ptr(colsum_a),
-                          _ptr(b_pre), int(accumulate), _ptr(ws), wsn, _stream()),
+                          _ptr(b_pre), int(accumulate), _ptr(rowstats), _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
@@ -323,13 +323,18 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     return out
 
 
-def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP):
-    """y[R,N] = epilogue(x[R,K] w[N,K]^T)"""
+def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP, rowstats=None):
+    """y[R,N] = epilogue(x[R,K] w[N,K]^T); rowstats [R/64, N/64, 2] receives the frame-statistics partials of y"""
     R, K = x.shape
     N = w.shape[0]
     y = torch.empty(R, N, dtype=torch.float32, device=x.device)
     return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual,
-                drop=drop, b_pre=WeightPlanes.get(w, "F") if R >= 1024 else None)
+                drop=drop, b_pre=WeightPlanes.get(w, "F") if (R >= 1024 and rowstats is None) else None, rowstats=rowstats)
+
+
+def linear_frame_stats_supported(R, N):
+    """the forward GEMM can emit the frame-LayerNorm statistics of its output (frames of 64 token rows)"""
+    return (GEMM_PRECISION & 0xff) == 4 and R % 64 == 0 and N % 128 == 0
 
 
 def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
@@ -581,7 +586,7 @@ class _Linear(torch.autograd.Function):
     and the dropout / drop-path that follows them in the reference fused into the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, drop):
+    def forward(ctx, x, w, b, residual, drop, frame_stats=False):
         _chk(x, w, b, residual)
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
@@ -589,14 +594,26 @@ class _Linear(torch.autograd.Function):
             x2 = x2.contiguous()
         w = w if (w.stride(1) == 1 and w.stride(0) % 4 == 0) else w.contiguous()
         r2 = None if residual is None else _c(residual).reshape(-1, w.shape[0])
-        y = linear_fwd(x2, w, b, residual=r2, drop=drop)
         ctx.save_for_backward(x2, w)
         ctx.drop, ctx.has_b, ctx.has_r, ctx.xshape = drop, b is not None, residual is not None, x.shape
         ctx.sink = _wb_sink(w, b)
+        if frame_stats:
+            # the GEMM's epilogue leaves per-(frame, 64-column block) partial statistics of y; a tiny kernel merges them
+            R, N = x2.shape[0], w.shape[0]
+            frames = R // 64
+            part = torch.empty(frames * (N // 64) * 2, dtype=torch.float32, device=x.device)
+            y = linear_fwd(x2, w, b, rowstats=part)
+            mean = torch.empty(frames, dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            check(lib().npvp_frame_stats_finalize(_ptr(part), N // 64, 4096.0, _ptr(mean), _ptr(rstd), frames, 1e-5, _stream()),
+                  "npvp_frame_stats_finalize")
+            ctx.mark_non_differentiable(mean, rstd)
+            return y.reshape(*x.shape[:-1], N), mean, rstd
+        y = linear_fwd(x2, w, b, residual=r2, drop=drop)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_stats_grads):
         x2, w = ctx.saved_tensors
         N = w.shape[0]
         dy2 = _c(dy).reshape(-1, N)
@@ -614,7 +631,7 @@ class _Linear(torch.autograd.Function):
         elif want_b:
             db = colsum(dz)
         dres = dy if ctx.has_r else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
 def _sunk_wgrad(dy, x, with_b, sk):
@@ -638,8 +655,12 @@ def _wb_sink(w, b):
     return (sw, sb) if sb is not None else None
 
 
-def linear(x, w, b=None, residual=None, drop=NO_DROP):
-    return _Linear.apply(x, w, b, residual, drop)
+def linear(x, w, b=None, residual=None, drop=NO_DROP, frame_stats=False):
+    """frame_stats=True (plain bias-only linear whose rows come in frames of 64): returns (y, mean, rstd), the statistics
+    a following frame LayerNorm needs, computed in the GEMM's epilogue"""
+    if frame_stats:
+        assert residual is None and not drop.on
+    return _Linear.apply(x, w, b, residual, drop, bool(frame_stats))
 
 
 class _FFN(torch.autograd.Function):

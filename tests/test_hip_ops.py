@@ -131,6 +131,27 @@ def test_gemm_f16x3_experimental():
         ops.GEMM_PRECISION = old
 
 
+def test_linear_emits_frame_statistics(K):
+    """linear(frame_stats=True): the forward GEMM's epilogue yields the frame-LayerNorm statistics of its output
+    (frames of 64 token rows) - what MlpDWBN's norm1 / norm3 consume instead of a statistics pass."""
+    from npvp_amd import ops
+    if not ops.linear_frame_stats_supported(320, 2048):
+        pytest.skip("row statistics ride on the default (bf16x6db) forward kernel")
+    for R, N, K_ in ((5 * 64, 2048, 512), (3 * 64, 512, 2048), (64, 128, 64)):      # odd frame counts: half-empty last tile
+        x = (O.seeded_randn((R, K_), 47) + 0.5).to(DEV).requires_grad_()
+        w = (O.seeded_randn((N, K_), 48) / math.sqrt(K_)).to(DEV).requires_grad_(); b = (O.seeded_randn((N,), 49) + 2.0).to(DEV).requires_grad_()
+        cot = O.seeded_randn((R, N), 50).to(DEV)
+        y0 = ops.linear(x, w, b)
+        y1, mean, rstd = ops.linear(x, w, b, frame_stats=True)
+        close(y1, y0, tol=1e-6, what="output")
+        fr = y1.detach().double().reshape(R // 64, -1)
+        close(mean, fr.mean(1).float(), tol=1e-6, what="mean")
+        close(rstd, (1.0 / torch.sqrt(fr.var(1, unbiased=False) + 1e-5)).float(), tol=2e-6, what="rstd")
+        g0 = torch.autograd.grad((y0 * cot).sum(), [x, w, b]); g1 = torch.autograd.grad((y1 * cot).sum(), [x, w, b])
+        for a_, b_ in zip(g0, g1):
+            assert torch.equal(a_, b_)
+
+
 def test_linear_autograd(K):
     x = O.seeded_randn((3, 64, 512), 11).requires_grad_(); w = (O.seeded_randn((256, 512), 12) / 22.0).requires_grad_()
     b = O.seeded_randn((256,), 13).requires_grad_(); r = O.seeded_randn((3, 64, 256), 14).requires_grad_()
