@@ -216,8 +216,11 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic_c1.json")
             if args.workload == "c1" and args.gemm == "bf16x6db" and args.flavour == "predictor" and os.path.exists(tj):
-                ent = json.load(open(tj)).get("pooled", {}).get("npvp::gemm_split_db_kernel<3, true, true, false>")
-                traffic = None if ent is None else round(ent["hbm_bytes_per_dispatch"])
+                # the forward GEMM kernel has two instantiations (plain epilogue / frame-statistics epilogue): pool them
+                ents = [v for k, v in json.load(open(tj)).get("pooled", {}).items()
+                        if k.startswith("npvp::gemm_split_db_kernel<3, true, true, false")]
+                nd = sum(e["dispatches"] for e in ents)
+                traffic = round(sum(e["hbm_bytes_per_dispatch"] * e["dispatches"] for e in ents) / nd) if nd else None
             roof = {"bound": "mfma", "kernel": KERNEL_NAME[args.gemm],
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,

@@ -608,6 +608,7 @@ class _Linear(torch.autograd.Function):
             check(lib().npvp_frame_stats_finalize(_ptr(part), N // 64, 4096.0, _ptr(mean), _ptr(rstd), frames, 1e-5, _stream()),
                   "npvp_frame_stats_finalize")
             ctx.mark_non_differentiable(mean, rstd)
+            ctx.set_materialize_grads(False)        # no zero-filled gradient tensors for the two statistics outputs
             return y.reshape(*x.shape[:-1], N), mean, rstd
         y = linear_fwd(x2, w, b, residual=r2, drop=drop)
         return y.reshape(*x.shape[:-1], w.shape[0])
@@ -859,6 +860,7 @@ class _DwConv(torch.autograd.Function):
             check(lib().npvp_dwconv3x3_stats(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), _ptr(mean), _ptr(rstd), frames, H, W,
                                              Ch, 1e-5, _ptr(ws), wsn, _stream()), "npvp_dwconv3x3_stats")
             ctx.mark_non_differentiable(mean, rstd)
+            ctx.set_materialize_grads(False)
             return out, mean, rstd
         check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), frames, H, W, Ch, 0, _stream()),
               "npvp_dwconv3x3")
