@@ -188,6 +188,25 @@ def test_module_zero_grad_set_to_none_flow(impl):
     assert err < 1e-6, f"set_to_none flow vs flat flow: rel-L2 {err:.3e}"
 
 
+def test_training_step_is_bitwise_deterministic(impl):
+    """Dropout active, gradient stream on: two identical runs give bit-identical parameters (every in-place gradient
+    write is serialised on one stream in program order, every reduction has a fixed order) - a race would show here."""
+    import hashlib
+    past = O.synth_features((2, 3, 512, 8, 8), 202).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 203).to(DEV)
+    digests = []
+    for _ in range(2):
+        m = GC._small_predictor(impl, True, 201, DEV, evt_layers=2, dec_layers=2, dropout=0.1, drop_path=0.1)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        impl.ops.rng.manual_seed(9, torch.device(DEV))
+        torch.manual_seed(3)                      # the NPVP-S reparameterisation noise comes from torch.randn
+        for _ in range(3):
+            impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0, sync=False)
+        torch.cuda.synchronize()
+        digests.append(hashlib.sha256(opt.flat_p.cpu().numpy().tobytes()).hexdigest())
+    assert digests[0] == digests[1]
+
+
 def test_graphed_step_equals_eager(impl):
     """GraphedTrainStep (the whole optimisation step captured into a HIP graph, gradient stream included) replays to the
     same parameters as the eager step; the dropout seed, lr and step count live in device memory."""
