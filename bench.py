@@ -238,7 +238,9 @@ def main():
         res = {"metric": "predictor train frames/sec", "value": round(frames / (ms * 1e-3), 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.gemm == "f32" else f"f32 ({args.gemm} split-precision MFMA, fp32 accumulate)",
+               "dtype": "f32" if args.gemm == "f32" else
+                        f"f32 ({args.gemm} split-precision MFMA, fp32 accumulate"
+                        + ("; weight-gradient GEMMs bf16x3db" if (args.gemm == "bf16x6db" and ops.WGRAD_PRECISION == 5) else "") + ")",
                "data": "synthetic",
                "config": {"workload": f"{name} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
                                                      else "FULL train step from pixels (frozen AE enc/dec in stock PyTorch-ROCm)")

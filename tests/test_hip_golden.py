@@ -188,6 +188,23 @@ def test_module_zero_grad_set_to_none_flow(impl):
     assert err < 1e-6, f"set_to_none flow vs flat flow: rel-L2 {err:.3e}"
 
 
+def test_six_term_weight_gradients(impl):
+    """NPVP_WGRAD=bf16x6 (six-term weight-gradient GEMMs, the non-default setting) against the reference's training-step
+    vectors; the default (two-term weight gradients) is what every other test in this file runs."""
+    from npvp_amd import ops
+    old = ops.WGRAD_PRECISION
+    ops.WGRAD_PRECISION = None
+    try:
+        mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        res = GC.case_train_step(impl, DEV, "S", make_opt=mk)
+        g = GC.load("train_step_S")
+        GC.compare({k: v for k, v in res.items() if k.endswith("_0")}, {k: v for k, v in g.items() if k.endswith("_0")}, TOL,
+                   tag=f"train_step_S_wgrad6[{MODE}]")
+        GC.compare({k: v for k, v in res.items() if k.endswith("_1")}, {k: v for k, v in g.items() if k.endswith("_1")}, max(3e-3, TOL))
+    finally:
+        ops.WGRAD_PRECISION = old
+
+
 def test_training_step_is_bitwise_deterministic(impl):
     """Dropout active, gradient stream on: two identical runs give bit-identical parameters (every in-place gradient
     write is serialised on one stream in program order, every reduction has a fixed order) - a race would show here."""
