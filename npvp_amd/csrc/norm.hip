@@ -541,7 +541,7 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   NPVP_CHECK_LAUNCH();
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 127) / 128, nchunks), dim3(128), 0, stream, p,
+  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
                      dout, (const float*)psum, dh, part, frames, fpc);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
