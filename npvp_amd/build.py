@@ -2,7 +2,7 @@
 
 The shared object lives next to this file (npvp_amd/libnpvp_hip.so): it is git-ignored but
 travels to the GPU box with the repo snapshot.  Incremental: a source is recompiled only when it
-(or common.h) is newer than its object file.
+(or a header of csrc/) is newer than its object file.
 """
 import os
 import subprocess
@@ -31,12 +31,12 @@ def _newer(a, b):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hipcc = _hipcc()
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
-        if force or _newer(src, obj) or _newer(hdr, obj):
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
             jobs.append((src, obj))
 
     def cc(job):

@@ -1,0 +1,143 @@
+// Shared by the GEMM translation units (gemm.hip: fp32-MFMA triage kernel + 128x128 split kernel + C entry point;
+// gemm_wide.hip: 256-row-tile split kernels for the large forward / dgrad / wgrad shapes).
+#pragma once
+#include "common.h"
+
+namespace npvp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  const float* bias;       // [N] or null
+  const float* residual;   // [M][ldr] or null (added last)
+  float* aux_out;          // [M][ldc] pre-activation copy (after bias) or null
+  const float* aux_in;     // [M][ldc] for act 3/4 (activation gradients)
+  float* rowstats;         // frame-statistics partials of the output (see epilogue_rowstats_block), or null
+  float* colsum;           // a_kc==0 only: colsum[z][m] = sum over this split's k of A[k][m] (bias gradient), or null
+  const unsigned long long* seed;  // device seed for dropout or null
+  long long lda, ldb, ldc, ldr;
+  int M, N, K;             // K = this launch's reduction length per split
+  int act;                 // 0 none 1 gelu 2 relu 3 *gelu'(aux_in) 4 *relu'(aux_in)
+  DropSpec drop;
+  int tiles_m, tiles_n;
+  int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
+  float alpha;
+  const void* b_pre;       // pre-split B planes (bf16, blocked [term][K/8][N][8]) or null: see split_weight kernels
+  long long b_pre_plane;   // bf16 elements per term plane (= N*K)
+  int colgroups;           // XCD tiling: 1 = every XCD sweeps all tile columns; G>1 = XCD x owns column group x%G (see tile_of_block)
+  int accum;               // 1: C += result and colsum += sums (gradient accumulation into a live .grad slice)
+};
+
+__device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
+  p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
+}
+
+// ---- epilogue of ONE 32x32 accumulator whose top-left element is (row0, col0): the C/D map of the 32x32 MFMA is
+// col = lane&31 (= r), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (= h).
+// order: *alpha +bias -> aux_out (pre-activation copy) -> act -> dropout -> +residual -> (+= C when accumulating)
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h, int z,
+                                              unsigned long long seed) {
+  const int col = col0 + r;
+  if (col >= p.N) return;
+  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
+  const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+    if (row >= p.M) continue;
+    const long long idx = (long long)row * p.ldc + col;
+    float v = acc[g];
+    if (p.splits > 1) { Cz[idx] = v; continue; }
+    v = v * p.alpha + bv;
+    if (p.aux_out) p.aux_out[idx] = v;
+    if (p.act == 1) v = gelu_f(v);
+    else if (p.act == 2) v = fmaxf(v, 0.f);
+    else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
+    else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
+    if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
+    if (p.residual) v += p.residual[(long long)row * p.ldr + col];
+    if (p.accum) v += Cz[idx];
+    Cz[idx] = v;
+  }
+}
+
+// Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
+// plus, per wave, the (mean, M2) of a 64 x 64 block of outputs held as 2 x 2 accumulators.  Token rows come in frames of
+// 64 and the block's 64 rows are exactly one frame (row0 % 64 == 0, M % 64 == 0), so rowstats[frame][column block of 64]
+// = (mean, M2) are the partials of the frame statistics (merged by frame_stats_finalize): the LayerNorm needs no pass
+// over C.  Sums are taken about the lane's first value and combined across the wave in Chan's form; fixed order,
+// deterministic.  M % 64 == 0 and N % 64 == 0 (checked by the launcher): the block is either inside the matrix or outside.
+__device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, const f32x16& a00, const f32x16& a01,
+                                                        const f32x16& a10, const f32x16& a11, int row0, int col0, int r, int h) {
+  if (row0 >= p.M || col0 >= p.N) return;
+  float shift = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const f32x16& acc = tm == 0 ? (tn == 0 ? a00 : a01) : (tn == 0 ? a10 : a11);
+      const int col = col0 + tn * 32 + r;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = row0 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        const float v = acc[g] * p.alpha + bv;
+        p.C[(long long)row * p.ldc + col] = v;
+        if (tm == 0 && tn == 0 && g == 0) shift = v;
+        const float d = v - shift;
+        s1 += d; s2 += d * d;
+      }
+    }
+  }
+  const float n = 64.f, m1 = s1 / n, mean_l = shift + m1, m2_l = s2 - s1 * m1;       // this lane's 64 values
+  const float mean_w = wave_sum(mean_l) * (1.f / 64.f);
+  const float dl = mean_l - mean_w;
+  const float m2_w = wave_sum(m2_l + n * dl * dl);
+  if ((threadIdx.x & 63) == 0) {
+    const long long frame = row0 >> 6;
+    const int cb = col0 >> 6, ncb = p.N >> 6;
+    p.rowstats[(frame * ncb + cb) * 2] = mean_w;
+    p.rowstats[(frame * ncb + cb) * 2 + 1] = m2_w;
+  }
+}
+
+// XCD-aware, bijective tile remap (cdna guide T1) for an unsplit launch of gridDim.x = tiles_m * tiles_n workgroups.
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), each XCD has a private 4 MiB L2.  Default
+// (colgroups = 1): XCD x walks a contiguous run of tiles, tile_n fastest, so an A row-panel is fetched by one XCD and
+// reused from its L2 across the tile columns - but then the XCD needs ALL of B resident, and the weights of the
+// 512<->2048 layers do not fit next to the streaming A panels.  colgroups = G > 1: XCD x owns column group x % G (a B
+// slice that stays L2 resident) and row group x / G; A panels are then read by G XCDs.  Placement only changes speed.
+__device__ __forceinline__ void tile_of_block_unsplit(const GemmParams& p, int& tile_m, int& tile_n) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  if (p.colgroups > 1) {
+    const int G = p.colgroups, tn_g = p.tiles_n / G, tm_g = p.tiles_m / (8 / G);
+    const int lm = loc / tn_g;
+    tile_m = (xcd / G) * tm_g + lm;
+    tile_n = (xcd % G) * tn_g + (loc - lm * tn_g);
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    tile_m = nid / p.tiles_n;
+    tile_n = nid - tile_m * p.tiles_n;
+  }
+}
+
+// smallest G in {1,2,4,8} with b_bytes / G <= 2 MB that tiles the grid evenly (see tile_of_block_unsplit)
+inline int pick_colgroups(long long b_bytes, int tiles_m, int tiles_n) {
+  for (int G = 1; G <= 8; G *= 2) {
+    if (b_bytes / G > (2ll << 20)) continue;
+    if (G > 1 && (tiles_n % G == 0) && (tiles_m % (8 / G) == 0) && ((tiles_m * tiles_n) % 8 == 0)) return G;
+    break;
+  }
+  return 1;
+}
+
+// gemm_wide.hip: 256 x 256 tile, 8 waves, A = fp32 [M][K] split on the fly, B = pre-split planes.  Returns true if it
+// took the launch (shape / operand requirements met), false if the caller should use the 128 x 128 kernel.
+bool launch_gemm_wide(GemmParams& p, hipStream_t stream);
+
+}  // namespace npvp

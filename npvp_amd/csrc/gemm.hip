@@ -20,38 +20,12 @@
 // k-row l>>5).  LDS is double buffered: one barrier per K-step.  blockIdx is remapped
 // so that the 8 XCDs each walk a contiguous run of tiles (B = the weight stays in the
 // XCD's L2; each A row-panel is fetched by one XCD).
-#include "common.h"
+#include "gemm.h"
 #include <type_traits>
 
 namespace npvp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int BM = 128, BN = 128, BK = 32, GEMM_THREADS = 256;
-
-struct GemmParams {
-  float a_scale = 1.f, b_scale = 1.f;   // f16x3 path: power-of-two operand scales (alpha already carries 1/(sa*sb))
-  const float* A; const float* B; float* C;
-  const float* bias;       // [N] or null
-  const float* residual;   // [M][ldr] or null (added last)
-  float* aux_out;          // [M][ldc] pre-activation copy (after bias) or null
-  const float* aux_in;     // [M][ldc] for act 3/4 (activation gradients)
-  float* rowstats;         // frame-statistics partials of the output (see gemm_epilogue_rowstats), or null
-  float* colsum;           // a_kc==0 only: colsum[z][m] = sum over this split's k of A[k][m] (bias gradient), or null
-  const unsigned long long* seed;  // device seed for dropout or null
-  long long lda, ldb, ldc, ldr;
-  int M, N, K;             // K = this launch's reduction length per split
-  int act;                 // 0 none 1 gelu 2 relu 3 *gelu'(aux_in) 4 *relu'(aux_in)
-  DropSpec drop;
-  int tiles_m, tiles_n;
-  int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
-  float alpha;
-  const void* b_pre;       // pre-split B planes (bf16, blocked [term][K/8][N][8]) or null: see split_weight kernels
-  long long b_pre_plane;   // bf16 elements per term plane (= N*K)
-  int colgroups;           // XCD tiling: 1 = every XCD sweeps all tile columns; G>1 = XCD x owns column group x%G (see tile_of_block)
-  int accum;               // 1: C += result and colsum += sums (gradient accumulation into a live .grad slice)
-  int dbg;                 // profiling ablations (results INVALID): 1 = no global loads, 2 = no split VALU, 4 = no MFMA
-};
 
 // ---- operand staging: one 128 x 32 (rows x k) tile -----------------------------------
 template <bool KC> struct Stager;
@@ -110,95 +84,20 @@ template <> struct Stager<false> {  // source [K][rows], rows contiguous
   }
 };
 
-__device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
-  p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
-}
-
-// ---- epilogue shared by both MFMA paths: C/D map of the 32x32 MFMA is col = lane&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// the four 32x32 accumulators of a wave's 64 x 64 block (128 x 128 tile, 2 x 2 waves)
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
                                               const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm, int wn,
                                               int r, int h, int z) {
   const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
-  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
-      const int col = n0 + wn * 64 + tn * 32 + r;
-      if (col >= p.N) continue;
-      const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (row >= p.M) continue;
-        const long long idx = (long long)row * p.ldc + col;
-        float v = acc[g];
-        if (p.splits > 1) { Cz[idx] = v; continue; }
-        v = v * p.alpha + bv;
-        if (p.aux_out) p.aux_out[idx] = v;
-        if (p.act == 1) v = gelu_f(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
-        else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
-        if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
-        if (p.residual) v += p.residual[(long long)row * p.ldr + col];
-        if (p.accum) v += Cz[idx];
-        Cz[idx] = v;
-      }
-    }
-  }
+  const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+  epilogue_tile(p, acc00, row0, col0, r, h, z, seed);
+  epilogue_tile(p, acc01, row0, col0 + 32, r, h, z, seed);
+  epilogue_tile(p, acc10, row0 + 32, col0, r, h, z, seed);
+  epilogue_tile(p, acc11, row0 + 32, col0 + 32, r, h, z, seed);
 }
 
-// Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
-// plus, per wave, the (mean, M2) of its 64 x 64 block of outputs.  Token rows come in frames of 64 and a wave's 64 rows
-// are exactly one frame (BM = 128, M % 64 == 0), so rowstats[frame][column block of 64] = (mean, M2) are the partials of
-// the frame statistics (merged by frame_stats_finalize): the LayerNorm needs no pass over C.  Sums are taken about the
-// lane's first value and combined across the wave in Chan's form; fixed order, deterministic.
-__device__ __forceinline__ void gemm_epilogue_rowstats(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
-                                                       const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm, int wn,
-                                                       int r, int h) {
-  // M % 64 == 0 and N % 128 == 0 (checked by the launcher): a wave's 64 x 64 block is either completely inside the
-  // matrix or completely outside it (the lower half of the last 128-row tile when M % 128 == 64)
-  if (m0 + wm * 64 >= p.M) return;
-  float shift = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const f32x16& acc = tm == 0 ? (tn == 0 ? acc00 : acc01) : (tn == 0 ? acc10 : acc11);
-      const int col = n0 + wn * 64 + tn * 32 + r;
-      const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = m0 + wm * 64 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        const float v = acc[g] * p.alpha + bv;
-        p.C[(long long)row * p.ldc + col] = v;
-        if (tm == 0 && tn == 0 && g == 0) shift = v;
-        const float d = v - shift;
-        s1 += d; s2 += d * d;
-      }
-    }
-  }
-  const float n = 64.f, m1 = s1 / n, mean_l = shift + m1, m2_l = s2 - s1 * m1;       // this lane's 64 values
-  const float mean_w = wave_sum(mean_l) * (1.f / 64.f);
-  const float dl = mean_l - mean_w;
-  const float m2_w = wave_sum(m2_l + n * dl * dl);
-  if ((threadIdx.x & 63) == 0) {
-    const long long frame = (m0 + wm * 64) >> 6;
-    const int cb = (n0 >> 6) + wn, ncb = p.N >> 6;
-    p.rowstats[(frame * ncb + cb) * 2] = mean_w;
-    p.rowstats[(frame * ncb + cb) * 2 + 1] = m2_w;
-  }
-}
-
-// XCD-aware, bijective tile remap (cdna guide T1).  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one),
-// each XCD has a private 4 MiB L2.  Default (colgroups = 1): XCD x walks a contiguous run of tiles, tile_n fastest, so an
-// A row-panel is fetched by one XCD and reused from its L2 across the tile columns - but then the XCD needs ALL of B
-// resident, and the 4 MiB weights of the 512<->2048 layers do not fit next to the streaming A panels (rocprofv3:
-// FETCH_SIZE 2.5x the algorithmic bytes).  colgroups = G > 1: XCD x owns column group x % G (a B slice <= 2 MB that stays
-// L2 resident) and row group x / G; A panels are then read by G XCDs.  Placement only changes speed, never results.
+// 128 x 128 tiles: unsplit launches use the XCD-aware remap of gemm.h; split-K launches (weight gradients) keep all tiles
+// of one K-chunk on one XCD.
 __device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int& n0, int& z) {
   if (p.splits > 1) {
     // split-K (weight gradients): all tiles of one K-chunk z read the same rows of dy and x.  Dealt round-robin, the tiles
@@ -220,20 +119,8 @@ __device__ __forceinline__ void tile_of_block(const GemmParams& p, int& m0, int&
     return;
   }
   z = 0;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, loc = bid >> 3;
   int tile_m, tile_n;
-  if (p.colgroups > 1) {
-    const int G = p.colgroups, tn_g = p.tiles_n / G, tm_g = p.tiles_m / (8 / G);
-    const int lm = loc / tn_g;
-    tile_m = (xcd / G) * tm_g + lm;
-    tile_n = (xcd % G) * tn_g + (loc - lm * tn_g);
-  } else {
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    tile_m = nid / p.tiles_n;
-    tile_n = nid - tile_m * p.tiles_n;
-  }
+  tile_of_block_unsplit(p, tile_m, tile_n);
   m0 = tile_m * BM; n0 = tile_n * BN;
 }
 
@@ -320,87 +207,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
 //     NS = 3 ("bf16x6"): p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1 6 MFMAs / product, ~2^-23: fp32-grade
 // i.e. 16/3 = 5.3x resp. 16/6 = 2.7x the fp32-input MFMA rate, with bf16's full fp32 exponent range (no scaling
 // pass, gradients of 1e-8 are safe - an fp16 split would need one).  LDS image per operand and per term:
-// [k/8][row][8 k] bf16 - a row's 8 consecutive k are one 16-byte slot, rows contiguous, 129 slots per k-group to
-// skew banks - so the MFMA fragment of lane (row r, half h) is ONE conflict-free ds_read_b128.  One LDS stage
-// (33 / 49.5 KB -> 3 workgroups per CU); the next K-tile is prefetched into registers while the MFMAs run.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// [k/8][row][8 k] bf16 - a row's 8 consecutive k are one 16-byte slot, rows contiguous - so the MFMA fragment of lane
+// (row r, half h) is ONE conflict-free ds_read_b128.  (Earlier organisations of the same arithmetic - single LDS stage,
+// producer/consumer waves, a two-term fp16 split - were measured and dropped; they live in the history of this file.)
 constexpr int KG_STRIDE = 129 * 16;          // bytes between k-groups
-constexpr int OPER_BYTES = 4 * KG_STRIDE;    // one operand tile (128 rows x 32 k), one split term
-
-template <int NS, bool KC> struct SplitStager;
-
-template <int NS> struct SplitStager<NS, true> {
-  // source [rows][K].  16 consecutive lanes = 8 rows x the two 4-k halves of ONE k-group, so a ds_write_b64
-  // wave-instruction covers 128 contiguous LDS bytes per 16-lane group (conflict free; the first version's
-  // (row, 8 k-chunks) mapping was 2-way: profiles/r01_pmc_gemm_bf16x6.md).  Global side: a row's 128 B
-  // (32 k) is read by 8 lanes as one full line.
-  float4 r[4];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
-    const int kof = ((t >> 4) & 3) * 8 + (t & 1) * 4, rl = (t >> 6) * 8 + ((t >> 1) & 7);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = row0 + rl + 32 * i;
-      r[i] = (row < nrows) ? ld4(src + (long long)row * ld + k0 + kof) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  __device__ __forceinline__ void store(char* base, int t) const {      // base -> term 0; term s at base + s*OPER_BYTES
-    const int off0 = ((t >> 4) & 3) * KG_STRIDE + (t & 1) * 8, rl = (t >> 6) * 8 + ((t >> 1) & 7);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rl + 32 * i;
-      float4 v = r[i];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        bf16x4 q;
-        q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(base + s * OPER_BYTES + off0 + row * 16) = q;
-        v.x -= (float)q[0]; v.y -= (float)q[1]; v.z -= (float)q[2]; v.w -= (float)q[3];
-      }
-    }
-  }
-};
-
-template <int NS> struct SplitStager<NS, false> {
-  // source [K][rows].  One row per lane (64 consecutive rows = 256 contiguous bytes per load), 8 k per k-group
-  // gathered in registers, then ONE ds_write_b128 per term with consecutive lanes on consecutive 16-byte slots
-  // (conflict free).
-  float r[2][8];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
-    const int row = t & 127, kgb = t >> 7;
-    const bool ok = row0 + row < nrows;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        r[i][j] = ok ? src[(long long)(k0 + (kgb + 2 * i) * 8 + j) * ld + row0 + row] : 0.f;
-  }
-  __device__ __forceinline__ float tile_sum() const {       // this thread's row (a column of the [K][rows] operand), 16 k
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a += r[i][j];
-    return a;
-  }
-  __device__ __forceinline__ void store(char* base, int t) const {
-    const int row = t & 127, kgb = t >> 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = (kgb + 2 * i) * KG_STRIDE + row * 16;
-      float a[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = r[i][j];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        bf16x8 q;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { q[j] = (__bf16)a[j]; a[j] -= (float)q[j]; }
-        *reinterpret_cast<bf16x8*>(base + s * OPER_BYTES + off) = q;
-      }
-    }
-  }
-};
 
 #define NPVP_MFMA4(A0, A1, B0, B1)                                                  \
   acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc00, 0, 0, 0);          \
@@ -408,177 +218,11 @@ template <int NS> struct SplitStager<NS, false> {
   acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc10, 0, 0, 0);          \
   acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc11, 0, 0, 0);
 
-template <int NS, bool AKC, bool BKC>
-__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_kernel(GemmParams p) {
-  // [A term 0..NS-1 | B term 0..NS-1]
-  __shared__ __attribute__((aligned(16))) char lds[2 * NS * OPER_BYTES];
-  int m0, n0;
-  int z;
-  tile_of_block(p, m0, n0, z);
-  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
-  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-
-  SplitStager<NS, AKC> sa; SplitStager<NS, BKC> sb;
-  char* const ldsA = lds;
-  char* const ldsB = lds + NS * OPER_BYTES;
-  const char* const fa = ldsA + h * KG_STRIDE + (wm * 64 + r) * 16;     // this lane's fragment slot, term 0, k16-step 0
-  const char* const fb = ldsB + h * KG_STRIDE + (wn * 64 + r) * 16;
-  const int nk = p.K / BK;
-  const bool want_cs = !AKC && p.colsum && n0 == 0;
-  float cs = 0.f;
-  const int t = threadIdx.x;
-  bf16x8 cfrag;
-  for (int j = 0; j < 8; ++j) cfrag[j] = (__bf16)(float)(lane + j);
-  sa.load(A, p.lda, m0, p.M, 0, t);
-  sb.load(B, p.ldb, n0, p.N, 0, t);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
-    if (!(p.dbg & 2)) { sa.store(ldsA, t); sb.store(ldsB, t); }   // split + stage tile kt
-    if (!(p.dbg & 8)) __syncthreads();
-    if (kt + 1 < nk && !(p.dbg & 1)) {                   // tile kt+1 travels HBM/L2 -> registers under the MFMAs
-      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, t);
-      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, t);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {                     // two k16 steps per 32-deep tile; lane half h takes k-group 2kk+h
-      const int ko = kk * 2 * KG_STRIDE;
-      bf16x8 a0[NS], a1[NS], b0[NS], b1[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (p.dbg & 16) { a0[s] = a1[s] = b0[s] = b1[s] = cfrag; continue; }   // ablation: no LDS fragment reads
-        a0[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko);
-        a1[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko + 32 * 16);
-        b0[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko);
-        b1[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko + 32 * 16);
-      }
-      if (p.dbg & 4) {
-        asm volatile("" :: "v"(a0[0]), "v"(a1[0]), "v"(b0[0]), "v"(b1[0]), "v"(a0[NS - 1]), "v"(a1[NS - 1]), "v"(b0[NS - 1]), "v"(b1[NS - 1]));
-        continue;
-      }
-      if (NS == 3) {                                      // smallest terms first
-        NPVP_MFMA4(a0[1], a1[1], b0[1], b1[1])
-        NPVP_MFMA4(a0[0], a1[0], b0[2], b1[2])
-        NPVP_MFMA4(a0[2], a1[2], b0[0], b1[0])
-      }
-      NPVP_MFMA4(a0[0], a1[0], b0[1], b1[1])
-      NPVP_MFMA4(a0[1], a1[1], b0[0], b1[0])
-      NPVP_MFMA4(a0[0], a1[0], b0[0], b1[0])
-    }
-    if (!(p.dbg & 8)) __syncthreads();                    // every wave is done with the stage before it is rewritten
-  }
-  if constexpr (!AKC) {
-    if (want_cs) {            // threads t and t+128 hold the two halves of column t&127
-      float* red = reinterpret_cast<float*>(lds);
-      red[threadIdx.x] = cs;
-      __syncthreads();
-      if (threadIdx.x < 128 && m0 + (int)threadIdx.x < p.M)
-        store_colsum(p, (long long)z * p.M + m0 + threadIdx.x, red[threadIdx.x] + red[threadIdx.x + 128]);
-    }
-  }
-  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
-}
 
 // -----------------------------------------------------------------------------------------------------
-// Producer / consumer form of the split-precision GEMM (the default for bf16x6).  In gemm_split_kernel every
-// wave alternates between "split + stage a tile" (VALU + LDS writes) and "MFMA", with barriers between: measured
-// MfmaUtil 34-42 % (profiles/r01_pmc_gemm_bf16x6.md) - the matrix pipe idles while its own wave stages.  Here a
-// workgroup is 8 waves: waves 0-3 (one per SIMD) ONLY read fragments and issue MFMAs on LDS stage kt&1, waves 4-7
-// (the SIMDs' second wave) ONLY load, split and write tile kt+1 into the other stage and prefetch tile kt+2 into
-// registers.  VALU / LDS-write work of a producer wave and the MFMAs of the consumer wave on the same SIMD run on
-// separate pipes concurrently; one barrier per K-step.  2 x 49.5 KB LDS -> one workgroup per CU.
-template <int NS, bool AKC, bool BKC>
-__global__ __launch_bounds__(512, 2) void gemm_split_pc_kernel(GemmParams p) {
-  constexpr int STAGE = 2 * NS * OPER_BYTES;                 // [A term 0..NS-1 | B term 0..NS-1]
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
-  int m0, n0;
-  int z;
-  tile_of_block(p, m0, n0, z);
-  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
-  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
-  const int nk = p.K / BK;
-  const int wave = threadIdx.x >> 6;
-
-  if (wave >= 4) {
-    // ------------------------------------------------ producers
-    const int t = threadIdx.x - 256;
-    SplitStager<NS, AKC> sa; SplitStager<NS, BKC> sb;
-    const bool want_cs = !AKC && p.colsum && n0 == 0;
-    float cs = 0.f;
-    sa.load(A, p.lda, m0, p.M, 0, t);
-    sb.load(B, p.ldb, n0, p.N, 0, t);
-    if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
-    sa.store(lds, t); sb.store(lds + NS * OPER_BYTES, t);
-    if (nk > 1) { sa.load(A, p.lda, m0, p.M, BK, t); sb.load(B, p.ldb, n0, p.N, BK, t); }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        char* st = lds + ((kt + 1) & 1) * STAGE;
-        if constexpr (!AKC) { if (want_cs) cs += sa.tile_sum(); }
-        sa.store(st, t); sb.store(st + NS * OPER_BYTES, t);
-        if (kt + 2 < nk) { sa.load(A, p.lda, m0, p.M, (kt + 2) * BK, t); sb.load(B, p.ldb, n0, p.N, (kt + 2) * BK, t); }
-      }
-      __syncthreads();
-    }
-    if constexpr (!AKC) {
-      if (want_cs) {                       // threads t and t+128 hold the two halves of column t&127
-        float* red = reinterpret_cast<float*>(lds);
-        red[t] = cs;
-      }
-    }
-    __syncthreads();                       // matches the consumers' barrier before their epilogue
-    if constexpr (!AKC) {
-      if (want_cs && t < 128 && m0 + t < p.M) {
-        const float* red = reinterpret_cast<const float*>(lds);
-        store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------- consumers
-  const int lane = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  const int fa_off = h * KG_STRIDE + (wm * 64 + r) * 16;
-  const int fb_off = NS * OPER_BYTES + h * KG_STRIDE + (wn * 64 + r) * 16;
-  __syncthreads();                         // stage 0 is ready
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* fa = lds + (kt & 1) * STAGE + fa_off;
-    const char* fb = lds + (kt & 1) * STAGE + fb_off;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ko = kk * 2 * KG_STRIDE;
-      bf16x8 a0[NS], a1[NS], b0[NS], b1[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        a0[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko);
-        a1[s] = *reinterpret_cast<const bf16x8*>(fa + s * OPER_BYTES + ko + 32 * 16);
-        b0[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko);
-        b1[s] = *reinterpret_cast<const bf16x8*>(fb + s * OPER_BYTES + ko + 32 * 16);
-      }
-      if (NS == 3) {
-        NPVP_MFMA4(a0[1], a1[1], b0[1], b1[1])
-        NPVP_MFMA4(a0[0], a1[0], b0[2], b1[2])
-        NPVP_MFMA4(a0[2], a1[2], b0[0], b1[0])
-      }
-      NPVP_MFMA4(a0[0], a1[0], b0[1], b1[1])
-      NPVP_MFMA4(a0[1], a1[1], b0[0], b1[0])
-      NPVP_MFMA4(a0[0], a1[0], b0[0], b1[0])
-    }
-    __syncthreads();
-  }
-  __syncthreads();                         // matches the producers' column-sum barrier
-  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
-}
-
-// -----------------------------------------------------------------------------------------------------
-// Double-buffered, software-pipelined form of the split-precision GEMM ("db").  The ablations of
-// gemm_split_kernel (tools/gemm_bench.py --dbg) show its matrix pipe at 42-51 % even with loads and staging
-// removed: every wave serialises [stage -> barrier -> fragment reads -> 48 MFMAs -> barrier].  Here the K-step
+// Double-buffered, software-pipelined form of the split-precision GEMM ("db").  A single-stage kernel
+// (every wave alternating stage / barrier / MFMA) left the matrix pipe at 42-51 % even with loads and staging
+// removed: every wave serialised [stage -> barrier -> fragment reads -> 48 MFMAs -> barrier].  Here the K-step
 // is 16 deep with TWO LDS stages (2 x 24.2 KB -> still 3 workgroups per CU): within one K-step a wave issues
 // its fragment reads, then its 24 MFMAs with the split + ds_write of the NEXT tile (already in registers)
 // placed in the MFMA shadows, then one barrier.  Global loads run two tiles ahead in a second register set.
@@ -773,158 +417,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
-  if constexpr (ROWSTATS) gemm_epilogue_rowstats(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h);
+  if constexpr (ROWSTATS) epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h);
   else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
-}
-
-// -----------------------------------------------------------------------------------------------------
-// fp16 two-term split ("f16x3"): x*s = hi + lo/2^11 + eps,  hi = rne_f16(x*s), lo = rne_f16((x*s - hi) * 2^11), |eps| <=
-// 2^-22 |x*s| (fp16 carries 11 significand bits, so TWO terms reach fp32-grade where bf16 needs three).  The product is
-//     sum hiA*hiB                       -> accumulator set M        (1 MFMA)
-//     sum hiA*loB + loA*hiB             -> accumulator set X        (2 MFMAs),   C = (M + X * 2^-11) / (sA sB)
-// 3 v_mfma_f32_32x32x16_f16 per product instead of 6 bf16 ones; lo is stored pre-scaled by 2^11 so that it is a normal
-// fp16 number whenever hi is.  fp16 has a 5-bit exponent: operands are pre-multiplied by the caller's power-of-two
-// scales sA / sB (exact) to sit inside it; the representation is exact to 2^-22 relative for |x*s| in [2^-14, 65504] and
-// degrades gradually (absolute error 2^-36) below.  Same LDS image, staging and pipeline as gemm_split_db_kernel.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-template <bool KC> struct HalfStager16;
-
-template <> struct HalfStager16<true> {
-  float4 r[2];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
-    const int kof = ((t >> 4) & 1) * 8 + (t & 1) * 4, rl = (t >> 5) * 8 + ((t >> 1) & 7);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = min(row0 + rl + 64 * i, nrows - 1);
-      r[i] = ld4(src + (long long)row * ld + k0 + kof);
-    }
-  }
-  template <int I> __device__ __forceinline__ void store_part(char* base, int t, float sc) const {
-    const int off = ((t >> 4) & 1) * KG_STRIDE + (t & 1) * 8 + ((t >> 5) * 8 + ((t >> 1) & 7) + 64 * I) * 16;
-    const float4 v = r[I];
-    const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
-    f16x4 hi, lo;
-    hi[0] = (_Float16)x0; hi[1] = (_Float16)x1; hi[2] = (_Float16)x2; hi[3] = (_Float16)x3;
-    lo[0] = (_Float16)((x0 - (float)hi[0]) * 2048.f); lo[1] = (_Float16)((x1 - (float)hi[1]) * 2048.f);
-    lo[2] = (_Float16)((x2 - (float)hi[2]) * 2048.f); lo[3] = (_Float16)((x3 - (float)hi[3]) * 2048.f);
-    *reinterpret_cast<f16x4*>(base + off) = hi;
-    *reinterpret_cast<f16x4*>(base + OPER16 + off) = lo;
-  }
-  __device__ __forceinline__ float tile_sum() const { return 0.f; }
-};
-
-template <> struct HalfStager16<false> {
-  float r2[2][4];
-  __device__ __forceinline__ void load(const float* src, long long ld, int row0, int nrows, int k0, int t) {
-    const int row = min(row0 + (t & 127), nrows - 1), kg = t >> 7;
-    const float* q = src + (long long)(k0 + kg * 8) * ld + row;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r2[j >> 2][j & 3] = q[(long long)j * ld];
-  }
-  template <int I> __device__ __forceinline__ void store_part(char* base, int t, float sc) const {
-    const int off = (t >> 7) * KG_STRIDE + (t & 127) * 16 + I * 8;
-    f16x4 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x = r2[I][j] * sc;
-      hi[j] = (_Float16)x;
-      lo[j] = (_Float16)((x - (float)hi[j]) * 2048.f);
-    }
-    *reinterpret_cast<f16x4*>(base + off) = hi;
-    *reinterpret_cast<f16x4*>(base + OPER16 + off) = lo;
-  }
-  __device__ __forceinline__ float tile_sum() const {
-    return r2[0][0] + r2[0][1] + r2[0][2] + r2[0][3] + r2[1][0] + r2[1][1] + r2[1][2] + r2[1][3];
-  }
-};
-
-#define NPVP_HMFMA4(P, A0, A1, B0, B1)                                               \
-  P##00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, P##00, 0, 0, 0);            \
-  P##01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, P##01, 0, 0, 0);            \
-  P##10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, P##10, 0, 0, 0);            \
-  P##11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, P##11, 0, 0, 0);
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h3_kernel(GemmParams p) {
-  constexpr int STAGE = 4 * OPER16;                           // [A hi | A lo | B hi | B lo]
-  constexpr int BK16 = 16;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
-  int m0, n0;
-  int z;
-  tile_of_block(p, m0, n0, z);
-  const float* A = p.A + (AKC ? (long long)z * p.K : (long long)z * p.K * p.lda);
-  const float* B = p.B + (BKC ? (long long)z * p.K : (long long)z * p.K * p.ldb);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};       // hi*hi
-  f32x16 acx00 = {0}, acx01 = {0}, acx10 = {0}, acx11 = {0};       // hi*lo + lo*hi, scaled by 2^11
-  const int nk = p.K / BK16;
-  const bool want_cs = !AKC && p.colsum && n0 == 0;
-  float cs = 0.f;
-  const float sca = p.a_scale, scb = p.b_scale;
-  const int fa_off = h * KG_STRIDE + (wm * 64 + r) * 16;
-  const int fb_off = 2 * OPER16 + h * KG_STRIDE + (wn * 64 + r) * 16;
-
-  HalfStager16<AKC> a0s, a1s;
-  HalfStager16<BKC> b0s, b1s;
-  a0s.load(A, p.lda, m0, p.M, 0, t); b0s.load(B, p.ldb, n0, p.N, 0, t);
-  if constexpr (!AKC) { if (want_cs) cs += a0s.tile_sum(); }
-  a0s.template store_part<0>(lds, t, sca); a0s.template store_part<1>(lds, t, sca);
-  b0s.template store_part<0>(lds + 2 * OPER16, t, scb); b0s.template store_part<1>(lds + 2 * OPER16, t, scb);
-  { const int k1 = min(BK16, p.K - BK16); a0s.load(A, p.lda, m0, p.M, k1, t); b0s.load(B, p.ldb, n0, p.N, k1, t); }
-  __syncthreads();
-
-#define NPVP_H3_STEP(KT, SA_CUR, SB_CUR, SA_NXT, SB_NXT)                                                        \
-  {                                                                                                             \
-    const char* st = lds + ((KT) & 1) * STAGE;                                                                  \
-    char* nx = lds + (((KT) + 1) & 1) * STAGE;                                                                  \
-    const int k2 = min(((KT) + 2) * BK16, p.K - BK16);                                                          \
-    SA_NXT.load(A, p.lda, m0, p.M, k2, t);                                                                      \
-    SB_NXT.load(B, p.ldb, n0, p.N, k2, t);                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    f16x8 fa0[2], fa1[2], fb0[2], fb1[2];                                                                       \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                             \
-      fa0[s] = *reinterpret_cast<const f16x8*>(st + fa_off + s * OPER16);                                       \
-      fa1[s] = *reinterpret_cast<const f16x8*>(st + fa_off + s * OPER16 + 32 * 16);                             \
-      fb0[s] = *reinterpret_cast<const f16x8*>(st + fb_off + s * OPER16);                                       \
-      fb1[s] = *reinterpret_cast<const f16x8*>(st + fb_off + s * OPER16 + 32 * 16);                             \
-    }                                                                                                           \
-    if constexpr (!AKC) { if (want_cs && (KT) + 1 < nk) cs += SA_CUR.tile_sum(); }                              \
-    SA_CUR.template store_part<0>(nx, t, sca);                                                                  \
-    NPVP_HMFMA4(acx, fa0[0], fa1[0], fb0[1], fb1[1])                                                            \
-    SA_CUR.template store_part<1>(nx, t, sca);                                                                  \
-    SB_CUR.template store_part<0>(nx + 2 * OPER16, t, scb);                                                     \
-    NPVP_HMFMA4(acc, fa0[0], fa1[0], fb0[0], fb1[0])                                                            \
-    SB_CUR.template store_part<1>(nx + 2 * OPER16, t, scb);                                                     \
-    NPVP_HMFMA4(acx, fa0[1], fa1[1], fb0[0], fb1[0])                                                            \
-    __syncthreads();                                                                                            \
-  }
-
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    NPVP_H3_STEP(kt, a0s, b0s, a1s, b1s)
-    NPVP_H3_STEP(kt + 1, a1s, b1s, a0s, b0s)
-  }
-  if (kt < nk) NPVP_H3_STEP(kt, a0s, b0s, a1s, b1s)
-#undef NPVP_H3_STEP
-
-  if constexpr (!AKC) {
-    if (want_cs) {
-      float* red = reinterpret_cast<float*>(lds);
-      red[t] = cs;
-      __syncthreads();
-      if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
-    }
-  }
-  constexpr float LO = 1.f / 2048.f;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    acc00[g] = fmaf(acx00[g], LO, acc00[g]); acc01[g] = fmaf(acx01[g], LO, acc01[g]);
-    acc10[g] = fmaf(acx10[g], LO, acc10[g]); acc11[g] = fmaf(acx11[g], LO, acc11[g]);
-  }
-  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
@@ -989,21 +483,19 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              int precision, float* colsum_a, const void* b_pre, int accumulate, float* rowstats,
                              void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  const int dbg = precision >> 8;      // profiling ablation flags (tools/gemm_bench.py --dbg), results invalid
-  precision &= 0xff;
-  NPVP_CHECK_ARG(precision >= 0 && precision <= 6,
-                 "gemm: precision must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16x6), 3 (bf16x6 producer/consumer), "
-                 "4 (bf16x6 double-buffered pipeline), 5 (bf16x3 double-buffered pipeline) or 6 (f16x3, experimental)");
+  NPVP_CHECK_ARG(precision == 0 || precision == 4 || precision == 5,
+                 "gemm: precision must be 0 (exact fp32-input MFMA), 4 (three-term bf16 split, 6 MFMAs per product: "
+                 "fp32-grade, the default) or 5 (two-term bf16 split, 3 MFMAs per product, ~2^-16)");
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
   NPVP_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
-  NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm: A/B must be 16-byte aligned");
   NPVP_CHECK_ARG(!(a_kc == 0 && b_kc == 1), "gemm: (a_kc=0,b_kc=1) is not used by the path");
   NPVP_CHECK_ARG((act != 3 && act != 4) || aux_in, "gemm: act 3/4 need aux_in");
   NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p out of range");
   NPVP_CHECK_ARG(drop_p == 0.f || seed, "gemm: dropout needs a device seed");
   NPVP_CHECK_ARG(!colsum_a || a_kc == 0, "gemm: colsum_a is the column sum of a [K][M] operand (a_kc = 0)");
+  NPVP_CHECK_ARG(!b_pre || ((uintptr_t)b_pre % 16) == 0, "gemm: b_pre must be 16-byte aligned");
 
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux_out = aux_out; p.aux_in = aux_in;
@@ -1019,22 +511,20 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.rowstats = rowstats;
   NPVP_CHECK_ARG(!rowstats || (precision == 4 && a_kc && b_kc && M % 64 == 0 && N % 128 == 0 && act == 0 && !aux_out && !residual &&
                                drop_p == 0.f && !accumulate),
-                 "gemm: rowstats needs the default (bf16x6db) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");
+                 "gemm: rowstats needs the default (bf16x6) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");
   p.accum = accumulate ? 1 : 0;
-  p.dbg = dbg;
-  // pre-split B planes are only consumed by the db bf16x6 kernel with a row-major A and an unsplit reduction
+  // pre-split B planes are only consumed by the bf16x6 kernels with a row-major A and an unsplit reduction
   p.b_pre = (precision == 4 && a_kc && splits == 1 && K % 16 == 0 && N % 8 == 0) ? b_pre : nullptr;
   p.b_pre_plane = (long long)N * K;
   b_pre = p.b_pre;
-  // B-slice residency rule (see tile_of_block): smallest G in {1,2,4,8} with N*K*4/G <= 2 MB that tiles the grid evenly
-  p.colgroups = 1;
-  if (splits == 1 && !(dbg & 32)) {
-    for (int G = 1; G <= 8; G *= 2) {
-      if ((long long)N * K * 4 / G > (2ll << 20)) continue;
-      if (G > 1 && (p.tiles_n % G == 0) && (p.tiles_m % (8 / G) == 0) && ((p.tiles_m * p.tiles_n) % 8 == 0)) p.colgroups = G;
-      break;
-    }
+
+  // large forward / dgrad shapes: 256 x 256 tiles (gemm_wide.hip); it declines what it is not built for
+  if (b_pre && launch_gemm_wide(p, stream)) {
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
   }
+
+  p.colgroups = splits == 1 ? pick_colgroups((long long)N * K * 4, p.tiles_m, p.tiles_n) : 1;
   if (splits > 1) {
     p.K = K / splits; p.C = (float*)workspace; p.ldc = N;
     if (colsum_a) p.colsum = (float*)workspace + (long long)splits * M * N;
@@ -1045,33 +535,16 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
-  } else if (precision == 1) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<2, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_kernel<2, false, false>), grid, block, 0, stream, p);
-  } else if (precision == 2) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_kernel<3, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_kernel<3, false, false>), grid, block, 0, stream, p);
   } else if (precision == 4) {
     if (rowstats) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false, true>), grid, block, 0, stream, p);
     else if (b_pre && a_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
     else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);
-  } else if (precision == 6) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_h3_kernel<true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_h3_kernel<true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_h3_kernel<false, false>), grid, block, 0, stream, p);
-  } else if (precision == 5) {
+  } else {
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true, false>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_split_db_kernel<2, false, false, false>), grid, block, 0, stream, p);
-  } else {
-    const dim3 block2(512);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, true>), grid, block2, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_pc_kernel<3, true, false>), grid, block2, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_pc_kernel<3, false, false>), grid, block2, 0, stream, p);
   }
   NPVP_CHECK_LAUNCH();
   if (splits > 1) {

@@ -93,27 +93,23 @@ class Drop:
 NO_DROP = Drop(0.0)
 
 
-# GEMM arithmetic (NPVP_GEMM=f32|bf16x3|bf16x6), all with fp32 accumulation on the matrix cores:
-#   f32    exact fp32-input MFMA (v_mfma_f32_32x32x2_f32)
-#   bf16x3 2-term bf16 split, 3 v_mfma_f32_32x32x16_bf16 per product, ~2^-16 relative product error
-#   bf16x6 3-term bf16 split, 6 MFMAs per product, ~2^-23: fp32-grade; every wave stages and multiplies
-#   bf16x6pc same arithmetic, producer/consumer waves (4 MFMA waves + 4 staging waves per workgroup)
-#   bf16x6db / bf16x3db: same arithmetic, 16-deep K-steps, two LDS stages, staging interleaved with the MFMAs
-#   f16x3  EXPERIMENT: 2-term fp16 split, 3 MFMAs per product, ~2^-22 - fp32-grade ONLY inside fp16's exponent range
-#          (overflows above 65504, degrades below 2^-24: gradients of 1e-9 need a scaling pass it does not have).
-#          Measured 170 TF vs 151 TF for bf16x6db over the c1 shapes (tools/h3_check.py, tools/gemm_bench.py): halving
-#          the MFMA count buys 13 %, i.e. the K-step is bound by LDS traffic + staging, not by the matrix pipe.
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16x6pc": 3, "bf16x6db": 4, "bf16x3db": 5, "f16x3": 6}
-GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6db")]
+# GEMM arithmetic (NPVP_GEMM=bf16x6|f32), fp32 accumulation on the matrix cores:
+#   bf16x6 (default) every fp32 operand is split into three bf16 terms and the six leading cross products run on
+#          v_mfma_f32_32x32x16_bf16: ~2^-23 per product, fp32-grade.  Kernels: gemm_wide_kernel (256-row tiles, weights
+#          from pre-split planes: the large forward / dgrad shapes) and gemm_split_db_kernel (128 x 128 tiles: small
+#          shapes, weight gradients)
+#   f32    exact fp32-input MFMA (v_mfma_f32_32x32x2_f32), 1/16 of the bf16 rate: parity triage
+#   bf16x3 two-term split, 3 MFMAs per product, ~2^-16: only ever used for weight gradients, opt-in (NPVP_WGRAD=bf16x3)
+GEMM_MODES = {"f32": 0, "bf16x6": 4, "bf16x6db": 4, "bf16x3": 5, "bf16x3db": 5}
+GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6")]
 
 
-# Arithmetic of the WEIGHT-GRADIENT GEMMs when the path runs in its default mode (bf16x6db): two bf16 terms, 3 MFMAs per
-# product ("bf16x3db", 2^-16 per product).  A weight gradient is a LEAF of the backward graph - its rounding error does not
-# propagate through the layers the way an activation-gradient error does (which is why the forward / dgrad GEMMs need the
-# six-term split) - and it is a 10^4-long sum whose per-product errors average out.  Measured against the reference's
-# vectors: weight-gradient rel-L2 4e-6..7e-6 (six terms: 1e-6..5e-6), parameters after two AdamW steps 2.4e-5, every
-# parity test unchanged at its 1e-3 bar; c1 step 119.5 -> 113.4 ms.  NPVP_WGRAD=bf16x6 keeps six terms everywhere.
-WGRAD_PRECISION = {"": 5, "bf16x3": 5, "bf16x6": None, "same": None}[os.environ.get("NPVP_WGRAD", "")]
+# Arithmetic of the WEIGHT-GRADIENT GEMMs.  Default: the same six-term split as forward / dgrad (fp32-grade, what the
+# reference's fp32 wgrad delivers).  NPVP_WGRAD=bf16x3 is an OPT-IN fast mode (two bf16 terms, 3 MFMAs per product, 2^-16
+# per product): a weight gradient is a leaf of the backward graph, so its rounding error does not propagate through the
+# layers, and the reference's small-N vectors are met (weight-gradient rel-L2 4e-6..7e-6), but there is no full-depth,
+# full-batch evidence for it - bench.py never measures it unless asked to, and says so in `dtype` when it does.
+WGRAD_PRECISION = {"": None, "bf16x6": None, "same": None, "bf16x3": 5}[os.environ.get("NPVP_WGRAD", "")]
 
 
 def set_gemm_precision(name):
@@ -122,14 +118,15 @@ def set_gemm_precision(name):
 
 
 class WeightPlanes:
-    """Optional (NPVP_PRESPLIT=1) per-step cache of pre-split weight planes (npvp_split_weight) for the B operand of
-    the forward / dgrad GEMMs.  Measured on MI355X: it removes half of the split VALU work but does not change the
-    GEMM time (the K-step is not VALU-issue bound after all: 150.7 vs 151.4 TF over the c1 shapes), so it is OFF by
-    default.  The cache lives ON the owning tensor object (the Parameter, or the flat parameter buffer it is a view
-    of), never in a table keyed by device address: a freed weight's address is reused by the next model's weights.
-    An entry is re-split after `invalidate()` (FlatAdamW.step) or an in-place torch update (version counter)."""
+    """Per-optimiser-step cache of the pre-split bf16 planes of a weight (npvp_split_weight): the B operand of the forward
+    (F planes) and dgrad (D planes) GEMMs.  A weight changes once per step but is staged by every tile of two GEMMs, so it
+    is split ONCE, into the exact layout of the GEMM's LDS image - the wide GEMM kernel then copies it HBM -> LDS by
+    LDS-DMA and spends no VALU or VGPR on it.  The cache lives ON the owning tensor object (the Parameter, or the flat
+    parameter buffer it is a view of), never in a table keyed by device address: a freed weight's address is reused by
+    the next model's weights.  An entry is re-split after `invalidate()` (FlatAdamW.step) or an in-place torch update
+    (version counter).  NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly)."""
     epoch = 0
-    enabled = os.environ.get("NPVP_PRESPLIT", "0") == "1"
+    enabled = os.environ.get("NPVP_PRESPLIT", "1") == "1"
 
     @classmethod
     def invalidate(cls):
@@ -157,29 +154,38 @@ class WeightPlanes:
 
 
 class GemmProbe:
-    """bench.py's live roofline probe: when armed, every GEMM launch of the probed operand layout is bracketed
-    by a pair of HIP events on the launching stream (no synchronisation; read after the timed region)."""
-    armed = None          # (a_kc, b_kc) or None
-    records = []          # (start_event, end_event, flops)
+    """bench.py's live roofline probe: when armed, every GEMM launch is bracketed by a pair of HIP events on the stream
+    it is launched on (no synchronisation; read after the timed region), keyed by operand layout:
+    (1,1) forward, (1,0) dgrad, (0,0) weight gradient."""
+    armed = False
+    records = []          # (start_event, end_event, flops, bytes, layout)
 
     @classmethod
-    def arm(cls, a_kc, b_kc):
-        cls.armed, cls.records = (a_kc, b_kc), []
+    def arm(cls):
+        cls.armed, cls.records = True, []
 
     @classmethod
     def disarm(cls):
-        cls.armed = None
+        cls.armed = False
 
     @classmethod
     def summary(cls):
-        """(launches, total_ms, total_flops) - call after torch.cuda.synchronize()."""
-        times = [r[0].elapsed_time(r[1]) for r in cls.records]
-        ms = sum(times)
-        cls.bytes = sum(r[3] for r in cls.records)          # algorithmic operand + result bytes of the probed launches
-        # the launches that had the device to themselves (outside the two-stream encoder region)
-        alone = [(t, r[2]) for t, r in zip(times, cls.records) if not r[4]]
-        cls.unshared = (len(alone), sum(t for t, _ in alone), sum(f for _, f in alone))
-        return len(cls.records), ms, sum(r[2] for r in cls.records)
+        """{layout: (launches, total_ms, total_flops, total_algorithmic_bytes)} - call after torch.cuda.synchronize()."""
+        out = {}
+        for e0, e1, fl, by, lay in cls.records:
+            n, ms, f, b = out.get(lay, (0, 0.0, 0.0, 0.0))
+            out[lay] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+        return out
+
+
+def gemm_kernel_name(layout):
+    """what bench.py prints as the roofline kernel for 'forward' / 'dgrad' / 'wgrad'"""
+    if GEMM_PRECISION == 0:
+        return "npvp::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)"
+    if layout == "wgrad":
+        return "npvp::gemm_split_db_kernel<3,false,false> (128x128 tiles, split-K)"
+    return ("npvp::gemm_wide_kernel (256x256 / 256x128 tiles, 8 waves; A split on the fly, pre-split weight planes by "
+            "LDS-DMA; small shapes fall to npvp::gemm_split_db_kernel) - " + layout)
 
 
 class GradSink:
@@ -315,9 +321,9 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
     seed = rng.seed_tensor(A.device) if drop.on else None
-    # every launch of the armed layout is timed, also those that share the device with a kernel of another stream: the
-    # population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
-    probe = GemmProbe.armed == (a_kc, b_kc)
+    # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
+    # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
+    probe = GemmProbe.armed
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -329,7 +335,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
           "npvp_gemm_f32")
     if probe:
         e1.record()
-        GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), AuxStream.active))
+        GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), (a_kc, b_kc)))
     return out
 
 
@@ -339,12 +345,12 @@ def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP, rowsta
     N = w.shape[0]
     y = torch.empty(R, N, dtype=torch.float32, device=x.device)
     return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual,
-                drop=drop, b_pre=WeightPlanes.get(w, "F") if (R >= 1024 and rowstats is None) else None, rowstats=rowstats)
+                drop=drop, b_pre=WeightPlanes.get(w, "F") if R >= 256 else None, rowstats=rowstats)
 
 
 def linear_frame_stats_supported(R, N):
     """the forward GEMM can emit the frame-LayerNorm statistics of its output (frames of 64 token rows)"""
-    return (GEMM_PRECISION & 0xff) == 4 and R % 64 == 0 and N % 128 == 0
+    return GEMM_PRECISION == 4 and R % 64 == 0 and N % 128 == 0
 
 
 def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
@@ -353,7 +359,7 @@ def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
     K = w.shape[1]
     dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
     return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop,
-                b_pre=WeightPlanes.get(w, "D") if R >= 1024 else None)
+                b_pre=WeightPlanes.get(w, "D") if R >= 256 else None)
 
 
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None):
@@ -366,7 +372,7 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None):
     dw = into if acc else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = (into_b if acc else torch.empty(N, dtype=torch.float32, device=dy.device)) if with_bias_grad else None
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc,
-         precision=WGRAD_PRECISION if (GEMM_PRECISION & 0xff) == 4 else None)
+         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None)
     return (dw, db) if with_bias_grad else dw
 
 

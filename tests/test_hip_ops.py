@@ -32,9 +32,8 @@ def close(a, b, tol=TOL, what=""):
     assert e < tol, f"{what}: rel-L2 {e:.3e} >= {tol:.1e}"
 
 
-# default: the exact fp32-MFMA kernel, the default split kernel (bf16x6db) and its 2-term sibling;
-# NPVP_TEST_ALL_MODES=1 adds the earlier kernel generations that are still selectable (bf16x3, bf16x6, bf16x6pc)
-MODES = ["f32", "bf16x6db", "bf16x3db"] + (["bf16x3", "bf16x6", "bf16x6pc"] if os.environ.get("NPVP_TEST_ALL_MODES") else [])
+# the exact fp32-MFMA kernel, the default three-term split (wide + 128x128 kernels) and its two-term sibling (opt-in wgrad mode)
+MODES = ["f32", "bf16x6", "bf16x3"]
 
 
 @pytest.fixture(scope="module", params=MODES)
@@ -46,7 +45,7 @@ def K(request):
     ops.rng.manual_seed(1234, torch.device(DEV))
     ops.set_gemm_precision(request.param)
     yield ops
-    ops.set_gemm_precision("bf16x6db")
+    ops.set_gemm_precision("bf16x6")
 
 
 def g(t):
@@ -110,33 +109,12 @@ def test_gemm_full_size_against_rocblas(K):
     close(K.linear_fwd(2.5 * x1 + x2, w, None), 2.5 * K.linear_fwd(x1, w, None) + K.linear_fwd(x2, w, None), tol=5e-5)
 
 
-def test_gemm_f16x3_experimental():
-    """The experimental two-term fp16 split (precision 6): fp32-grade on operands inside fp16's exponent range,
-    ragged tile edges included.  Not used by the path (no scaling pass for 1e-9 gradients) - see npvp_amd/ops.py."""
-    from npvp_amd import ops
-    old = ops.GEMM_PRECISION
-    ops.set_gemm_precision("f16x3")
-    try:
-        for M, N, K_ in ((200, 132, 64), (4096, 512, 2048)):
-            x = O.seeded_randn((M, K_), 41).to(DEV); w = (O.seeded_randn((N, K_), 42) / math.sqrt(K_)).to(DEV)
-            b = O.seeded_randn((N,), 43).to(DEV)
-            close(ops.linear_fwd(x, w, b), (x.double() @ w.double().T + b.double()).float(), tol=1e-5, what="f16x3 fwd")
-        R, N, K_ = 4096, 512, 256
-        dy = O.seeded_randn((R, N), 44).to(DEV); x = O.seeded_randn((R, K_), 45).to(DEV); w = (O.seeded_randn((N, K_), 46) / 16).to(DEV)
-        close(ops.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=1e-5, what="f16x3 dgrad")
-        dw, db = ops.linear_wgrad(dy, x, True)
-        close(dw, (dy.double().T @ x.double()).float(), tol=1e-5, what="f16x3 wgrad")
-        close(db, dy.sum(0), tol=1e-5, what="f16x3 fused bias grad")
-    finally:
-        ops.GEMM_PRECISION = old
-
-
 def test_linear_emits_frame_statistics(K):
     """linear(frame_stats=True): the forward GEMM's epilogue yields the frame-LayerNorm statistics of its output
     (frames of 64 token rows) - what MlpDWBN's norm1 / norm3 consume instead of a statistics pass."""
     from npvp_amd import ops
     if not ops.linear_frame_stats_supported(320, 2048):
-        pytest.skip("row statistics ride on the default (bf16x6db) forward kernel")
+        pytest.skip("row statistics ride on the default (bf16x6) forward kernels")
     for R, N, K_ in ((5 * 64, 2048, 512), (3 * 64, 512, 2048), (64, 128, 64)):      # odd frame counts: half-empty last tile
         x = (O.seeded_randn((R, K_), 47) + 0.5).to(DEV).requires_grad_()
         w = (O.seeded_randn((N, K_), 48) / math.sqrt(K_)).to(DEV).requires_grad_(); b = (O.seeded_randn((N,), 49) + 2.0).to(DEV).requires_grad_()

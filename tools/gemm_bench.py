@@ -1,18 +1,21 @@
-"""GEMM micro-benchmark on the predictor's c1 shapes (R = 20480 token rows): TFLOP/s per variant and mode.
-Usage: python tools/gemm_bench.py [modes...] [--iters N]"""
-import sys, os
+"""GEMM micro-benchmark on the predictor's shapes (R token rows x the linears' (N_out, K_in)): algorithmic TFLOP/s of the
+forward / dgrad / weight-gradient GEMMs and max error against an fp64 product.
+Usage: python tools/gemm_bench.py [--rows R] [--iters N] [--mode bf16x6|f32] [--check]"""
+import sys, os, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from npvp_amd import ops
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, nargs="*", default=[114688, 20480, 8192])      # c2 decoder, c1, c2 encoder / c4 shard
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--mode", default="bf16x6")
+ap.add_argument("--check", action="store_true")
+args = ap.parse_args()
 dev = "cuda:0"
-modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["f32", "bf16x3", "bf16x6"]
-dbg = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--dbg=")]
-dbg = dbg[0] if dbg else 0
-iters = 20
-R = 20480
 shapes = [(512, 512), (1024, 512), (2048, 512), (512, 2048), (512, 1024)]      # (N_out, K_in) of the linears
 torch.manual_seed(0)
+ops.set_gemm_precision(args.mode)
 
 
 def timeit(fn):
@@ -20,24 +23,34 @@ def timeit(fn):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
+    for _ in range(args.iters):
         fn()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / args.iters * 1e-3
 
 
-for mode in modes:
-    ops.set_gemm_precision(mode)
-    ops.GEMM_PRECISION |= dbg << 8        # ablation flags: 1 no global loads, 2 no split/stage, 4 no MFMA (results invalid)
-    tot_t, tot_f = 0.0, 0.0
+def err(a, ref):
+    return float((a.double() - ref).norm() / ref.norm())
+
+
+for R in args.rows:
+    tot_t, tot_f = [0.0, 0.0, 0.0], 0.0
     for N, K in shapes:
-        x = torch.randn(R, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
+        x = torch.randn(R, K, device=dev); w = torch.nn.Parameter(torch.randn(N, K, device=dev) / K ** 0.5)
         dy = torch.randn(R, N, device=dev); b = torch.randn(N, device=dev)
         fl = 2.0 * R * N * K
         t1 = timeit(lambda: ops.linear_fwd(x, w, b))
         t2 = timeit(lambda: ops.linear_dgrad(dy, w))
         t3 = timeit(lambda: ops.linear_wgrad(dy, x))
-        tot_t += t1 + t2 + t3; tot_f += 3 * fl
-        print(f"{mode:7s} N={N:5d} K={K:5d}  fwd {fl/t1/1e12:7.1f} TF ({t1*1e6:7.1f} us)  dgrad {fl/t2/1e12:7.1f} TF ({t2*1e6:7.1f} us)  "
-              f"wgrad {fl/t3/1e12:7.1f} TF ({t3*1e6:7.1f} us)", flush=True)
-    print(f"{mode:7s} all shapes: {tot_f/tot_t/1e12:.1f} TF")
+        for i, t in enumerate((t1, t2, t3)):
+            tot_t[i] += t
+        tot_f += fl
+        extra = ""
+        if args.check:
+            n = min(R, 4096)
+            e1 = err(ops.linear_fwd(x, w, b)[:n], x[:n].double() @ w.double().T + b.double())
+            e2 = err(ops.linear_dgrad(dy, w)[:n], dy[:n].double() @ w.double())
+            extra = f"  err fwd {e1:.1e} dgrad {e2:.1e}"
+        print(f"R={R:6d} N={N:5d} K={K:5d}  fwd {fl/t1/1e12:6.1f} TF ({t1*1e6:7.1f} us)  dgrad {fl/t2/1e12:6.1f} TF ({t2*1e6:7.1f} us)  "
+              f"wgrad {fl/t3/1e12:6.1f} TF ({t3*1e6:7.1f} us){extra}", flush=True)
+    print(f"R={R:6d} all shapes: fwd {tot_f/tot_t[0]/1e12:.1f}  dgrad {tot_f/tot_t[1]/1e12:.1f}  wgrad {tot_f/tot_t[2]/1e12:.1f} TF", flush=True)
