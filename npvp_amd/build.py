@@ -41,7 +41,9 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        # NPVP_HIPCC_EXTRA: extra flags for one-off measurement builds on the GPU box (e.g. -DNPVP_WIDE_ABL=1); never set
+        # by the product build
+        cmd = [hipcc] + FLAGS + os.environ.get("NPVP_HIPCC_EXTRA", "").split() + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -38,30 +38,86 @@ __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx,
 // ---- epilogue of ONE 32x32 accumulator whose top-left element is (row0, col0): the C/D map of the 32x32 MFMA is
 // col = lane&31 (= r), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (= h).
 // order: *alpha +bias -> aux_out (pre-activation copy) -> act -> dropout -> +residual -> (+= C when accumulating)
+// Every option is a wave-uniform flag tested ONCE per tile around a straight 16-element loop (the first version tested
+// them per element: ~170 instructions and 13 branches per output element, a 22 000-line epilogue that ran at 1.4 TB/s and
+// cost 40 % of a K = 512 GEMM).  CHECK = false: the tile lies inside the matrix, no per-element bounds tests.
+template <bool CHECK>
+__device__ __forceinline__ void epilogue_tile_impl(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h,
+                                                   int z, unsigned long long seed) {
+  const int col = col0 + r, rowb = row0 + 4 * h;
+  if (CHECK && col >= p.N) return;
+#define NPVP_RD(g) (((g) & 3) + 8 * ((g) >> 2))
+#define NPVP_INB(g) (!CHECK || rowb + NPVP_RD(g) < p.M)
+  const long long base = (long long)rowb * p.ldc + col;
+  const long long ld = p.ldc;
+  float* cp = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll) + base;
+  if (p.splits > 1) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cp[NPVP_RD(g) * ld] = acc[g];
+    return;
+  }
+  const float bv = p.bias ? p.bias[col] : 0.f;
+  float v[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) v[g] = acc[g] * p.alpha + bv;
+  if (p.aux_out) {
+    float* ap = p.aux_out + base;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) ap[NPVP_RD(g) * ld] = v[g];
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = gelu_f(v[g]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = fmaxf(v[g], 0.f);
+  } else if (p.act == 3 || p.act == 4) {
+    const float* ip = p.aux_in + base;
+    float u[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) u[g] = NPVP_INB(g) ? ip[NPVP_RD(g) * ld] : 0.f;
+    if (p.act == 3) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v[g] *= gelu_grad_f(u[g]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v[g] = u[g] > 0.f ? v[g] : 0.f;
+    }
+  }
+  if (p.drop.thresh) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] *= drop_spec_scale(p.drop, seed, rowb + NPVP_RD(g), col, p.N);
+  }
+  if (p.residual) {
+    const float* rp = p.residual + (long long)rowb * p.ldr + col;
+    const long long lr = p.ldr;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) v[g] += rp[NPVP_RD(g) * lr];
+  }
+  if (p.accum) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) v[g] += cp[NPVP_RD(g) * ld];
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cp[NPVP_RD(g) * ld] = v[g];
+#undef NPVP_INB
+#undef NPVP_RD
+}
+
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h, int z,
                                               unsigned long long seed) {
-  const int col = col0 + r;
-  if (col >= p.N) return;
-  float* Cz = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll);
-  const float bv = (p.bias && p.splits == 1) ? p.bias[col] : 0.f;
+  // fast path: a tile inside the matrix with a bias-only epilogue (most forward and all plain dgrad GEMMs)
+  const bool simple = p.splits == 1 && !p.aux_out && p.act == 0 && !p.drop.thresh && !p.residual && !p.accum;
+  if (simple && row0 + 32 <= p.M && col0 + 32 <= p.N) {
+    const int col = col0 + r;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    float* cp = p.C + (long long)(row0 + 4 * h) * p.ldc + col;
+    const long long ld = p.ldc;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-    if (row >= p.M) continue;
-    const long long idx = (long long)row * p.ldc + col;
-    float v = acc[g];
-    if (p.splits > 1) { Cz[idx] = v; continue; }
-    v = v * p.alpha + bv;
-    if (p.aux_out) p.aux_out[idx] = v;
-    if (p.act == 1) v = gelu_f(v);
-    else if (p.act == 2) v = fmaxf(v, 0.f);
-    else if (p.act == 3) v *= gelu_grad_f(p.aux_in[idx]);
-    else if (p.act == 4) v = p.aux_in[idx] > 0.f ? v : 0.f;
-    if (p.drop.thresh) v *= drop_spec_scale(p.drop, seed, row, col, p.N);
-    if (p.residual) v += p.residual[(long long)row * p.ldr + col];
-    if (p.accum) v += Cz[idx];
-    Cz[idx] = v;
+    for (int g = 0; g < 16; ++g) cp[((g & 3) + 8 * (g >> 2)) * ld] = acc[g] * p.alpha + bv;
+    return;
   }
+  epilogue_tile_impl<true>(p, acc, row0, col0, r, h, z, seed);
 }
 
 // Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
@@ -136,7 +192,7 @@ inline int pick_colgroups(long long b_bytes, int tiles_m, int tiles_n) {
   return 1;
 }
 
-// gemm_wide.hip: 256 x 256 tile, 8 waves, A = fp32 [M][K] split on the fly, B = pre-split planes.  Returns true if it
+// gemm_wide.hip: 128 x 256 tile, 4 waves, A = fp32 [M][K] split on the fly, B = pre-split planes.  Returns true if it
 // took the launch (shape / operand requirements met), false if the caller should use the 128 x 128 kernel.
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream);
 

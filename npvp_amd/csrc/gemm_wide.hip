@@ -7,36 +7,45 @@
 //
 // Why a second kernel.  In the 128 x 128 kernel (gemm.hip) a K-step of 24 MFMAs per wave carries the split VALU and the
 // ds_write of BOTH operands, 12 fragment reads, a barrier - the matrix pipe ends up ~1/3 busy.  Here a workgroup is
-// 8 waves (2 per SIMD) on a 256 x BN tile (BN = 256: waves 2 x 4, each 128 x 64 = 4 x 2 accumulators of 32 x 32;
-// BN = 128: waves 4 x 2, each 64 x 64), K-step 16, two LDS stages:
+// 4 waves (one per SIMD) on a 128 x 256 tile (waves 2 x 2, each 64 x 128 = 2 x 4 accumulators of 32 x 32), K-step 16,
+// two LDS stages of 36.4 KB -> TWO independent workgroups per CU (2 waves per SIMD, 256 VGPRs each):
 //   * B never touches a VGPR or the VALU: its planes are laid out in HBM exactly like the LDS image, so a K-step's B tile
-//     is 6 slabs of BN x 16 B that global_load_lds (LDS-DMA, 16 B per lane) copies straight into LDS;
+//     is 6 slabs of 256 x 16 B that global_load_lds (LDS-DMA, 16 B per lane) copies straight into LDS;
 //   * A: 2 float4 loads per thread and K-step (a row's 64 B by 4 lanes), split into 3 bf16 terms in registers, 6
-//     ds_write_b64 - half the staging work per MFMA of the 128 x 128 kernel, and per wave 48 (BN = 256) MFMAs per
-//     barrier instead of 24;
-//   * fragment reads per MFMA: 18 / 48 (BN = 256) instead of 12 / 24.
+//     ds_write_b64 - half the staging work per MFMA of the 128 x 128 kernel, and 48 MFMAs per wave and barrier
+//     instead of 24;
+//   * fragment reads per MFMA: 18 / 48 instead of 12 / 24;
+//   * the two workgroups of a CU run out of phase: one's prologue, epilogue (a 128 KB C tile leaves through a 20 GB/s
+//     per-CU share of HBM write bandwidth) and barrier waits sit under the other's MFMAs.  (First version: ONE 8-wave
+//     workgroup per CU on a 256 x 256 tile - per-tile fixed cost 32-38 us against 39 us per 512 of K: 120 TF at K = 512.)
 // LDS image per operand and term: [k-group of 8][row][8 k] bf16, one conflict-free ds_read_b128 per MFMA fragment (lanes
 // 0-31 = rows of k-group 0, lanes 32-63 = k-group 1).  The A k-groups are skewed by 64 B so that the 16-lane groups of a
 // ds_write_b64 (4 rows x 4 k-quads) cover all 32 banks once.
 #include "gemm.h"
 
-namespace npvp {
+// measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_WIDE_ABL=n on the GPU box; results INVALID): 1 = epilogue without its
+// global stores, 2 = no K loop
+#ifndef NPVP_WIDE_ABL
+#define NPVP_WIDE_ABL 0
+#endif
 
-constexpr int WIDE_THREADS = 512;
+namespace npvp {
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int TM, int TN, int WM, int WN, bool ROWSTATS>
-__global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(GemmParams p) {
+  constexpr int NW = WM * WN, THREADS = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static_assert(BM == 256 && WM * WN == 8, "8 waves on a 256-row tile");
+  constexpr int APASS = BM / (THREADS / 4);           // float4 loads per thread and K-step (rows of THREADS/4 per pass)
+  static_assert(APASS == 2 && BN % 64 == 0, "A staging is written for two row passes");
   constexpr int KGS_A = BM * 16 + 64, A_PLANE = 2 * KGS_A, A_BYTES = 3 * A_PLANE;
   constexpr int KGS_B = BN * 16, B_PLANE = 2 * KGS_B, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int CPS = BN / 64;                       // 1 KB glds chunks per (term, k-group) slab
-  constexpr int NCHUNK = 6 * CPS, CPW = (NCHUNK + 7) / 8;
+  constexpr int NCHUNK = 6 * CPS, CPW = (NCHUNK + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
   int tile_m, tile_n;
@@ -54,18 +63,18 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  // ---- A staging: thread -> (rows rl and rl + 128, k-quad); rows past the edge are clamped (they only feed output rows
+  // ---- A staging: thread -> (rows rl and rl + BM/2, k-quad); rows past the edge are clamped (they only feed output rows
   // that are never stored)
   const int quad = t & 3, rl = t >> 2;
   const float* a_src0 = p.A + (long long)min(m0 + rl, p.M - 1) * p.lda + 4 * quad;
-  const float* a_src1 = p.A + (long long)min(m0 + rl + 128, p.M - 1) * p.lda + 4 * quad;
+  const float* a_src1 = p.A + (long long)min(m0 + rl + BM / 2, p.M - 1) * p.lda + 4 * quad;
   const int a_dst = (quad >> 1) * KGS_A + (quad & 1) * 8 + rl * 16;
-  // ---- B staging: wave -> chunks c = wave + 8 i of the step's 6 slabs
+  // ---- B staging: wave -> chunks c = wave + NW i of the step's 6 slabs
   const uint4* b_src[CPW];
   int b_dst[CPW];
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
-    const int c = wave + 8 * i;
+    const int c = wave + NW * i;
     const int slab = c / CPS, part = c - slab * CPS, s = slab >> 1, kg = slab & 1;
     const int col = min(n0 + part * 64 + lane, p.N - 1);
     b_src[i] = reinterpret_cast<const uint4*>(p.b_pre) + (long long)s * (p.b_pre_plane >> 3) + (long long)kg * p.N + col;
@@ -91,14 +100,14 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
 #define NPVP_W_BLOAD(ST, KT)                                                             \
   { const long long ko_ = (long long)min((KT), nk - 1) * b_step;                         \
     _Pragma("unroll") for (int i_ = 0; i_ < CPW; ++i_)                                   \
-      if (wave + 8 * i_ < NCHUNK)                                                        \
+      if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK)                                                    \
         __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i_] + ko_), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
 
   // prologue: tile 0 -> stage 0, A tile 1 -> registers
   NPVP_W_BLOAD(lds, 0)
   NPVP_W_ALOAD(0)
   NPVP_W_ASTORE(lds, ra0, 0)
-  NPVP_W_ASTORE(lds, ra1, 128 * 16)
+  NPVP_W_ASTORE(lds, ra1, (BM / 2) * 16)
   NPVP_W_ALOAD(1)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
       if (i_ == 0) NPVP_W_ASTORE(nx_, ra0, 0)                                                              \
       /* the loads of A tile KT+2 go out here, a quarter into the step (pinned: the scheduler would sink them to the */ \
       /* end of the step, right in front of the wait) */                                                   \
-      if (i_ == 1) { NPVP_W_ASTORE(nx_, ra1, 128 * 16) NPVP_W_ALOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); } \
+      if (i_ == 1) { NPVP_W_ASTORE(nx_, ra1, (BM / 2) * 16) NPVP_W_ALOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); } \
       /* smallest terms first */                                                                           \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[1], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[0], fb_[2][j_], acc[i_][j_], 0, 0, 0); \
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
-  int kt = 0;
+  int kt = (NPVP_WIDE_ABL & 2) ? nk : 0;
   for (; kt + 1 < nk; kt += 2) {
     NPVP_W_STEP(kt, 0, 1)
     NPVP_W_STEP(kt + 1, 1, 0)
@@ -149,11 +158,22 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
 #undef NPVP_W_ALOAD
 
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (NPVP_WIDE_ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    return;
+  }
+#endif
   if constexpr (ROWSTATS) {
-    static_assert(!ROWSTATS || (TN == 2 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
+    static_assert(!ROWSTATS || (TN % 2 == 0 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
 #pragma unroll
     for (int i = 0; i < TM; i += 2)
-      epilogue_rowstats_block(p, acc[i][0], acc[i][TN - 1], acc[i + 1][0], acc[i + 1][TN - 1], row_base + i * 32, col_base, r, h);
+#pragma unroll
+      for (int j = 0; j < TN; j += 2)
+        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, r, h);
   } else {
     const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
 #pragma unroll
@@ -163,39 +183,27 @@ __global__ __launch_bounds__(WIDE_THREADS, 2) void gemm_wide_kernel(GemmParams p
   }
 }
 
-// Which tiling for an [M, N] output: estimated time = rounds over the 256 CUs x relative cost of one round.  A wide
-// workgroup owns its CU (148 KB / 98 KB... LDS); the 128 x 128 kernel runs 3 workgroups per CU, each at a third of the CU.
-// eff = measured relative MFMA throughput of the three kernels on full rounds (256 x 256 = 1).
-static int pick_wide(int M, int N) {
-  const double CUS = 256.0;
-  auto rounds = [&](double tiles, double per_cu) { return (double)(long long)((tiles + CUS * per_cu - 1) / (CUS * per_cu)); };
-  const double t256 = ((M + 255) / 256) * (double)((N + 255) / 256), t128w = ((M + 255) / 256) * (double)((N + 127) / 128);
-  const double t128 = ((M + 127) / 128) * (double)((N + 127) / 128);
-  const double c256 = rounds(t256, 1) * 1.0 / 1.00;
-  const double c128w = rounds(t128w, 1) * 0.5 / 0.90;
-  const double c128 = rounds(t128, 3) * 0.75 / 0.72;
-  if (c256 <= c128w && c256 <= c128) return 256;
-  if (c128w <= c128) return 128;
-  return 0;
+// Which kernel for an [M, N] output: estimated time = rounds over the CUs x relative cost of one round.  The wide kernel
+// runs 2 workgroups of 128 x 256 per CU, the 128 x 128 kernel 3 per CU; eff = measured relative MFMA throughput on full rounds.
+static bool wide_pays(int M, int N) {
+  auto rounds = [](double tiles, double slots) { return (double)(long long)((tiles + slots - 1) / slots); };
+  const double tw = ((M + 127) / 128) * (double)((N + 255) / 256), t128 = ((M + 127) / 128) * (double)((N + 127) / 128);
+  const double cw = rounds(tw, 512) * 2.0 / 1.00;
+  const double c128 = rounds(t128, 768) * 1.5 / 0.80;
+  return cw <= c128;
 }
 
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream) {
-  if (!p.b_pre || p.splits != 1 || (p.K & 15) || (p.N & 7) || p.colsum || p.M < 256) return false;
+  if (!p.b_pre || p.splits != 1 || (p.K & 15) || (p.N & 7) || p.colsum || p.M < 128) return false;
   if (((uintptr_t)p.b_pre & 15) != 0) return false;
-  int bn = pick_wide(p.M, p.N);
   if (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0)) return false;
-  if (bn == 0) return false;
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + bn - 1) / bn;
+  if (!wide_pays(p.M, p.N)) return false;
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 255) / 256;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 6, p.tiles_m, p.tiles_n);
-  dim3 grid(p.tiles_m * p.tiles_n), block(WIDE_THREADS);
-  if (bn == 256) {
-    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<4, 2, 2, 4, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_wide_kernel<4, 2, 2, 4, false>), grid, block, 0, stream, p);
-  } else {
-    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 4, 2, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 4, 2, false>), grid, block, 0, stream, p);
-  }
+  dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
   return true;
 }
 
