@@ -457,10 +457,12 @@ static int pick_splits(int M, int N, int K) {
 
 using namespace npvp;
 
-// split-K partial slabs [splits][M][N] followed by the column-sum partials [splits][M]
+// split-K partial slabs [splits][M][N] followed by the column-sum partials [splits][M]: the larger of what the 128 x 128
+// kernel and the wide weight-gradient kernel would use for this shape
 extern "C" long long npvp_gemm_workspace_bytes(int M, int N, int K) {
-  const int s = pick_splits(M, N, K);
-  return s > 1 ? ((long long)s * M * N + (long long)s * M) * 4 : 0;
+  const int s = pick_splits(M, N, K), sw = wide_wgrad_splits(M, N, K);
+  const int m = s > sw ? s : sw;
+  return m > 1 ? ((long long)m * M * N + (long long)m * M) * 4 : 0;
 }
 
 // w [N][K] fp32 -> bf16 planes (3 terms each): F for y = x w^T (B operand [N][K]), D for dx = dy w (B operand [K][N]).
@@ -524,6 +526,16 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     return NPVP_OK;
   }
 
+  // weight gradients (dW = dy^T x): 128 x 256 tiles, row-major staging + transposing LDS reads (gemm_wide.hip)
+  bool wide_wgrad = false;
+  if (precision == 4 && !a_kc && !b_kc && plain && !rowstats && N % 4 == 0 && M % 4 == 0) {
+    const int sw = wide_wgrad_splits(M, N, K);
+    if (sw == 1 || (sw > 1 && workspace && ws_bytes >= ((long long)sw * M * N + (long long)sw * M) * 4)) {
+      wide_wgrad = true;
+      splits = sw; p.splits = sw;
+    }
+  }
+
   p.colgroups = splits == 1 ? pick_colgroups((long long)N * K * 4, p.tiles_m, p.tiles_n) : 1;
   if (splits > 1) {
     p.K = K / splits; p.C = (float*)workspace; p.ldc = N;
@@ -531,7 +543,9 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   }
 
   dim3 grid(p.tiles_m * p.tiles_n, splits), block(GEMM_THREADS);
-  if (precision == 0) {
+  if (wide_wgrad) {
+    launch_gemm_wgrad_wide(p, splits, stream);
+  } else if (precision == 0) {
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);

@@ -183,6 +183,186 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
   }
 }
 
+// =====================================================================================================
+// Weight gradients on the same wave / tile geometry:  dW[M,N] = A^T B  with  A = dy [K][M], B = x [K][N]  (K = token
+// rows, M = out features, N = in features; both operands "k-major": a K-step's tile is 16 full rows of each matrix).
+//
+// The MFMA fragment of lane (column c, k-half h) is 8 consecutive k of ONE column - strided in memory.  The 128 x 128
+// kernel gathers it with 8 dword loads per (column, k-group); here the tiles are staged ROW-major, exactly as they lie in
+// memory (float4 loads of 512 B / 1 KB rows, 6 per thread and K-step instead of 24 dword loads), split into three bf16
+// planes [16 k][columns], and the fragments are read with ds_read_b64_tr_b16, the LDS transposing read: a 16-lane group
+// reads a 4 k x 16 column block and each lane receives its column's 4 k (two reads per fragment).  Bank conflicts: a
+// 32-lane half reads 4 k-rows x 64 B; rows are 256 / 512 B apart (the same banks), so the 64-B granule index of row k is
+// XORed with k & 3 - on the ds_write side too - and the four rows land in the four bank quadrants.
+// Split-K over blockIdx.y (each K-chunk owned by one XCD), partial tiles to the workspace, column sums of dy (the bias
+// gradient) from the staging registers of the blocks in tile column 0.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 lds_read_tr_pair(const char* a, int second_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + second_off));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_wide_kernel(GemmParams p) {
+  constexpr int NW = WM * WN, THREADS = 64 * NW;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(THREADS == 256 && BM == 128 && BN == 256, "staging maps are written for 256 threads on a 128 x 256 tile");
+  constexpr int ROWA = BM * 2, ROWB = BN * 2;                       // bytes per k-row of a plane
+  constexpr int A_PLANE = 16 * ROWA, B_PLANE = 16 * ROWB, A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+  // ---- (K-chunk z, tile): with splits % 8 == 0 chunk z is owned by XCD z % 8 (its tiles share each row block in ONE L2)
+  int z, tl;
+  {
+    const int tiles = gridDim.x;
+    if (p.splits > 1 && (p.splits & 7) == 0) {
+      const int lin = blockIdx.x + tiles * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+      const int g = slot / tiles;
+      tl = slot - g * tiles; z = g * 8 + xcd;
+    } else { z = blockIdx.y; tl = blockIdx.x; }
+  }
+  const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* A = p.A + (long long)z * p.K * p.lda;
+  const float* B = p.B + (long long)z * p.K * p.ldb;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+  const int nk = p.K >> 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  // ---- staging maps.  A: float4 f = t, t + 256 -> k-row t >> 5 (+8), column quad t & 31.  B: f = t + 256 i -> k-row
+  // (t >> 6) + 4 i, column quad t & 63.  Columns past the edge are clamped (they feed outputs that are never stored).
+  const int ka = t >> 5, cqa = t & 31, kb = t >> 6, cqb = t & 63;
+  const float* a_src = A + (long long)ka * p.lda + min(m0 + 4 * cqa, p.M - 4);
+  const float* b_src = B + (long long)kb * p.ldb + min(n0 + 4 * cqb, p.N - 4);
+  const long long a_row8 = 8 * p.lda, b_row4 = 4 * p.ldb, a_step = 16 * p.lda, b_step = 16 * p.ldb;
+  const int a_dst = ka * ROWA + ((8 * cqa) ^ ((ka & 3) << 6));
+  const int b_dst = A_BYTES + kb * ROWB + ((8 * cqb) ^ ((kb & 3) << 6));
+  // ---- fragment addresses (transposing reads): 16-lane group G -> k-half h = G >> 1, columns 16 (G & 1) ..+15; lane
+  // 4 q + pp of the group supplies k-row 8 h + q, columns 4 pp ..+3
+  const int q = (lane >> 2) & 3, pp = lane & 3, cg = 16 * ((lane >> 4) & 1) + 4 * pp;
+  int fa[TM], fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i] = (8 * h + q) * ROWA + (((wm * TM * 32 + i * 32 + cg) * 2) ^ (q << 6));
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j] = A_BYTES + (8 * h + q) * ROWB + (((wn * TN * 32 + j * 32 + cg) * 2) ^ (q << 6));
+
+  const bool want_cs = p.colsum && tile_n == 0;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[2], rb[4];
+#define NPVP_G_LOAD(KT)                                                                                     \
+  { const int kt_ = min((KT), nk - 1);                                                                      \
+    const float* pa_ = a_src + (long long)kt_ * a_step; const float* pb_ = b_src + (long long)kt_ * b_step; \
+    ra[0] = *reinterpret_cast<const f32x4*>(pa_); ra[1] = *reinterpret_cast<const f32x4*>(pa_ + a_row8);    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) rb[i_] = *reinterpret_cast<const f32x4*>(pb_ + i_ * b_row4); }
+#define NPVP_G_STORE(DST, V, PLANE)                                                                         \
+  { f32x4 v_ = (V);                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                                      \
+      bf16x4 q_;                                                                                            \
+      q_[0] = (__bf16)v_[0]; q_[1] = (__bf16)v_[1]; q_[2] = (__bf16)v_[2]; q_[3] = (__bf16)v_[3];           \
+      *reinterpret_cast<bf16x4*>((DST) + s_ * (PLANE)) = q_;                                                \
+      v_[0] -= (float)q_[0]; v_[1] -= (float)q_[1]; v_[2] -= (float)q_[2]; v_[3] -= (float)q_[3];           \
+    } }
+#define NPVP_G_STORE_A(ST) { NPVP_G_STORE((ST) + a_dst, ra[0], A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], A_PLANE) }
+#define NPVP_G_STORE_B(ST, I) NPVP_G_STORE((ST) + b_dst + (I) * 4 * ROWB, rb[I], B_PLANE)
+
+  NPVP_G_LOAD(0)
+  if (want_cs) cs += ra[0] + ra[1];
+  NPVP_G_STORE_A(lds)
+  NPVP_G_STORE_B(lds, 0) NPVP_G_STORE_B(lds, 1) NPVP_G_STORE_B(lds, 2) NPVP_G_STORE_B(lds, 3)
+  NPVP_G_LOAD(1)
+  __syncthreads();
+
+#define NPVP_G_STEP(KT, CUR, NXT)                                                                            \
+  {                                                                                                          \
+    const char* st_ = lds + (CUR) * STAGE;                                                                   \
+    char* nx_ = lds + (NXT) * STAGE;                                                                         \
+    if (want_cs && (KT) + 1 < nk) cs += ra[0] + ra[1];                                                       \
+    bf16x8 fa_[TM][3];                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) fa_[i_][s_] = lds_read_tr_pair(st_ + fa[i_] + s_ * A_PLANE, 4 * ROWA); \
+    _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) {                                                      \
+      bf16x8 fb_[3];                                                                                         \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) fb_[s_] = lds_read_tr_pair(st_ + fb[j_] + s_ * B_PLANE, 4 * ROWB); \
+      if (j_ == 0) { NPVP_G_STORE_A(nx_) NPVP_G_STORE_B(nx_, 0) }                                            \
+      if (j_ == 1) { NPVP_G_STORE_B(nx_, 1) NPVP_G_STORE_B(nx_, 2) NPVP_G_STORE_B(nx_, 3)                    \
+                     NPVP_G_LOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); }                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][1], fb_[1], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][0], fb_[2], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][2], fb_[0], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][0], fb_[1], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][1], fb_[0], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i_][0], fb_[0], acc[i_][j_], 0, 0, 0); \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+  }
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    NPVP_G_STEP(kt, 0, 1)
+    NPVP_G_STEP(kt + 1, 1, 0)
+  }
+  if (kt < nk) NPVP_G_STEP(kt, 0, 1)
+#undef NPVP_G_STEP
+#undef NPVP_G_STORE_B
+#undef NPVP_G_STORE_A
+#undef NPVP_G_STORE
+#undef NPVP_G_LOAD
+
+  if (want_cs) {          // the 8 threads with the same column quad (t & 31) hold partial sums: fixed-order reduction in LDS
+    float* red = reinterpret_cast<float*>(lds);
+    *reinterpret_cast<f32x4*>(red + (t >> 5) * 128 + cqa * 4) = cs;
+    __syncthreads();
+    if (t < 128 && m0 + t < p.M) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += red[i * 128 + t];
+      store_colsum(p, (long long)z * p.M + m0 + t, sum);
+    }
+  }
+  const unsigned long long seed = 0ull;
+  const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, z, seed);
+}
+
+// split count of the wide weight-gradient kernel: ~512 workgroups (2 per CU), >= 16 K-steps per split
+int wide_wgrad_splits(int M, int N, int K) {
+  // 0 = not taken.  Below ~32 K token rows the 128 x 128 kernel (3 workgroups per CU, finer tiles) is as fast or faster:
+  // measured 168 vs 166 TF at 20 480 rows, 144 vs 134 TF at 8 192 rows, 179 vs 189 TF at 114 688 rows.
+  if ((K & 15) || M < 64 || N < 128 || K < 32768) return 0;
+  const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
+  int s = (512 + tiles - 1) / tiles;
+  const int maxs = K / 256;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  if (s >= 8) s &= ~7;                                         // multiples of 8: one K-chunk per XCD
+  while (s > 1 && (K % (s * 16)) != 0) --s;
+  return s < 1 ? 1 : s;
+}
+
+bool launch_gemm_wgrad_wide(GemmParams& p, int splits, hipStream_t stream) {
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 255) / 256;
+  dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+  hipLaunchKernelGGL((gemm_wgrad_wide_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
+  return true;
+}
+
 // Which kernel for an [M, N] output: estimated time = rounds over the CUs x relative cost of one round.  The wide kernel
 // runs 2 workgroups of 128 x 256 per CU, the 128 x 128 kernel 3 per CU; eff = measured relative MFMA throughput on full rounds.
 static bool wide_pays(int M, int N) {
