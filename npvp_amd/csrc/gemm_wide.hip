@@ -214,7 +214,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_wide_k
   constexpr int ROWA = BM * 2, ROWB = BN * 2;                       // bytes per k-row of a plane
   constexpr int A_PLANE = 16 * ROWA, B_PLANE = 16 * ROWB, A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  // Weight gradients run on the low-priority gradient stream UNDER the critical path.  Two of these workgroups would take
+  // a whole CU (2 x 4 waves x 256 VGPRs, 2 x 72 KB LDS) for ~1 ms each and starve the critical-path kernel that arrives
+  // meanwhile.  The LDS allocation is padded to 84 KB: only ONE weight-gradient workgroup fits a CU, and beside it there
+  // is room for one forward / dgrad workgroup (74.5 KB LDS, 4 waves x 256 VGPRs) or for the low-register waves of the
+  // HBM-bound kernels.  NPVP_WGRAD_LDS_PAD=0 (measurement builds) restores two per CU.
+#ifndef NPVP_WGRAD_LDS_PAD
+#define NPVP_WGRAD_LDS_PAD 1
+#endif
+  constexpr int LDS_BYTES = NPVP_WGRAD_LDS_PAD ? 86016 : 2 * STAGE;
+  static_assert(LDS_BYTES >= 2 * STAGE, "stages must fit");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
   // ---- (K-chunk z, tile): with splits % 8 == 0 chunk z is owned by XCD z % 8 (its tiles share each row block in ONE L2)
   int z, tl;

@@ -66,6 +66,11 @@ class GradSync:
     def __init__(self, buf, bucket_bytes=64 << 20, group=None):
         self.buf, self.group = buf, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        from . import ops
+        if self.world > 1 and ops.AuxStream.enabled:
+            # a bucket's all-reduce is ordered after the compute stream and the gradient stream only: contributions
+            # produced on the auxiliary encoder stream (NPVP_DUAL_ENCODER=1) could land after it
+            raise RuntimeError("GradSync: NPVP_DUAL_ENCODER=1 (two-stream encoder passes) is not supported under data parallelism")
         self.cuda = buf.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.cuda else None
         # contiguous buckets over the flat buffer, each owning whole parameters
@@ -109,8 +114,9 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
             from . import ops
-            if ops.WgradStream._pending is not None:        # weight gradients are accumulated on their own stream
-                self.side.wait_stream(ops.WgradStream._pending[1])
+            gs = ops.WgradStream.pending_stream()           # weight gradients are accumulated on their own stream
+            if gs is not None:
+                self.side.wait_stream(gs)
             with torch.cuda.stream(self.side):
                 g.mul_(1.0 / self.world)
                 b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -132,8 +138,25 @@ class GradSync:
                 if self.expected[id(p)] > 0:
                     self.buckets[self.param_bucket[id(p)]]["n"] += 1
         elif self.count != self.expected:
+            # a different graph ran (e.g. an eval-mode forward with gradients, or other parameters in use): buckets may
+            # have been reduced before their last contribution.  Drain what is in flight and reset so that the NEXT step
+            # re-learns the counts, then fail loudly - this step's gradients are not trustworthy.
+            for b in self.buckets:
+                if b["work"] is not None:
+                    if self.cuda:
+                        with torch.cuda.stream(self.side):
+                            b["work"].wait()
+                    else:
+                        b["work"].wait()
+                b["work"], b["ready"] = None, 0
+            for k in self.count:
+                self.count[k] = 0
+            self.expected = None
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.side)
             raise RuntimeError("GradSync: the per-parameter gradient contribution counts changed between steps "
-                               "(a bucket may have been reduced before its last contribution)")
+                               "(a bucket may have been reduced before its last contribution); state was reset, call "
+                               "relearn() before changing the training graph on purpose")
         for k in self.count:
             self.count[k] = 0
         for b in self.buckets:
@@ -149,12 +172,36 @@ class GradSync:
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def relearn(self):
+        """Call before a step whose autograd graph differs from the previous one (e.g. a random-context batch with a
+        different number of context frames does NOT change it - parameter use is the same - but switching the predictor
+        between NPVP-S training with / without ground truth does): the next step reduces everything in finish() and
+        learns the new contribution counts."""
+        self.expected = None
+        for k in self.count:
+            self.count[k] = 0
+        for b in self.buckets:
+            b["ready"] = 0
+
     def remove(self):
         for h in self._handles:
             h.remove()
         from . import ops
         if ops.GradSink.listener == self._hook:
             ops.GradSink.listener = None
+
+
+_SYNCBN_GROUP = None
+
+
+def syncbn_group():
+    """The EventEncoder's SyncBatchNorm statistics travel on their OWN communicator: on the gradient communicator the tiny,
+    latency-critical [sum, sum_sq, n] all-reduces of the forward pass would queue behind 64 MB bucket reductions that are
+    still in flight from the previous step's tail / this step's backward."""
+    global _SYNCBN_GROUP
+    if _SYNCBN_GROUP is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _SYNCBN_GROUP = dist.new_group(ranks=list(range(dist.get_world_size())))
+    return _SYNCBN_GROUP
 
 
 class _SyncBNFn(torch.autograd.Function):
@@ -208,11 +255,13 @@ class SyncBatchNorm2d(nn.BatchNorm2d):
         if self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         return _SyncBNFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
-                               True, None)
+                               True, syncbn_group())
 
 
 def convert_sync_batchnorm(module):
-    """Swap every nn.BatchNorm2d under `module` for SyncBatchNorm2d in place (parameters and buffers are shared)."""
+    """Swap every nn.BatchNorm2d under `module` for SyncBatchNorm2d in place (parameters and buffers are shared).
+    Collective on first use: every rank must call it (it creates the SyncBatchNorm process group)."""
+    syncbn_group()
     for name, child in list(module.named_children()):
         if type(child) is nn.BatchNorm2d:
             new = SyncBatchNorm2d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)

@@ -89,8 +89,40 @@ class Drop:
     def on(self):
         return self.p > 0.0
 
+    @classmethod
+    def _like(cls, other, mode, g1, g2):
+        """same probability and salt (= same mask stream), other keying geometry"""
+        d = cls.__new__(cls)
+        d.p, d.mode, d.g1, d.g2, d.salt = other.p, mode, g1, g2, other.salt
+        return d
+
 
 NO_DROP = Drop(0.0)
+
+
+class DropRecorder:
+    """Test hook: while `sites` is a list, every forward kernel that applies a dropout / drop-path mask appends
+    (Drop, kind, count) - kind "elem": one decision per flat element index 0..count-1 (nn.Dropout sites and the
+    attention-probability dropout, whose key is the flat index of the [groups, heads, L, S] weights); kind "group": one
+    decision per row group 0..count-1 (DropPath).  `mask(site)` replays the site's mask through npvp_drop_apply on ones,
+    so a parity test can inject the very masks the kernels drew into the oracle (tests/test_hip_dropout.py)."""
+    sites = None
+
+    @classmethod
+    def note(cls, drop, kind, count):
+        if cls.sites is not None and drop.on:
+            cls.sites.append((drop, kind, int(count)))
+
+    @staticmethod
+    def mask(site, dev):
+        """the site's keep-scale per decision (0 or 1/(1-p)) as a flat tensor, from the current device seed"""
+        drop, kind, count = site
+        if kind == "elem":
+            pad = (-count) % 4
+            ones = torch.ones((count + pad) // 4, 4, dtype=torch.float32, device=dev)
+            return drop_apply(ones, Drop._like(drop, 0, 1, 1)).reshape(-1)[:count]
+        ones = torch.ones(count, 4, dtype=torch.float32, device=dev)          # group g = row g (g1 = 1, g2 = count)
+        return drop_apply(ones, Drop._like(drop, 1, 1, count))[:, 0].contiguous()
 
 
 # GEMM arithmetic (NPVP_GEMM=bf16x6|f32), fp32 accumulation on the matrix cores:
@@ -261,6 +293,17 @@ class AuxStream:
         return cls._streams[key]
 
 
+class DecoderSplit:
+    """EXPERIMENT (NPVP_DECODER_SPLIT=1, off by default): run the decoder on two half-batches on two streams
+    (npvp_amd.models.Predictor._decode)."""
+    enabled = os.environ.get("NPVP_DECODER_SPLIT", "0") == "1"
+    min_rows = int(os.environ.get("NPVP_DECODER_SPLIT_MIN_ROWS", "32768"))
+
+    @classmethod
+    def wanted(cls, N, T):
+        return cls.enabled and N >= 2 and N % 2 == 0 and (N // 2) * T * 64 >= cls.min_rows and torch.is_grad_enabled()
+
+
 class WgradStream:
     """Weight-gradient GEMMs run on a SECOND HIP stream.  In backward a layer's dgrad feeds the next layer, but its
     wgrad feeds nobody until the optimiser: when it is accumulated in place (GradSink) it has no consumer in the
@@ -302,6 +345,12 @@ class WgradStream:
             torch.autograd.Variable._execution_engine.queue_callback(cls.join)
 
     @classmethod
+    def pending_stream(cls):
+        """the gradient stream if this backward pass has work in flight on it, else None (npvp_amd.dp orders a bucket's
+        all-reduce after it)"""
+        return cls._pending[1] if cls._pending is not None else None
+
+    @classmethod
     def join(cls):
         """the caller's current stream waits for the gradient stream (the autograd engine runs its final callbacks
         under the streams that were current when backward() was called)"""
@@ -313,7 +362,9 @@ class WgradStream:
 
 # --------------------------------------------------------------------------- raw kernel wrappers
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None):
+         drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None,
+         replay=False):
+    """replay=True: `drop` replays a forward site's mask in backward (not a new site for ops.DropRecorder)"""
     _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
     wsb = L.npvp_gemm_workspace_bytes(M, N, K)
@@ -321,6 +372,8 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
     seed = rng.seed_tensor(A.device) if drop.on else None
+    if DropRecorder.sites is not None and not replay:
+        DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
     # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
     probe = GemmProbe.armed
@@ -359,7 +412,7 @@ def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
     K = w.shape[1]
     dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
     return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop,
-                b_pre=WeightPlanes.get(w, "D") if R >= 256 else None)
+                b_pre=WeightPlanes.get(w, "D") if R >= 256 else None, replay=True)
 
 
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None):
@@ -738,6 +791,10 @@ class AttnCfg:
 def _attn_fwd(q, k, v, o, cfg):
     hd = o.shape[1] // cfg.heads
     seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    if DropRecorder.sites is not None and cfg.drop.on:      # weights tensor [groups, heads, L, S]
+        L_, S_ = (cfg.ws * cfg.ws, cfg.ws * cfg.ws) if cfg.mode == 0 else (cfg.Tq, cfg.Tk)
+        groups = cfg.dim0 * (cfg.P // (cfg.ws * cfg.ws)) if cfg.mode == 0 else cfg.dim0 * cfg.P
+        DropRecorder.note(cfg.drop, "elem", groups * cfg.heads * L_ * S_)
     check(lib().npvp_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
                               cfg.mode, cfg.dim0, cfg.P, cfg.W, cfg.ws, cfg.Tq, cfg.Tk, cfg.heads, hd, cfg.mask_mode,
                               cfg.drop.p, _ptr(seed), cfg.drop.salt, _stream()), "npvp_attn_fwd")
@@ -820,6 +877,8 @@ class _FrameLnAct(torch.autograd.Function):
             rstd = torch.empty_like(mean)
             check(L.npvp_frame_stats(_ptr(h), _p(0), _ptr(mean), _ptr(rstd), frames, 1, PF, 1e-5, _stream()), "npvp_frame_stats")
         d, dp = Drop(p_drop), Drop(p_dp, 1)
+        DropRecorder.note(d, "elem", h.numel())
+        DropRecorder.note(dp, "group", frames // max(1, frames_per_sample))
         out = torch.empty_like(h)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
         check(L.npvp_frameln_act_fwd(_ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(res_c), _ptr(out), frames,

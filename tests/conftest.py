@@ -13,6 +13,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """`-m gpu` sessions: start the 2-rank data-parallel rehearsal (tools/dp_check.py) NOW, before this process initialises
+    the GPU (torch.cuda.device_count() does not), and let tests/test_dp_gpu.py collect it.  3 GPU processes in all."""
+    import subprocess
+    import tempfile
+    config = session.config
+    config._npvp_dp_job = None
+    mark = config.getoption("-m") or ""
+    if "gpu" not in mark or "not gpu" in mark or os.environ.get("NPVP_SKIP_DP_TEST"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    log = tempfile.NamedTemporaryFile(prefix="npvp_dp_check_", suffix=".log", delete=False)
+    env = dict(os.environ, NPVP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]
+    proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    config._npvp_dp_job = (proc, log.name)
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for."""
     try:

@@ -292,10 +292,11 @@ def _evt_relu_margin(ref, past, fut, stochastic):
     return min(vals)
 
 
-@pytest.mark.parametrize("variant,N,To,Tp,seed0", [("S", 2, 5, 15, 11), ("D", 2, 2, 18, 91)])
+@pytest.mark.parametrize("variant,N,To,Tp,seed0", [("S", 2, 5, 15, 11), ("D", 2, 2, 18, 91), ("D", 1, 2, 28, 91), ("S", 1, 2, 12, 11),
+                                                   ("D", 2, 4, 16, 91), ("S", 1, 10, 10, 11)])
 def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
-    """Full depth (4+8), c0-shaped (S, To=5, Tp=15) and c2'-shaped (D, To=2, Tp=18) clips: HIP vs oracle on
-    the same seeded inputs, forward (train mode, dropout 0) and gradients."""
+    """Full depth (4+8), every BASELINE config's clip shape - c0 (S, 5+15), c2' (D, 2+18), c2 (D, 2+28), c3 (S, 2+12),
+    c4 (D, 4+16), c1 (S, 10+10): HIP vs oracle on the same seeded inputs, forward (train mode, dropout 0) and gradients."""
     import oracle
     stochastic = variant == "S"
     h = torch.linspace(0, 7, 8)
@@ -331,6 +332,38 @@ def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
         e = GC.rel_err(a, b)
         GC.log_err(f"larger_{variant}[{MODE}]", n, e)
         assert e < TOL * 5, f"{n}: {e:.3e} (input seed {seed})"
+
+
+@pytest.mark.parametrize("name,variant,B,To,Tp", [("c2", "D", 64, 2, 28), ("c2p", "D", 64, 2, 18), ("c3 shard", "S", 8, 2, 12),
+                                                  ("c4 shard", "D", 8, 4, 16)])
+def test_full_size_properties_other_configs(impl, name, variant, B, To, Tp):
+    """BASELINE c2 (BAIR NPVP-D, B=64, 2+28), north_star's B=64 T=20 line and the per-GPU shards of c3 / c4 at FULL size,
+    dropout 0.1 / drop-path 0.1 active: training steps run, losses finite and decreasing on a fixed batch, gradients
+    finite, eval output deterministic, non-negative and of the right shape."""
+    if MODE != "bf16x6":
+        pytest.skip("full-size runs use the default arithmetic")
+    torch.manual_seed(0)
+    stochastic = variant == "S"
+    h = torch.linspace(0, 7, 8)
+    m = impl.Predictor(8, 8, To + Tp, h, h, torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp), 512, 'Add', 'layer',
+                       256, 1, stochastic, 8, evt_former=True, learn_evt_token=False, evt_former_num_layers=4).to(DEV)
+    opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer)
+    past, fut = O.synth_features((B, To, 512, 8, 8), 1).to(DEV), O.synth_features((B, Tp, 512, 8, 8), 2).to(DEV)
+    m.train()
+    losses = [impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-8, 1.0)["loss"] for _ in range(3)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(opt.flat_g).all())
+    m.eval()
+    if stochastic:
+        eps = O.seeded_randn((B, 512, 8, 8), 9).to(DEV)
+        m.evt_prior.eps_fn = lambda shape: eps
+    with torch.no_grad():
+        y1, y2 = m(past), m(past)
+    assert torch.equal(y1, y2), "eval forward must be bit-deterministic"
+    assert bool((y1 >= 0).all()) and y1.shape == (B, Tp, 512, 8, 8)
+    del m, opt, past, fut, y1, y2
+    torch.cuda.empty_cache()
 
 
 def test_full_size_properties(impl):

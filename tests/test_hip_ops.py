@@ -267,7 +267,9 @@ def test_attn_spatial(K, frames):
 
 
 @pytest.mark.parametrize("Tq,Tk,mask", [(1, 1, 0), (2, 2, 1), (3, 3, 1), (10, 10, 1), (10, 10, 0), (17, 17, 1), (28, 28, 0),
-                                        (32, 32, 1), (4, 2, 0), (18, 2, 0), (10, 28, 0), (28, 10, 0)])
+                                        (32, 32, 1), (4, 2, 0), (18, 2, 0), (10, 28, 0), (28, 10, 0),
+                                        # the BASELINE configs' decoder / cross shapes: c2 (28,28),(28,2); c3 (12,12),(12,2); c4 (16,16),(16,4)
+                                        (28, 2, 0), (12, 12, 0), (12, 2, 0), (16, 16, 0), (16, 4, 0), (4, 4, 1), (18, 18, 0)])
 def test_attn_temporal_and_cross(K, Tq, Tk, mask):
     from npvp_amd.ops import AttnCfg
     N, P, C = 2, 64, 512

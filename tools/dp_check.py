@@ -1,8 +1,14 @@
 """GPU rehearsal of the data-parallel path with W ranks (gloo or nccl): every rank runs the real HIP training
 step on its shard of a global batch; rank 0 then re-runs the whole batch alone and compares the all-reduced flat
 gradient, the loss and the EventEncoder BatchNorm running statistics (W ranks == 1 rank on the batch).
+Covered: GradSink listener -> GradSync._hook, bucket overlap with backward, the gradient-stream wait, SyncBatchNorm on its
+own communicator, a train -> eval -> train sequence, and random-context batches (Predictor(rand_context=True)) whose
+context / target split changes from step to step.
 
     NPVP_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_check.py
+
+Also run by `pytest -m gpu` (tests/conftest.py starts it before the test process touches the GPU, tests/test_dp_gpu.py
+waits for it): two ranks share the one card of the GPU box over gloo-on-device tensors.
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,13 +23,12 @@ dev = torch.device("cuda", local % torch.cuda.device_count())
 torch.cuda.set_device(dev)
 h = torch.linspace(0, 7, 8)
 To, Tp, B = 3, 4, 2 * world
-args = (8, 8, To + Tp, h, h, torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp), 512, 'Add', 'layer', 256, 1, True, 2)
-kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, dropout=0.0, drop_path=0.0)
-past, fut = O.synth_features((B, To, 512, 8, 8), 1).to(dev), O.synth_features((B, Tp, 512, 8, 8), 2).to(dev)
-eps = O.seeded_randn((B, 512, 8, 8), 3).to(dev)
+T = To + Tp
 
 
-def build(sync):
+def build(sync, rand_context=False):
+    args = (8, 8, T, h, h, torch.linspace(0, To - 1, To), torch.linspace(To, T - 1, Tp), 512, 'Add', 'layer', 256, 1, True, 2)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, dropout=0.0, drop_path=0.0, rand_context=rand_context)
     m = npvp_amd.Predictor(*args, **kw)
     O.key_hashed_fill(m, 5)
     m = m.to(dev).train()
@@ -33,37 +38,82 @@ def build(sync):
     return m
 
 
-def run(m, p, f, e, gsync):
-    m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: e
-    # lr = 0: the parameters stay put, so the gradients of the LATER (overlapped) steps are comparable to 1e-6 -
-    # with lr > 0 AdamW's first updates are ~lr*sign(g) and amplify rounding-level gradient differences
+def steps(m, batches, gsync, eval_between=False):
+    """lr = 0: the parameters stay put, so the gradients of the LATER (overlapped) steps are comparable to 1e-6 - with
+    lr > 0 AdamW's first updates are ~lr*sign(g) and amplify rounding-level gradient differences.  The first step teaches
+    GradSync the per-parameter contribution counts (everything reduced in finish()), the next ones take the overlapped path."""
     opt = npvp_amd.FlatAdamW(m, lr=0.0, clip_module=m.transformer)
     gs = dp.GradSync(opt.buf, bucket_bytes=8 << 20) if gsync else None
-    # 3 steps: the first one teaches GradSync the per-parameter contribution counts (everything reduced in finish()),
-    # the next ones take the overlapped path (buckets reduced while backward is still running)
-    for _ in range(3):
+    out = None
+    for i, (p, f, e, split) in enumerate(batches):
+        m.evt_prior.eps_fn = m.evt_posterior.eps_fn = (lambda shape, e=e: e)
+        if split is not None:
+            npvp_amd.rand_context_batch_process(m, (p, f) + split)
         out = npvp_amd.predictor_train_step(m, opt, p, f, 0.01, 1e-6, 1.0, grad_sync=gs)
+        if eval_between and i == 0:            # train -> eval -> train: an eval forward (no gradients) must not disturb GradSync
+            m.eval()
+            with torch.no_grad():
+                m(p)
+            m.train()
     return opt, out, gs
 
 
-m = build(True)
-opt, out, gs = run(m, dp.shard_batch(past, rank, world), dp.shard_batch(fut, rank, world), dp.shard_batch(eps, rank, world), True)
-torch.cuda.synchronize()
-loss = torch.tensor([out["loss"]], device=dev)
-dist.all_reduce(loss)
-if rank == 0:
-    ref = build(False)
-    ropt, rout, _ = run(ref, past, fut, eps, False)
-    torch.cuda.synchronize()
+def compare(tag, opt, out, gs, ropt, rout, m, ref):
     g, gr = opt.flat_g, ropt.flat_g
     rel = float((g - gr).norm() / gr.norm())
     rm = float((m.evt_posterior.conv1[1].running_mean - ref.evt_posterior.conv1[1].running_mean).abs().max())
     pe = float((opt.flat_p - ropt.flat_p).abs().max())
-    print(f"[dp_check] world={world} backend={dist.get_backend()} buckets={len(gs.buckets)} launched={gs.launched} "
-          f"grad rel-L2 {rel:.3e}  mean-loss {float(loss) / world:.6f} vs single {rout['loss']:.6f}  "
-          f"BN running_mean max diff {rm:.2e}  param max diff after step {pe:.2e}", flush=True)
+    print(f"[dp_check] {tag}: world={world} backend={dist.get_backend()} buckets={len(gs.buckets)} launched={gs.launched} "
+          f"grad rel-L2 {rel:.3e}  mean-loss {out:.6f} vs single {rout['loss']:.6f}  BN running_mean max diff {rm:.2e}  "
+          f"param max diff {pe:.2e}", flush=True)
     assert pe == 0.0, "lr = 0: parameters must not move"
-    assert rel < 1e-4 and abs(float(loss) / world - rout["loss"]) < 1e-5 * abs(rout["loss"]) + 1e-8 and rm < 1e-5, "DP != single"
+    assert rel < 1e-4 and abs(out - rout["loss"]) < 1e-5 * abs(rout["loss"]) + 1e-8 and rm < 1e-5, f"{tag}: DP != single"
+    assert gs.launched > len(gs.buckets), "the overlapped path (buckets reduced during backward) never ran"
+
+
+def mean_loss(out):
+    t = torch.tensor([out["loss"]], device=dev)
+    dist.all_reduce(t)
+    return float(t) / world
+
+
+sh = lambda x: dp.shard_batch(x, rank, world)
+# ---- case 1: fixed context / target split, 3 steps, an eval forward after the first
+past, fut = O.synth_features((B, To, 512, 8, 8), 1).to(dev), O.synth_features((B, Tp, 512, 8, 8), 2).to(dev)
+eps = O.seeded_randn((B, 512, 8, 8), 3).to(dev)
+m = build(True)
+opt, out, gs = steps(m, [(sh(past), sh(fut), sh(eps), None)] * 3, True, eval_between=True)
+torch.cuda.synchronize()
+ml = mean_loss(out)
+if rank == 0:
+    ref = build(False)
+    ropt, rout, _ = steps(ref, [(past, fut, eps, None)] * 3, False, eval_between=True)
+    torch.cuda.synchronize()
+    compare("fixed split + eval between steps", opt, ml, gs, ropt, rout, m, ref)
+gs.remove()
+dist.barrier()
+
+# ---- case 2: random-context batches, a different (context, target) split of the T steps every step (same split on all ranks)
+clip = O.synth_features((B, T, 512, 8, 8), 11).to(dev)
+gen = torch.Generator().manual_seed(99)
+splits = []
+for _ in range(3):
+    perm = torch.randperm(T, generator=gen)
+    lo = int(torch.randint(2, 5, (1,), generator=gen))
+    splits.append((perm[:lo], perm[lo:]))
+mk = lambda c: [(c[:, io.to(dev)].contiguous(), c[:, ip.to(dev)].contiguous(), None, (io, ip)) for io, ip in splits]
+m2 = build(True, rand_context=True)
+eps2 = O.seeded_randn((B, 512, 8, 8), 12).to(dev)
+b_sh = [(p_, f_, sh(eps2), s_) for (p_, f_, _, s_) in mk(sh(clip))]
+opt2, out2, gs2 = steps(m2, b_sh, True)
+torch.cuda.synchronize()
+ml2 = mean_loss(out2)
+if rank == 0:
+    ref2 = build(False, rand_context=True)
+    b_all = [(p_, f_, eps2, s_) for (p_, f_, _, s_) in mk(clip)]
+    ropt2, rout2, _ = steps(ref2, b_all, False)
+    torch.cuda.synchronize()
+    compare("random context", opt2, ml2, gs2, ropt2, rout2, m2, ref2)
     print("[dp_check] OK", flush=True)
 dist.barrier()
 dist.destroy_process_group()
