@@ -72,6 +72,9 @@ int npvp_frame_stats_finalize(const float* part, int parts_per_frame, float valu
  * F feeds y = x w^T (pass as b_pre with b_kc = 1), D feeds dx = dy w (b_pre with b_kc = 0).  b_pre is optional
  * (NULL = split B on the fly) and only honoured by precision 4 with a_kc = 1. */
 int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void* D, npvp_stream_t stream);
+/* The same for MANY weight views in one launch (after the optimiser step, ref/models/Predictor.py:136 opt.step()): desc is a
+ * DEVICE array of `count` records of six 64-bit words {w, ld, N, K, F, D} (pointers as integers). */
+int npvp_split_weights_batched(const void* desc, int count, npvp_stream_t stream);
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.
@@ -123,6 +126,27 @@ int npvp_dwconv3x3(const float* a, const float* wt, const float* bias, float* ou
  * output, so that MlpDWBN's norm2 needs no statistics pass (8x8 grid, Ch % 1024 == 0; workspace >= frames*Ch/1024*8 B) */
 int npvp_dwconv3x3_stats(const float* a, const float* wt, const float* bias, float* out, float* mean, float* rstd, int frames,
                          int H, int W, int Ch, float eps, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* ---- fused middle of MlpDWBN (ref/models/VidHRFormer.py:381-385: norm1 -> GELU -> depthwise 3x3 [-> norm2's statistics]),
+ * 8x8 grid, Ch % 512 == 0.  Forward: h2 = dwconv3x3(gelu(LayerNorm((Ch,H,W))(h1))) + bias in ONE pass over the hidden tensor
+ * (a1 is never materialised) plus mean2 / rstd2 of h2 per frame.  wt [9][Ch] tap-major, bias [Ch], w1n / b1n [H*W][Ch].
+ * workspace >= frames * (Ch/512) * 8 bytes. */
+int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const float* rstd1, const float* w1n, const float* b1n,
+                       const float* wt, const float* bias, float* h2, float* mean2, float* rstd2, int frames, int H, int W,
+                       int Ch, float eps, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* Backward: da1 = conv^T(dh2); dwt_db [10][Ch] (9 tap rows + bias row; accumulate 1: +=, 2: leave the partials in workspace
+ * for npvp_mlpdw_mid_bwd_reduce) with a1 recomputed from h1; psum [frames][Ch/256][2] = partial (sum g, sum g*hhat),
+ * g = da1 * gelu'(y1) * w1n: the statistics of norm1's backward (npvp_frameln_act_bwd_apply, nparts = Ch/256). */
+long long npvp_mlpdw_mid_bwd_workspace_bytes(int frames, int Ch);
+int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, const float* rstd1, const float* w1n,
+                       const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H, int W,
+                       int Ch, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
+int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate, npvp_stream_t stream);
+/* frame-LN backward with the statistics supplied by the producer of dout (one pass instead of two; no dropout):
+ * psum [frames][nparts][2]; workspace as npvp_frameln_act_bwd. */
+int npvp_frameln_act_bwd_apply(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                               const float* b, const float* psum, int nparts, float* dh, float* dw, float* db, int frames,
+                               int per_frame, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
+
 /* im2col / col2im of the EventEncoder's dense 3x3 conv (ref/models/submodules.py:376), channels-last:
  * col2im=0: in [F][H*W][C] -> out [F*H*W][9*C] (tap-major columns); col2im=1: the adjoint. */
 int npvp_im2col3x3(const float* in, float* out, int frames, int H, int W, int C, int col2im, npvp_stream_t stream);

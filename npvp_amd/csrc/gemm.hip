@@ -421,6 +421,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
+// All registered weight views in ONE launch (after the optimiser step): desc[v] = {w, ld, N, K, F, D} as 64-bit words
+// (npvp_split_weights_batched); blockIdx.y = view, blockIdx.x strides over its N*K/8 output slots of F, then of D.
+struct SplitDesc { const float* w; long long ld; long long N; long long K; __bf16* F; __bf16* D; };
+__global__ void split_weights_batched_kernel(const SplitDesc* __restrict__ desc) {
+  const SplitDesc d = desc[blockIdx.y];
+  const int N = (int)d.N, K = (int)d.K;
+  const long long slots = (long long)N * K / 8, plane = (long long)N * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * slots; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    __bf16* out;
+    if (i < slots) {                          // F[term][k/8][n][8 over k]
+      const int n = (int)(i % N), kb = (int)(i / N);
+      const float4 a = ld4(d.w + (long long)n * d.ld + kb * 8), b = ld4(d.w + (long long)n * d.ld + kb * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      out = d.F + i * 8;
+    } else {                                  // D[term][n/8][k][8 over n]
+      const long long j = i - slots;
+      const int k = (int)(j % K), nb = (int)(j / K);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = d.w[(long long)(nb * 8 + e) * d.ld + k];
+      out = d.D + j * 8;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      bf16x8 q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { q[e] = (__bf16)v[e]; v[e] -= (float)q[e]; }
+      *reinterpret_cast<bf16x8*>(out + (long long)s_ * plane) = q;
+    }
+  }
+}
+
 // sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
                                      long long ldc, int splits, float alpha, int accum) {
@@ -474,6 +506,15 @@ extern "C" int npvp_split_weight(const float* w, long long ld, int N, int K, voi
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   if (F) { hipLaunchKernelGGL(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)F); NPVP_CHECK_LAUNCH(); }
   if (D) { hipLaunchKernelGGL(split_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)D); NPVP_CHECK_LAUNCH(); }
+  return NPVP_OK;
+}
+
+// desc: DEVICE array of `count` records of six 64-bit words {w, ld, N, K, F, D} (pointers as integers); every view obeys the
+// npvp_split_weight contract.  One launch re-splits every weight of the model after an optimiser step.
+extern "C" int npvp_split_weights_batched(const void* desc, int count, hipStream_t stream) {
+  NPVP_CHECK_ARG(desc && count > 0, "split_weights_batched: empty table");
+  hipLaunchKernelGGL(split_weights_batched_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDesc*)desc);
+  NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
 

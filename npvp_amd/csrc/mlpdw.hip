@@ -102,6 +102,203 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused middle of MlpDWBN (ref/models/VidHRFormer.py:381-385): norm1 + GELU + depthwise 3x3 (+ the statistics norm2 needs)
+// in ONE pass over the hidden tensor.  a1 = GELU(LayerNorm((Ch,H,W))(h1)) is never written to memory: forward reads h1 and
+// writes h2 (2 passes over [R, Ch] instead of 4), backward recomputes a1 from h1 where the weight gradient needs it.
+// Same register window as dwconv3x3_win_kernel, but VEC = 2 channels per thread instead of 4: the LayerNorm / GELU
+// arithmetic and the two affine loads per element need registers and latency hiding that a 4-channel window (1 wave per
+// SIMD) cannot give (that first attempt lost 176 us per block in backward); at 2 channels the kernels run 3-5 waves per SIMD.
+template <int VEC> struct Vec { float v[VEC]; };
+template <int VEC> __device__ __forceinline__ Vec<VEC> ldv(const float* p) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) { const float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+  else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+  else r.v[0] = *p;
+  return r;
+}
+template <int VEC> __device__ __forceinline__ void stv(float* p, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) st4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
+  else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+  else *p = r.v[0];
+}
+
+// h2[f,p,c] = bias[c] + sum_tap wt[tap][c] * a1[f, p + off(tap), c],  a1 = gelu((h1 - mean1[f]) rstd1[f] w1n[p,c] + b1n[p,c]);
+// part[block] = (mean, M2) of the block's 256 x 64 x VEC outputs (a block lies inside one frame: (Ch / VEC) % 256 == 0).
+template <int VEC>
+__global__ __launch_bounds__(256, 4) void mlpdw_mid_fwd_kernel(const float* __restrict__ h1, const float* __restrict__ mean1,
+                                                            const float* __restrict__ rstd1, const float* __restrict__ w1n,
+                                                            const float* __restrict__ b1n, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ h2,
+                                                            float* __restrict__ part, int Ch) {
+  constexpr int HH = 8, WW = 8;
+  __shared__ float red[4];
+  // a block lies inside one frame ((Ch / VEC) % 256 == 0): the frame base is wave-uniform (SGPR pair) and every access is
+  // base + a 32-bit offset - with per-thread 64-bit pointers the 8 x 4 addresses of a row alone took 64 VGPRs
+  const int bpf = Ch / VEC / 256;                                   // blocks per frame
+  const long long f = blockIdx.x / bpf;
+  const int c = ((blockIdx.x - (int)f * bpf) * 256 + threadIdx.x) * VEC;
+  const float mu = mean1[f], rs = rstd1[f];
+  Vec<VEC> wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = ldv<VEC>(wt + t * Ch + c);
+  const Vec<VEC> bv = ldv<VEC>(bias + c);
+  const float* hf = h1 + f * (HH * WW) * Ch;
+  float* of = h2 + f * (HH * WW) * Ch;
+  Vec<VEC> r0[WW], r1[WW], r2[WW];
+  auto load_row = [&](Vec<VEC>* row, int hh) {
+#pragma unroll
+    for (int w = 0; w < WW; ++w) {
+      const int pix = hh * WW + w, off = pix * Ch + c;
+      const Vec<VEC> x = ldv<VEC>(hf + off), ww = ldv<VEC>(w1n + off), bb = ldv<VEC>(b1n + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) row[w].v[e] = gelu_f((x.v[e] - mu) * rs * ww.v[e] + bb.v[e]);
+    }
+  };
+#pragma unroll
+  for (int w = 0; w < WW; ++w)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r0[w].v[e] = 0.f;
+  load_row(r1, 0);
+  float shift = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+  for (int h = 0; h < HH; ++h) {          // NOT unrolled: unrolled, the compiler hoists a frame's 64 x 3 loads (256 VGPRs)
+    if (h + 1 < HH) load_row(r2, h + 1);
+    else {
+#pragma unroll
+      for (int w = 0; w < WW; ++w)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r2[w].v[e] = 0.f;
+    }
+#pragma unroll
+    for (int w = 0; w < WW; ++w) {
+      Vec<VEC> acc = bv;
+#pragma unroll
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int ww = w + kx;
+        if (ww < 0 || ww >= WW) continue;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          acc.v[e] += wv[kx + 1].v[e] * r0[ww].v[e] + wv[3 + kx + 1].v[e] * r1[ww].v[e] + wv[6 + kx + 1].v[e] * r2[ww].v[e];
+      }
+      stv<VEC>(of + (h * WW + w) * Ch + c, acc);
+      if (h == 0 && w == 0) shift = acc.v[0];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float a = acc.v[e] - shift; s1 += a; s2 += a * a; }
+    }
+#pragma unroll
+    for (int w = 0; w < WW; ++w) { r0[w] = r1[w]; r1[w] = r2[w]; }
+  }
+  const float n = (float)(HH * WW * VEC), m1 = s1 / n, mean_t = shift + m1, m2_t = s2 - s1 * m1;
+  const float mean_b = block_sum<4>(mean_t, red) / 256.f;
+  const float d = mean_t - mean_b;
+  const float m2_b = block_sum<4>(m2_t + n * d * d, red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = mean_b; part[blockIdx.x * 2 + 1] = m2_b; }
+}
+
+// Backward of the fused middle for the frames of one chunk (grid.y) and VEC channels per thread:
+//   da1[f,p,c]  = sum_tap wt[tap][c] * dh2[f, p - off(tap), c]                       (input gradient of the convolution)
+//   dwt[tap][c] += sum_{f,p} dh2[f,p,c] * a1[f, p + off(tap), c],  db[c] += sum dh2   (a1 recomputed from h1)
+//   psum[f][block] = (sum g, sum g*hhat) over the block's channels, g = da1 * gelu'(y1) * w1n   (norm1's backward statistics:
+//                    frameln_act_bwd then needs no statistics pass of its own)
+// part[chunk][tap 0..8 | bias][Ch] receives the weight-gradient partial sums (summed by sum_rows_kernel).
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void mlpdw_mid_bwd_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
+                                                            const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                            const float* __restrict__ w1n, const float* __restrict__ b1n,
+                                                            const float* __restrict__ wt, float* __restrict__ da1,
+                                                            float* __restrict__ part, float* __restrict__ psum, int Ch,
+                                                            int frames, int frames_per_chunk) {
+  constexpr int HH = 8, WW = 8;
+  __shared__ float red[4];
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const int nblk = gridDim.x;
+  Vec<VEC> wv[9], aw[9], ab;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wv[t] = ldv<VEC>(wt + t * Ch + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) aw[t].v[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) ab.v[e] = 0.f;
+  const int f0 = blockIdx.y * frames_per_chunk, f1 = min(frames, f0 + frames_per_chunk);
+  for (long long f = f0; f < f1; ++f) {
+    const float mu = mean1[f], rs = rstd1[f];
+    const float* hf = h1 + f * (HH * WW) * Ch;           // wave-uniform bases + 32-bit offsets (see the forward kernel)
+    const float* gf = dh2 + f * (HH * WW) * Ch;
+    float* of = da1 + f * (HH * WW) * Ch;
+    // windows: a = a1 rows (h-1, h, h+1); g = dh2 rows; for the centre row also gelu'(y1) * w1n and hhat
+    Vec<VEC> a0[WW], a1r[WW], a2[WW], g0[WW], g1[WW], g2[WW], gp1[WW], xh1[WW], gp2[WW], xh2[WW];
+    auto load_row = [&](Vec<VEC>* arow, Vec<VEC>* grow, Vec<VEC>* gprow, Vec<VEC>* xhrow, int hh) {
+#pragma unroll
+      for (int w = 0; w < WW; ++w) {
+        const int pix = hh * WW + w, off = pix * Ch + c;
+        const Vec<VEC> x = ldv<VEC>(hf + off), ww = ldv<VEC>(w1n + off), bb = ldv<VEC>(b1n + off);
+        grow[w] = ldv<VEC>(gf + off);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xh = (x.v[e] - mu) * rs, y = xh * ww.v[e] + bb.v[e];
+          float E;
+          const float phi = gelu_phi(y, E);
+          arow[w].v[e] = y * phi;
+          gprow[w].v[e] = fmaf(y * 0.39894228040143267794f, E, phi) * ww.v[e];
+          xhrow[w].v[e] = xh;
+        }
+      }
+    };
+#pragma unroll
+    for (int w = 0; w < WW; ++w)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { a0[w].v[e] = 0.f; g0[w].v[e] = 0.f; }
+    load_row(a1r, g1, gp1, xh1, 0);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int h = 0; h < HH; ++h) {
+      if (h + 1 < HH) load_row(a2, g2, gp2, xh2, h + 1);
+      else {
+#pragma unroll
+        for (int w = 0; w < WW; ++w)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { a2[w].v[e] = 0.f; g2[w].v[e] = 0.f; }
+      }
+#pragma unroll
+      for (int w = 0; w < WW; ++w) {
+        Vec<VEC> acc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { acc.v[e] = 0.f; ab.v[e] += g1[w].v[e]; }
+#pragma unroll
+        for (int kx = -1; kx <= 1; ++kx) {
+          const int ww = w + kx;
+          if (ww < 0 || ww >= WW) continue;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            // input gradient: flipped taps on the dh2 window
+            acc.v[e] += wv[8 - (kx + 1)].v[e] * g0[ww].v[e] + wv[8 - (3 + kx + 1)].v[e] * g1[ww].v[e] + wv[8 - (6 + kx + 1)].v[e] * g2[ww].v[e];
+            // weight gradient: dh2 at the output pixel times a1 at its 3x3 neighbourhood
+            const float d = g1[w].v[e];
+            aw[kx + 1].v[e] += d * a0[ww].v[e];
+            aw[3 + kx + 1].v[e] += d * a1r[ww].v[e];
+            aw[6 + kx + 1].v[e] += d * a2[ww].v[e];
+          }
+        }
+        stv<VEC>(of + (h * WW + w) * Ch + c, acc);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float g = acc.v[e] * gp1[w].v[e]; s1 += g; s2 += g * xh1[w].v[e]; }
+      }
+#pragma unroll
+      for (int w = 0; w < WW; ++w) { a0[w] = a1r[w]; a1r[w] = a2[w]; g0[w] = g1[w]; g1[w] = g2[w]; gp1[w] = gp2[w]; xh1[w] = xh2[w]; }
+    }
+    s1 = block_sum<4>(s1, red);
+    s2 = block_sum<4>(s2, red);
+    if (threadIdx.x == 0) { psum[(f * nblk + blockIdx.x) * 2] = s1; psum[(f * nblk + blockIdx.x) * 2 + 1] = s2; }
+  }
+  float* o = part + (long long)blockIdx.y * 10 * Ch;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) stv<VEC>(o + t * Ch + c, aw[t]);
+  stv<VEC>(o + 9 * Ch + c, ab);
+}
+
 // per frame: J partials (mean_j, M2_j) over nb values each -> mean, rstd
 __global__ void frame_stats_finalize_kernel(const float* __restrict__ part, int J, float nb, float* __restrict__ mean,
                                             float* __restrict__ rstd, int frames, float eps) {
@@ -302,6 +499,58 @@ extern "C" int npvp_dwconv3x3_stats(const float* a, const float* wt, const float
   hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
                      65536.f, mean, rstd, frames, eps);
   NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// Fused MlpDWBN middle, forward (8x8 grid, Ch % 512 == 0): h2 = dwconv3x3(gelu(frame_ln(h1))) + bias, and the frame
+// statistics (mean2, rstd2) of h2.  wt [9][Ch] tap-major, w1n / b1n [64][Ch] channels-last.  workspace >= frames*(Ch/512)*8 B.
+extern "C" int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const float* rstd1, const float* w1n, const float* b1n,
+                                  const float* wt, const float* bias, float* h2, float* mean2, float* rstd2, int frames,
+                                  int H, int W, int Ch, float eps, void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 512 == 0, "mlpdw_mid_fwd: needs an 8x8 grid and Ch % 512 == 0");
+  const int J = Ch / 512;
+  NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * J * 8, "mlpdw_mid_fwd: workspace too small");
+  const long long nthreads = (long long)frames * (Ch / 2);
+  hipLaunchKernelGGL((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, mean1, rstd1, w1n, b1n,
+                     wt, bias, h2, (float*)workspace, Ch);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
+                     32768.f, mean2, rstd2, frames, eps);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+static int mid_chunks(int frames) { return frames < 128 ? frames : 128; }
+
+// workspace of npvp_mlpdw_mid_bwd: weight-gradient partials [chunks][10][Ch]
+extern "C" long long npvp_mlpdw_mid_bwd_workspace_bytes(int frames, int Ch) {
+  return (long long)mid_chunks(frames) * 10 * Ch * 4;
+}
+
+// Fused MlpDWBN middle, backward: da1 (gradient w.r.t. a1 = gelu(norm1(h1)), [frames, 64, Ch]), dwt_db [10][Ch] (depthwise
+// weight taps + bias gradient, written or accumulated), and psum [frames][Ch/256][2] = the statistics norm1's backward needs
+// (pass to npvp_frameln_act_bwd_apply with nparts = Ch / 256).
+extern "C" int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, const float* rstd1, const float* w1n,
+                                  const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H,
+                                  int W, int Ch, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 512 == 0, "mlpdw_mid_bwd: needs an 8x8 grid and Ch % 512 == 0");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_mlpdw_mid_bwd_workspace_bytes(frames, Ch), "mlpdw_mid_bwd: workspace too small");
+  const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  // one channel per thread: the windows of a1, dh2, gelu'(y1) w1n and hhat (10 rows of 8) fit 242 VGPRs without spilling
+  hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n, b1n, wt,
+                     da1, (float*)workspace, psum, Ch, frames, fpc);
+  NPVP_CHECK_LAUNCH();
+  if (accumulate == 2) return NPVP_OK;        // the caller reduces the partials (npvp_mlpdw_mid_bwd_reduce)
+  const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream, accumulate);
+  if (rc) { npvp_set_error("mlpdw_mid_bwd: reduce launch failed"); return rc; }
+  return NPVP_OK;
+}
+
+extern "C" int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate,
+                                         hipStream_t stream) {
+  const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream, accumulate ? 1 : 0);
+  if (rc) { npvp_set_error("mlpdw_mid_bwd_reduce: launch failed"); return rc; }
   return NPVP_OK;
 }
 

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p,
 // (summed by sum_rows_kernel).  Saves the separate apply pass of the first version (a full re-read of dout and h).
 __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ psum,
                                              float* __restrict__ dh, float* __restrict__ part, int frames,
-                                             int frames_per_chunk) {
+                                             int frames_per_chunk, int nparts) {
   const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e >= p.per_frame) return;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
@@ -345,8 +345,7 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
     const long long g0 = f * p.per_frame + e;
     const float mu = p.mean[f], rs = p.rstd[f];
     float a1 = 0.f, a2 = 0.f;              // s1 = mean(g), s2 = mean(g*hhat) from the FLN_PARTS partial sums, fixed order
-#pragma unroll
-    for (int j = 0; j < FLN_PARTS; ++j) { a1 += psum[(f * FLN_PARTS + j) * 2]; a2 += psum[(f * FLN_PARTS + j) * 2 + 1]; }
+    for (int j = 0; j < nparts; ++j) { a1 += psum[(f * nparts + j) * 2]; a2 += psum[(f * nparts + j) * 2 + 1]; }
     a1 /= p.per_frame; a2 /= p.per_frame;
     const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
@@ -542,11 +541,37 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
-                     dout, (const float*)psum, dh, part, frames, fpc);
+                     dout, (const float*)psum, dh, part, frames, fpc, FLN_PARTS);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
     npvp_set_error("frameln_act_bwd: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
+  return NPVP_OK;
+}
+
+// The same with the statistics supplied by the producer of dout: psum [frames][nparts][2] = partial (sum g, sum g*hhat)
+// (npvp_mlpdw_mid_bwd emits them for norm1) - ONE pass instead of two.  No dropout / drop-path here (norm1 has none).
+// workspace: same layout and size as npvp_frameln_act_bwd (the first frames*2*FLN_PARTS floats stay unused).
+extern "C" int npvp_frameln_act_bwd_apply(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                                          const float* b, const float* psum, int nparts, float* dh, float* dw, float* db,
+                                          int frames, int per_frame, int accumulate, void* workspace, long long ws_bytes,
+                                          hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0 && psum && nparts > 0, "frameln_act_bwd_apply: bad arguments");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
+                 "frameln_act_bwd_apply: workspace too small");
+  FlnParams p;
+  fill_fln(p, h, mean, rstd, w, b, nullptr, frames, per_frame, 0.f, 0u, 0.f, 0u, 1, nullptr);
+  float* part = (float*)workspace + (long long)frames * 2 * FLN_PARTS;
+  const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
+  const int nchunks = (frames + fpc - 1) / fpc;
+  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
+                     dout, psum, dh, part, frames, fpc, nparts);
+  NPVP_CHECK_LAUNCH();
+  if (accumulate == 2) return NPVP_OK;
+  if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
+    npvp_set_error("frameln_act_bwd_apply: reduce launch failed");
     return NPVP_ERR_LAUNCH;
   }
   return NPVP_OK;

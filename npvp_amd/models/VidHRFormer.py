@@ -162,6 +162,13 @@ class MlpDWBN(nn.Module):
         F_, R = N * T, N * T * H * W
         pd = self.drop.p if self.training else 0.0
         hid = self.fc1.out_channels
+        if ops.mlpdwbn_fused_supported(R, C, hid, self.out_features, H, W) and self.fc1.bias is not None:
+            # one autograd node, fused middle (norm1 + GELU + depthwise 3x3 + norm2 statistics in one pass)
+            out = ops.mlpdwbn(x.reshape(R, C), None if residual is None else residual.reshape(R, self.out_features),
+                              self.fc1.weight.flatten(1), self.fc1.bias, self.norm1.weight, self.norm1.bias,
+                              self.dw3x3.weight, self.dw3x3.bias, self.norm2.weight, self.norm2.bias,
+                              self.fc2.weight.flatten(1), self.fc2.bias, self.norm3.weight, self.norm3.bias, F_, T, pd, p_dp)
+            return out.view(N, T, H, W, self.out_features)
         # fc1 / the depthwise conv / fc2 hand the frame LayerNorm that follows them its statistics (no pass over h)
         if ops.linear_frame_stats_supported(R, hid) and H * W == 64:
             h, m1, r1 = ops.linear(x.reshape(R, C), self.fc1.weight.flatten(1), self.fc1.bias, frame_stats=True)

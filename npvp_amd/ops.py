@@ -150,19 +150,27 @@ def set_gemm_precision(name):
 
 
 class WeightPlanes:
-    """Per-optimiser-step cache of the pre-split bf16 planes of a weight (npvp_split_weight): the B operand of the forward
-    (F planes) and dgrad (D planes) GEMMs.  A weight changes once per step but is staged by every tile of two GEMMs, so it
-    is split ONCE, into the exact layout of the GEMM's LDS image - the wide GEMM kernel then copies it HBM -> LDS by
-    LDS-DMA and spends no VALU or VGPR on it.  The cache lives ON the owning tensor object (the Parameter, or the flat
-    parameter buffer it is a view of), never in a table keyed by device address: a freed weight's address is reused by
-    the next model's weights.  An entry is re-split after `invalidate()` (FlatAdamW.step) or an in-place torch update
-    (version counter).  NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly)."""
-    epoch = 0
+    """The pre-split bf16 planes of every weight that is a GEMM B operand (npvp_split_weight): F planes for the forward
+    GEMM, D planes for dgrad.  A weight changes once per optimiser step but is staged by every tile of two GEMMs, so it is
+    split ONCE per step, into the exact layout of the GEMM's LDS image - the wide GEMM kernel copies it HBM -> LDS by LDS-DMA
+    and spends no VALU or VGPR on it.
+      * A view registers itself on first use (split there and then, one small launch).
+      * `refresh_all()` (FlatAdamW.step, right after the AdamW kernel) re-splits EVERY registered view with ONE launch
+        (npvp_split_weights_batched over a device table) - not ~350 small launches per step, and no per-call bookkeeping.
+      * An in-place torch update (load_state_dict, a test's fill) is caught by the tensor version counter: that view is
+        re-split lazily.
+    The cache lives ON the owning tensor object (the Parameter, or the flat parameter buffer it is a view of), never in a
+    table keyed by device address: a freed weight's address is reused by the next model's weights.
+    NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly, 128 x 128 kernel only)."""
     enabled = os.environ.get("NPVP_PRESPLIT", "1") == "1"
+    _owners = []            # weak references to tensors that carry a `_npvp_planes` store
+    _table = None           # (device table tensor, [entries]) - rebuilt when a view registers or an owner dies
+    _dirty = True
 
     @classmethod
     def invalidate(cls):
-        cls.epoch += 1
+        """the parameters changed under the planes (optimiser step): re-split everything now"""
+        cls.refresh_all()
 
     @classmethod
     def get(cls, w, want):
@@ -172,17 +180,63 @@ class WeightPlanes:
         owner = w._base if w._base is not None else w
         if not owner.is_leaf and owner.grad_fn is not None:
             return None                     # a temporary (e.g. a permuted conv weight): nothing persistent to cache on
-        store = owner.__dict__.setdefault("_npvp_planes", {})
+        store = owner.__dict__.get("_npvp_planes")
+        if store is None:
+            import weakref
+            store = owner.__dict__["_npvp_planes"] = {}
+            cls._owners.append(weakref.ref(owner))
         key = (w.storage_offset(), tuple(w.shape), w.stride(0))
         ent = store.get(key)
-        if ent is None or ent[0] != cls.epoch or ent[1] != w._version:
+        if ent is None or ent[0] != w._version:
             N, K = w.shape
-            planes = ent[2] if ent is not None else torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
+            planes = ent[1] if ent is not None else torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
             check(lib().npvp_split_weight(_ptr(w), w.stride(0), N, K, _p(planes[0].data_ptr()), _p(planes[1].data_ptr()),
                                           _stream()), "npvp_split_weight")
-            ent = (cls.epoch, w._version, planes)
-            store[key] = ent
-        return ent[2][0 if want == "F" else 1]
+            if ent is None:
+                cls._dirty = True
+            ent = store[key] = [w._version, planes, w.detach()]
+        return ent[1][0 if want == "F" else 1]
+
+    @classmethod
+    def refresh_if_stale(cls):
+        """re-split everything if any registered weight was updated in place behind the planes' back (GraphedTrainStep calls
+        this before a replay: the captured step refreshes the planes only after ITS optimiser step)"""
+        for ref in cls._owners:
+            owner = ref()
+            if owner is not None and any(ent[0] != ent[2]._version for ent in owner.__dict__.get("_npvp_planes", {}).values()):
+                cls.refresh_all()
+                return
+
+    @classmethod
+    def refresh_all(cls):
+        if not cls.enabled:
+            return
+        if cls._dirty or cls._table is None:
+            rows, ents, live = [], [], []
+            for ref in cls._owners:
+                owner = ref()
+                if owner is None:
+                    continue
+                live.append(ref)
+                for ent in owner.__dict__.get("_npvp_planes", {}).values():
+                    ver, planes, w = ent
+                    if not w.is_cuda:
+                        continue
+                    N, K = w.shape
+                    rows.append([w.data_ptr(), w.stride(0), N, K, planes[0].data_ptr(), planes[1].data_ptr()])
+                    ents.append(ent)
+            cls._owners = live
+            by_dev = {}
+            for r, e in zip(rows, ents):
+                by_dev.setdefault(e[2].device, ([], []))
+                by_dev[e[2].device][0].append(r); by_dev[e[2].device][1].append(e)
+            cls._table = [(torch.tensor(r, dtype=torch.int64).to(dev), e) for dev, (r, e) in by_dev.items()]
+            cls._dirty = False
+        for table, ents in cls._table:
+            with torch.cuda.device(table.device):
+                check(lib().npvp_split_weights_batched(_p(table.data_ptr()), table.shape[0], _stream()), "npvp_split_weights_batched")
+            for ent in ents:
+                ent[0] = ent[2]._version
 
 
 class GemmProbe:
@@ -960,6 +1014,144 @@ class _DwConv(torch.autograd.Function):
 def dwconv3x3(a, wtb, frames, H, W, want_stats=False):
     """want_stats (8x8 grid, Ch % 1024 == 0): returns (out, mean, rstd) - the frame-LayerNorm statistics of the output"""
     return _DwConv.apply(a, wtb, frames, H, W, bool(want_stats))
+
+
+class _MlpDwbn(torch.autograd.Function):
+    """The whole conv feed-forward sub-layer body of the reference's MlpDWBN (ref/models/VidHRFormer.py:374-392) as ONE
+    autograd node:  out = res + droppath(drop(GELU(norm3(fc2(drop(GELU(norm2(dw3x3(GELU(norm1(fc1(x))))))))))))
+    Forward = 6 launches + 3 tiny statistics merges: fc1 GEMM (frame statistics in its epilogue) -> fused middle (norm1 +
+    GELU + depthwise 3x3 + norm2's statistics: a1 is never written) -> norm2 + GELU + dropout -> fc2 GEMM (statistics) ->
+    norm3 + GELU + dropout + residual + drop-path.  Backward mirrors it; the fused middle's backward recomputes a1 from h1 for
+    the depthwise weight gradient and emits norm1's backward statistics, so norm1's backward is one pass.
+    Passes over the [R, 2048] hidden tensor: forward 6 (was 8), backward 15 (was 18); one Python autograd node instead of 9."""
+
+    @staticmethod
+    def forward(ctx, x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, frames, T, p_drop, p_dp):
+        _chk(x, res, w1, b1, w2, b2)
+        L = lib()
+        R, C = x.shape
+        hid, Co = w1.shape[0], w2.shape[0]
+        dev, f32 = x.device, torch.float32
+        st = _stream()
+        PFh, PFo = 64 * hid, 64 * Co
+        # fc1 (+ frame statistics of h1)
+        h1 = torch.empty(R, hid, dtype=f32, device=dev)
+        part = torch.empty(frames * (hid // 64) * 2, dtype=f32, device=dev)
+        gemm(1, 1, R, hid, C, x, x.stride(0), w1, w1.stride(0), h1, bias=b1, b_pre=WeightPlanes.get(w1, "F") if R >= 256 else None,
+             rowstats=part)
+        stats = torch.empty(6, frames, dtype=f32, device=dev)               # mean1, rstd1, mean2, rstd2, mean3, rstd3
+        check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _ptr(stats[0]), _ptr(stats[1]), frames, 1e-5, st),
+              "npvp_frame_stats_finalize")
+        # tap-major depthwise weights [9][hid] + bias row
+        wtb = torch.empty(10, hid, dtype=f32, device=dev)
+        check(L.npvp_transpose(_ptr(dww), _ptr(wtb), 1, hid, 9, st), "npvp_transpose")
+        wtb[9].copy_(dwb)
+        # fused middle
+        h2 = torch.empty(R, hid, dtype=f32, device=dev)
+        ws, wsn = _ws(frames * (hid // 512) * 8, dev)
+        check(L.npvp_mlpdw_mid_fwd(_ptr(h1), _ptr(stats[0]), _ptr(stats[1]), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(wtb[9]),
+                                   _ptr(h2), _ptr(stats[2]), _ptr(stats[3]), frames, 8, 8, hid, 1e-5, _ptr(ws), wsn, st),
+              "npvp_mlpdw_mid_fwd")
+        d2, d3, dp = Drop(p_drop), Drop(p_drop), Drop(p_dp, 1)
+        DropRecorder.note(d2, "elem", R * hid)
+        seed = rng.seed_tensor(dev) if (d2.on or dp.on) else None
+        a2 = torch.empty(R, hid, dtype=f32, device=dev)
+        check(L.npvp_frameln_act_fwd(_ptr(h2), _ptr(stats[2]), _ptr(stats[3]), _ptr(n2w), _ptr(n2b), _p(0), _ptr(a2), frames, PFh,
+                                     d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), st), "npvp_frameln_act_fwd")
+        # fc2 (+ statistics), norm3 + GELU + dropout + residual + drop-path
+        h3 = torch.empty(R, Co, dtype=f32, device=dev)
+        part3 = torch.empty(frames * (Co // 64) * 2, dtype=f32, device=dev)
+        gemm(1, 1, R, Co, hid, a2, hid, w2, w2.stride(0), h3, bias=b2, b_pre=WeightPlanes.get(w2, "F") if R >= 256 else None,
+             rowstats=part3)
+        check(L.npvp_frame_stats_finalize(_ptr(part3), Co // 64, 4096.0, _ptr(stats[4]), _ptr(stats[5]), frames, 1e-5, st),
+              "npvp_frame_stats_finalize")
+        DropRecorder.note(d3, "elem", R * Co)
+        DropRecorder.note(dp, "group", frames // max(1, T))
+        out = torch.empty(R, Co, dtype=f32, device=dev)
+        check(L.npvp_frameln_act_fwd(_ptr(h3), _ptr(stats[4]), _ptr(stats[5]), _ptr(n3w), _ptr(n3b), _ptr(res), _ptr(out), frames,
+                                     PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed), st), "npvp_frameln_act_fwd")
+        ctx.save_for_backward(x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b)
+        ctx.cfg = (frames, T, d2, d3, dp, res is not None, b1 is not None, b2 is not None)
+        ctx.sinks = (_wb_sink(w1, b1), _wb_sink(w2, b2), _ln_sink(n1w, n1b), _ln_sink(n2w, n2b), _ln_sink(n3w, n3b))
+        return out
+
+    @staticmethod
+    def _fln_bwd(L, dout, h, mean, rstd, w, b, frames, PF, d, dp, T, sk, psum=None, nparts=0):
+        """frame-LN backward (with its own statistics pass, or with the producer's `psum`); parameter gradients into the
+        sink (partials reduced on the gradient stream) or returned"""
+        dev = h.device
+        dh = torch.empty_like(h)
+        dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
+        ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), dev)
+        mode = _sink_mode(sk)
+        if psum is None:
+            seed = rng.seed_tensor(dev) if (d.on or dp.on) else None
+            check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(dh), _ptr(dw), _ptr(db),
+                                         frames, PF, d.p, d.salt, dp.p, dp.salt, T, _ptr(seed), mode, _ptr(ws), wsn, _stream()),
+                  "npvp_frameln_act_bwd")
+        else:
+            check(L.npvp_frameln_act_bwd_apply(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(psum), nparts,
+                                               _ptr(dh), _ptr(dw), _ptr(db), frames, PF, mode, _ptr(ws), wsn, _stream()),
+                  "npvp_frameln_act_bwd_apply")
+        if sk:
+            if WgradStream.enabled:
+                WgradStream.run(lambda: check(L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()),
+                                              "npvp_frameln_act_bwd_reduce"), ws)
+            GradSink.wrote(*sk)
+            return dh, None, None
+        return dh, dw, db
+
+    @staticmethod
+    def _lin_bwd(dy, x, w, sk, has_b):
+        """dgrad on this stream, weight (+bias) gradient into the sink on the gradient stream or returned"""
+        dx = linear_dgrad(dy, w)
+        if sk and (has_b == (sk[1] is not None)):
+            _sunk_wgrad(dy, x, has_b, sk)
+            return dx, None, None
+        g = linear_wgrad(dy, x, has_b)
+        return (dx, g[0], g[1]) if has_b else (dx, g, None)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b = ctx.saved_tensors
+        frames, T, d2, d3, dp, has_res, has_b1, has_b2 = ctx.cfg
+        s_fc1, s_fc2, s_n1, s_n2, s_n3 = ctx.sinks
+        L = lib()
+        R, hid = h1.shape
+        Co = h3.shape[1]
+        dev = x.device
+        dout = _c(dout)
+        F_ = _MlpDwbn
+        dh3, gn3w, gn3b = F_._fln_bwd(L, dout, h3, stats[4], stats[5], n3w, n3b, frames, 64 * Co, d3, dp, T, s_n3)
+        da2, gw2, gb2 = F_._lin_bwd(dh3, a2, w2, s_fc2, has_b2)
+        dh2, gn2w, gn2b = F_._fln_bwd(L, da2, h2, stats[2], stats[3], n2w, n2b, frames, 64 * hid, d2, NO_DROP, 1, s_n2)
+        del da2
+        # fused middle backward: da1, depthwise weight / bias gradient (a1 recomputed from h1), norm1's backward statistics
+        da1 = torch.empty_like(h1)
+        dwtb = torch.empty(10, hid, dtype=torch.float32, device=dev)
+        psum = torch.empty(frames * (hid // 256) * 2, dtype=torch.float32, device=dev)
+        ws, wsn = _ws(L.npvp_mlpdw_mid_bwd_workspace_bytes(frames, hid), dev)
+        check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _ptr(stats[0]), _ptr(stats[1]), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
+                                   _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
+        del dh2
+        gdww = torch.empty(hid, 1, 3, 3, dtype=torch.float32, device=dev)
+        check(L.npvp_transpose(_ptr(dwtb), _ptr(gdww), 1, 9, hid, _stream()), "npvp_transpose")
+        gdwb = dwtb[9]
+        dh1, gn1w, gn1b = F_._fln_bwd(L, da1, h1, stats[0], stats[1], n1w, n1b, frames, 64 * hid, NO_DROP, NO_DROP, 1, s_n1,
+                                      psum=psum, nparts=hid // 256)
+        del da1
+        dx, gw1, gb1 = F_._lin_bwd(dh1, x, w1, s_fc1, has_b1)
+        return (dx, dout if has_res else None, gw1, gb1, gn1w, gn1b, gdww, gdwb, gn2w, gn2b, gw2, gb2, gn3w, gn3b,
+                None, None, None, None)
+
+
+def mlpdwbn_fused_supported(R, C, hid, Co, H, W):
+    return (GEMM_PRECISION == 4 and H == 8 and W == 8 and R % 64 == 0 and hid % 512 == 0 and Co % 128 == 0 and hid % 128 == 0
+            and C % 32 == 0)
+
+
+def mlpdwbn(x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, frames, T, p_drop, p_dp):
+    return _MlpDwbn.apply(x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, frames, T, p_drop, p_dp)
 
 
 class _Im2Col(torch.autograd.Function):

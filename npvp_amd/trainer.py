@@ -370,5 +370,6 @@ class GraphedTrainStep:
             self.past.copy_(past_feats)
         if future_feats is not None:
             self.fut.copy_(future_feats)
+        ops.WeightPlanes.refresh_if_stale()
         self.graph.replay()
         return self.out

@@ -1,5 +1,5 @@
-"""cProfile of the host side of c1 training steps (where do the ~100 ms of Python per step go?).
-Usage: python tools/host_profile.py [steps]"""
+"""cProfile of the host side of training steps (where does the Python time per step go?).
+Usage: python tools/host_profile.py [steps] [c1|c4]"""
 import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,9 @@ from npvp_amd.trainer import load_config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-B, To, Tp = 32, 10, 10
-cfg = load_config(os.path.join(ROOT, "configs", "config_KTH_VFP_NPVP-S.yaml"), B, To, Tp)
+wl = sys.argv[2] if len(sys.argv) > 2 else "c1"
+B, To, Tp, cfgf = {"c1": (32, 10, 10, "config_KTH_VFP_NPVP-S.yaml"), "c4": (8, 4, 16, "config_KITTI_VFP_NPVP-D.yaml")}[wl]
+cfg = load_config(os.path.join(ROOT, "configs", cfgf), B, To, Tp)
 P = cfg["Predictor"]
 dev = torch.device("cuda", 0)
 model = npvp_amd.build_predictor_from_cfg(npvp_amd.Predictor, P, To, Tp).to(dev).train()
