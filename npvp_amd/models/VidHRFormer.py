@@ -7,6 +7,7 @@ tensor); the reference's permute/reshape/rearrange round trips (ref :34,50,94,11
 are epilogues of the GEMM / frame-LN kernels, never separate passes.
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
@@ -220,6 +221,12 @@ class DropPath(nn.Module):
         return "drop_prob={}".format(self.drop_prob)
 
 
+def _stock_fuser(pos_fuser):
+    """the sub-layer nodes call the positional-fuse kernels directly: only for the stock PosFeatFuser('layer')"""
+    from .submodules import PosFeatFuser
+    return type(pos_fuser) is PosFeatFuser and os.environ.get("NPVP_SUBLAYER_NODES", "1") == "1"
+
+
 def _get_clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
@@ -257,6 +264,15 @@ class VidHRFormerBlockEnc(nn.Module):
         pd, dp = (self.dropout if tr else 0.0), (self._dp if tr else 0.0)
         beta, gamma = memory_pos
         x = x.contiguous()
+        if _stock_fuser(pos_fuser):
+            # one autograd node per residual sub-layer (ops._SelfAttnSublayer / _MlpDwbn / _FfnSublayer)
+            x = ops.self_attn_sublayer(x, self.norm1, beta, gamma, None, self.SLMHSA.attn, self.SLMHSA._cfg(N, T, H, W),
+                                       Drop(dp, 1, T * P, N), N, T)                                              # ref :87-88
+            x, x1 = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            x = self.SpatialFFN.fused(x1, x, dp)                                                                  # ref :91
+            x = ops.self_attn_sublayer(x, self.norm3, beta, gamma, None, self.temporal_MHSA,
+                                       AttnCfg(1, N, P, W, 0, T, T, self.num_heads, 1, pd), Drop(pd), N, T)       # ref :94-107
+            return ops.ffn_sublayer(x, self.norm4, self.linear1, self.linear2, pd)                                # ref :110-112
         # spatial window attention: x += drop_path(SLMHSA(fuse(LN1 x), value = LN1 x))           ref :87-88
         x, x1 = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.SLMHSA.fused(pos_fuser(x1, beta, gamma), x1, x, Drop(dp, 1, T * P, N))
@@ -345,6 +361,20 @@ class VidHRFormerBlockDecNAR(nn.Module):
         pd, dp = (self.dropout if tr else 0.0), (self._dp if tr else 0.0)
         tb, tg = tgt_pos
         tgt = tgt.contiguous()
+        if _stock_fuser(pos_fuser):
+            x = ops.self_attn_sublayer(tgt, self.norm1, tb, tg, query_evt, self.SLMHSA.attn, self.SLMHSA._cfg(N, T2, H, W),
+                                       Drop(dp, 1, T2 * P, N), N, T2)                                             # ref :210-212
+            x, x1 = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            x = self.SpatialFFN.fused(x1, x, dp)                                                                  # ref :214
+            x = ops.self_attn_sublayer(x, self.norm3, tb, tg, None, self.temporal_MHSA,
+                                       AttnCfg(1, N, P, W, 0, T2, T2, self.num_heads, 0, pd), Drop(pd), N, T2)    # ref :217-221
+            x = ops.ffn_sublayer(x, self.norm4, self.linear1, self.linear2, pd)                                   # ref :224-226
+            key = fused_memory if fused_memory is not None else pos_fuser(memory, *memory_pos)
+            # encoder-decoder attention; its drop_path acts per TIME-STEP (tensor is (T2, N*H*W, C))               ref :229-239
+            x = ops.cross_attn_sublayer(x, self.norm5, tb, tg, query_evt, key, memory, self.EncDecAttn,
+                                        AttnCfg(1, N, P, W, 0, T2, T1, self.num_heads, 0, pd), Drop(dp, 1, P, T2), N, T2)
+            x, x1 = ops.layernorm_res(x, self.norm6.weight, self.norm6.bias, self.norm6.eps)
+            return self.SpatialFFN1.fused(x1, x, dp)                                                              # ref :243
         # spatial window attention over fuse(LN1 tgt + query_evt), value LN1 tgt                  ref :210-212
         tgt, t2 = ops.layernorm_res(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.SLMHSA.fused(pos_fuser(t2, tb, tg, add=query_evt), t2, tgt, Drop(dp, 1, T2 * P, N))

@@ -94,7 +94,8 @@ def _bn_rows(x2, bn):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     if isinstance(bn, SyncBatchNorm2d) and bn.training and dist.is_initialized() and dist.get_world_size() > 1:
-        return _SyncBNFn.apply(x2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True, None)
+        from ..dp import syncbn_group
+        return _SyncBNFn.apply(x2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True, syncbn_group())
     return F.batch_norm(x2, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
 
 

@@ -1154,6 +1154,223 @@ def mlpdwbn(x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, fram
     return _MlpDwbn.apply(x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, frames, T, p_drop, p_dp)
 
 
+# --------------------------------------------------------------------------- sub-layer nodes
+# One autograd node per residual sub-layer of a VidHRFormer block (ref/models/VidHRFormer.py:87-112,210-243): the pre-norm
+# LayerNorm, the positional fuse, the projections, the attention core / FFN and the residual epilogue are a fixed sequence
+# of kernel launches - nothing in between needs autograd's bookkeeping.  Against one node per kernel this removes ~3/4 of the
+# Python / autograd work per step (the 8-clip shards of c3 / c4 were bound by it) and the [R, C] gradient adds autograd
+# inserted where LN(x) feeds two consumers (they become the `residual` input of a dgrad GEMM's epilogue).
+def _raw_ln_fwd(x2, w, b, eps):
+    rows, C = x2.shape
+    y = torch.empty_like(x2)
+    st = torch.empty(2, rows, dtype=torch.float32, device=x2.device)
+    check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(st[0]), _ptr(st[1]), rows, C, eps, 0, _stream()),
+          "npvp_layernorm_fwd")
+    return y, st
+
+
+def _raw_ln_bwd(dy2, x2, w, b, st, dres, sk):
+    """-> dx, dw, db (None, None when the parameter gradients went into the sink)"""
+    L = lib()
+    rows, C = x2.shape
+    dx = torch.empty_like(x2)
+    dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
+    ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+    check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(st[0]), _ptr(st[1]), _ptr(dx), _ptr(dw), _ptr(db), rows, C,
+                               0, _ptr(dres), _sink_mode(sk), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+    if sk:
+        _sunk_ln_reduce(sk, ws, rows, C)
+        return dx, None, None
+    return dx, dw, db
+
+
+def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
+    PF = x.numel() // (N * T)
+    y = torch.empty_like(x)
+    st = torch.empty(2, N * T, dtype=torch.float32, device=x.device)
+    check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add), _ptr(beta), _ptr(gamma), _ptr(y), _ptr(st[0]), _ptr(st[1]), N, T, PF, 1e-5,
+                                 _stream()), "npvp_posfuse_fwd")
+    return y, st
+
+
+def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
+    """-> du [like x], dadd, dbeta, dgamma"""
+    PF = x.numel() // (N * T)
+    du = torch.empty_like(x)
+    dyxh = torch.empty_like(x) if gamma is not None else None
+    ws, wsn = _ws(8 * N * T, x.device)
+    check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(st[0]), _ptr(st[1]), _ptr(du), _ptr(dyxh), N, T, PF,
+                                 _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
+    dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and want_add) else None
+    dbeta = reduce_mid(dy.view(1, N, T * PF)).view(beta_shape)
+    dgamma = reduce_mid(dyxh.view(1, N, T * PF)).view(gamma.shape) if dyxh is not None else None
+    return du, dadd, dbeta, dgamma
+
+
+def _lin_grads(dy, x, w, b, sk):
+    """weight (+ bias) gradient of y = x w^T + b: into the sink on the gradient stream (-> None, None) or returned"""
+    has_b = b is not None
+    if sk and (has_b == (sk[1] is not None)):
+        _sunk_wgrad(dy, x, has_b, sk)
+        return None, None
+    g = linear_wgrad(dy, x, has_b)
+    return (g[0], g[1]) if has_b else (g, None)
+
+
+class _SelfAttnSublayer(torch.autograd.Function):
+    """y = x + drop(out_proj(attn(q = k = fuse(LN(x) [+ add]), v = LN(x))))   - spatial-window or temporal self-attention
+    (ref/models/VidHRFormer.py:87-88,94-107,210-212,217-221): LN, positional fuse (2 kernels), q|k GEMM, v GEMM, attention
+    core, out-projection GEMM with the dropout / drop-path + residual epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, lw, lb, eps, beta, gamma, add, wqk, bqk, wv, bv, wo, bo, cfg, drop, N, T):
+        # wqk / wv are the [:2C] / [2C:] row slices of in_proj_weight, sliced by the caller WITH grad mode on: a slice taken in
+        # here (grad mode off) would not be recognised as a view of a flat-buffer parameter by GradSink
+        _chk(x, lw, lb, beta, gamma, add, wqk, bqk, wv, bv, wo, bo)
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        x1, lst = _raw_ln_fwd(x2, lw, lb, eps)
+        beta_c = _c(beta)
+        gamma_c = None if gamma is None else _c(gamma)
+        add_c = None if add is None else _c(add)
+        fused, pst = _raw_posfuse_fwd(x1, add_c, beta_c, gamma_c, N, T)
+        qk = linear_fwd(fused, wqk, bqk)
+        v = linear_fwd(x1, wv, bv)
+        o = torch.empty_like(v)
+        _attn_fwd(qk[:, :C], qk[:, C:], v, o, cfg)
+        y = linear_fwd(o, wo, bo, residual=x2, drop=drop)
+        ctx.save_for_backward(x2, x1, lst, fused, pst, qk, v, o, lw, lb, gamma_c, add_c, wqk, bqk, wv, bv, wo, bo)
+        ctx.cfg = (cfg, drop, N, T, x.shape, beta.shape)
+        ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wqk, bqk), _wb_sink(wv, bv), _wb_sink(wo, bo))
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, x1, lst, fused, pst, qk, v, o, lw, lb, gamma, add, wqk, bqk, wv, bv, wo, bo = ctx.saved_tensors
+        cfg, drop, N, T, xshape, beta_shape = ctx.cfg
+        s_ln, s_qk, s_v, s_o = ctx.sinks
+        C = x2.shape[1]
+        dy2 = _c(dy).reshape(-1, C)
+        dz = drop_apply(dy2, drop) if drop.on else dy2
+        do = linear_dgrad(dz, wo)
+        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o)
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg)
+        dfused = linear_dgrad(dqk, wqk)
+        gwqk, gbqk = _lin_grads(dqk, fused, wqk, bqk, s_qk)
+        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dfused, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
+        # dx1 = dv Wv + du: the second consumer's gradient rides in as the dgrad GEMM's residual input (no separate add)
+        dx1 = torch.empty_like(x1)
+        gemm(1, 0, dv.shape[0], C, C, dv, dv.stride(0), wv, wv.stride(0), dx1, residual=du,
+             b_pre=WeightPlanes.get(wv, "D") if dv.shape[0] >= 256 else None, replay=True)
+        gwv, gbv = _lin_grads(dv, x1, wv, bv, s_v)
+        dx, glw, glb = _raw_ln_bwd(dx1, x2, lw, lb, lst, dy2, s_ln)
+        return (dx.view(xshape), glw, glb, None, dbeta, dgamma, dadd, gwqk, gbqk, gwv, gbv, gwo, gbo, None, None, None, None)
+
+
+class _CrossAttnSublayer(torch.autograd.Function):
+    """y = x + droppath_t(out_proj(attn(q = fuse(LN(x) + add), k = key, v = memory)))   - the decoder's encoder-decoder
+    attention (ref/models/VidHRFormer.py:229-239); key = fuse(memory) is layer invariant and supplied by the caller."""
+
+    @staticmethod
+    def forward(ctx, x, lw, lb, eps, beta, gamma, add, key, memory, wq, bq, wk, bk, wv, bv, wo, bo, cfg, drop, N, T):
+        _chk(x, lw, lb, beta, gamma, add, key, memory, wq, bq, wk, bk, wv, bv, wo, bo)
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        k2, m2 = _c(key).reshape(-1, C), _c(memory).reshape(-1, C)
+        x1, lst = _raw_ln_fwd(x2, lw, lb, eps)
+        beta_c = _c(beta)
+        gamma_c = None if gamma is None else _c(gamma)
+        add_c = None if add is None else _c(add)
+        query, pst = _raw_posfuse_fwd(x1, add_c, beta_c, gamma_c, N, T)
+        q = linear_fwd(query, wq, bq)
+        k = linear_fwd(k2, wk, bk)
+        v = linear_fwd(m2, wv, bv)
+        o = torch.empty_like(q)
+        _attn_fwd(q, k, v, o, cfg)
+        y = linear_fwd(o, wo, bo, residual=x2, drop=drop)
+        ctx.save_for_backward(x2, x1, lst, query, pst, q, k, v, o, k2, m2, lw, lb, gamma_c, add_c, wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.cfg = (cfg, drop, N, T, x.shape, beta.shape, key.shape, memory.shape)
+        ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wq, bq), _wb_sink(wk, bk), _wb_sink(wv, bv), _wb_sink(wo, bo))
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, x1, lst, query, pst, q, k, v, o, k2, m2, lw, lb, gamma, add, wq, bq, wk, bk, wv, bv, wo, bo = ctx.saved_tensors
+        cfg, drop, N, T, xshape, beta_shape, kshape, mshape = ctx.cfg
+        s_ln, s_q, s_k, s_v, s_o = ctx.sinks
+        C = x2.shape[1]
+        dy2 = _c(dy).reshape(-1, C)
+        dz = drop_apply(dy2, drop) if drop.on else dy2
+        do = linear_dgrad(dz, wo)
+        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _attn_bwd(q, k, v, do, dq, dk, dv, cfg)
+        dquery = linear_dgrad(dq, wq)
+        gq = _lin_grads(dq, query, wq, bq, s_q)
+        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dquery, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
+        dkey = linear_dgrad(dk, wk).view(kshape) if ctx.needs_input_grad[7] else None
+        gk = _lin_grads(dk, k2, wk, bk, s_k)
+        dmem = linear_dgrad(dv, wv).view(mshape) if ctx.needs_input_grad[8] else None
+        gv = _lin_grads(dv, m2, wv, bv, s_v)
+        dx, glw, glb = _raw_ln_bwd(du, x2, lw, lb, lst, dy2, s_ln)
+        return (dx.view(xshape), glw, glb, None, dbeta, dgamma, dadd, dkey, dmem, gq[0], gq[1], gk[0], gk[1], gv[0], gv[1], gwo, gbo,
+                None, None, None, None)
+
+
+class _FfnSublayer(torch.autograd.Function):
+    """y = x + drop3(linear2(drop2(GELU(linear1(LN(x))))))   (ref/models/VidHRFormer.py:110-112,224-226)"""
+
+    @staticmethod
+    def forward(ctx, x, lw, lb, eps, w1, b1, w2, b2, p):
+        _chk(x, lw, lb, w1, b1, w2, b2)
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        xn, lst = _raw_ln_fwd(x2, lw, lb, eps)
+        R, Fh = x2.shape[0], w1.shape[0]
+        d2, d3 = Drop(p), Drop(p)
+        h = torch.empty(R, Fh, dtype=torch.float32, device=x.device)
+        a = linear_fwd(xn, w1, b1, act=1, aux_out=h, drop=d2)
+        y = linear_fwd(a, w2, b2, residual=x2, drop=d3)
+        ctx.save_for_backward(x2, xn, lst, h, a, lw, lb, w1, b1, w2, b2)
+        ctx.cfg = (d2, d3, x.shape)
+        ctx.sinks = (_ln_sink(lw, lb), _wb_sink(w1, b1), _wb_sink(w2, b2))
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, lst, h, a, lw, lb, w1, b1, w2, b2 = ctx.saved_tensors
+        d2, d3, xshape = ctx.cfg
+        s_ln, s1, s2 = ctx.sinks
+        C = x2.shape[1]
+        dy2 = _c(dy).reshape(-1, C)
+        dz2 = drop_apply(dy2, d3) if d3.on else dy2
+        dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2)
+        gw2, gb2 = _lin_grads(dz2, a, w2, b2, s2)
+        dxn = linear_dgrad(dh, w1)
+        gw1, gb1 = _lin_grads(dh, xn, w1, b1, s1)
+        dx, glw, glb = _raw_ln_bwd(dxn, x2, lw, lb, lst, dy2, s_ln)
+        return dx.view(xshape), glw, glb, None, gw1, gb1, gw2, gb2, None
+
+
+def self_attn_sublayer(x, norm, beta, gamma, add, mha, cfg, drop, N, T):
+    C = mha.embed_dim
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    return _SelfAttnSublayer.apply(x, norm.weight, norm.bias, norm.eps, beta, gamma, add, w[:2 * C], b[:2 * C], w[2 * C:], b[2 * C:],
+                                   mha.out_proj.weight, mha.out_proj.bias, cfg, drop, N, T)
+
+
+def cross_attn_sublayer(x, norm, beta, gamma, add, key, memory, mha, cfg, drop, N, T):
+    C = mha.embed_dim
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    return _CrossAttnSublayer.apply(x, norm.weight, norm.bias, norm.eps, beta, gamma, add, key, memory, w[:C], b[:C], w[C:2 * C],
+                                    b[C:2 * C], w[2 * C:], b[2 * C:], mha.out_proj.weight, mha.out_proj.bias, cfg, drop, N, T)
+
+
+def ffn_sublayer(x, norm, lin1, lin2, p):
+    return _FfnSublayer.apply(x, norm.weight, norm.bias, norm.eps, lin1.weight, lin1.bias, lin2.weight, lin2.bias, p)
+
+
 class _Im2Col(torch.autograd.Function):
     """[F, H*W, C] -> [F*H*W, 9*C] patches of a 3x3 / pad-1 conv (tap-major columns); backward = col2im."""
 
