@@ -201,35 +201,42 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe):
 
     roof = None
     if probe:
-        per = ops.GemmProbe.summary()           # {(a_kc,b_kc): (launches, ms, flops, bytes)}
-        lay = {}
-        for k, (n, pms, pfl, pby) in per.items():
-            if n:
-                lay[LAYOUTS[k]] = {"launches": n, "avg_launch_us": round(1000.0 * pms / n, 2),
-                                   "achieved_tflops": round(pfl / (pms * 1e-3) / 1e12, 2),
-                                   "algorithmic_bytes_per_launch": round(pby / n), "total_ms": round(pms, 2)}
-        # dominant = the critical-path GEMM layout (forward / dgrad: same stream as the step) with the largest total time;
-        # the weight-gradient GEMMs run on the low-priority gradient stream UNDER other kernels, so their event-pair
-        # durations include time-sharing and are reported but not used for the roofline fraction
-        dom = max((k for k in lay if k != "wgrad"), key=lambda k: lay[k]["total_ms"], default=None)
-        if dom:
-            d = lay[dom]
+        per = ops.GemmProbe.summary()           # {((a_kc,b_kc), kernel id): (launches, ms, flops, bytes)}
+        groups = {}
+        for (lay, kid), (n, pms, pfl, pby) in per.items():
+            groups[f"{LAYOUTS[lay]}:{ops.GemmProbe.KERNELS[kid]}"] = {
+                "launches": n, "avg_launch_us": round(1000.0 * pms / n, 2), "achieved_tflops": round(pfl / (pms * 1e-3) / 1e12, 2),
+                "algorithmic_bytes_per_launch": round(pby / n), "total_ms": round(pms, 2)}
+        # dominant kernel = the one with the largest total time among the kernels of the critical path (forward and dgrad
+        # launches: same stream as the step).  The weight-gradient GEMMs run on the low-priority gradient stream UNDER other
+        # kernels, so their event-pair durations include time-sharing; they are reported but not used for the fraction.
+        crit = {}
+        for (lay, kid), (n, pms, pfl, pby) in per.items():
+            if LAYOUTS[lay] != "wgrad":
+                a = crit.setdefault(kid, [0, 0.0, 0.0, 0.0])
+                a[0] += n; a[1] += pms; a[2] += pfl; a[3] += pby
+        if crit:
+            kid = max(crit, key=lambda k: crit[k][1])
+            n, pms, pfl, pby = crit[kid]
+            kname = ops.GemmProbe.KERNELS[kid]
+            ach = pfl / (pms * 1e-3) / 1e12
             traffic = None
             tj = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{key}.json")
             if os.path.exists(tj) and not full:
                 # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command (separate
                 # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r02_hbm_traffic_<key>.*
-                ents = json.load(open(tj)).get("by_layout", {}).get(dom)
-                traffic = round(ents["hbm_bytes_per_dispatch"]) if ents else None
-            roof = {"bound": "mfma", "kernel": ops.gemm_kernel_name(dom), "layout": dom,
-                    "achieved": d["achieved_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(d["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4),
-                    "mfma_pipe_busy_frac": round(6 * d["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                    "launches": d["launches"], "avg_launch_us": d["avg_launch_us"], "by_layout": lay,
-                    "note": "achieved = ALGORITHMIC fp32-equivalent flops (2MNK) / event-pair time; each product costs 6 "
-                            "v_mfma_f32_32x32x16_bf16 (three-term bf16 split, fp32-grade), so frac <= 1/6 and "
-                            "mfma_pipe_busy_frac = 6 x frac is the share of the bf16 MFMA peak the pipe is doing",
+                ent = json.load(open(tj)).get("pooled", {}).get(kname)
+                traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
+            roof = {"bound": "mfma", "kernel": f"{kname} (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into "
+                                              "three bf16 terms, pre-split weight planes by LDS-DMA)" if kid == 2 else kname,
+                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "mfma_pipe_busy_frac": round(6 * ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
+                    "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel": groups,
+                    "note": "achieved = ALGORITHMIC fp32-equivalent flops (2MNK) / event-pair time over every forward and dgrad "
+                            "launch of this kernel in the timed region; each product costs 6 v_mfma_f32_32x32x16_bf16 (three-term "
+                            "bf16 split, fp32-grade), so frac <= 1/6 and mfma_pipe_busy_frac = 6 x frac is the share of the dense "
+                            "bf16 MFMA peak the matrix pipe delivers",
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
 
     res = {"key": key, "name": name, "B": B, "To": To, "Tp": Tp, "ms": ms, "frames_per_s": frames / (ms * 1e-3),

@@ -42,12 +42,12 @@ int npvp_stream_destroy(void* stream);
  *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 multiply by GELU'(aux_in), 4 multiply by [aux_in > 0]
  *   drop_mode 0: per element; 1: per row group key=(row/drop_g1)%drop_g2 (DropPath)
  * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
- * precision 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  precision 1 / 2: split precision - operands are split on
- * the fly into 2 / 3 bf16 terms and the 3 / 6 leading cross products are accumulated in fp32 on
- * v_mfma_f32_32x32x16_bf16 (relative product error ~2^-16 / ~2^-23).  precision 3 / 4 / 5: the same arithmetic as
- * 2 / 2 / 1 in other kernel organisations (producer-consumer waves; 16-deep double-buffered K-steps, 4 = default).
- * precision 6 (EXPERIMENTAL, not used by the path): two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 per product,
- * ~2^-22 - but only for operands inside fp16's exponent range (|x| < 65504, precision degrades below 2^-24).
+ * precision 0: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32; parity triage).  precision 4 (default): every fp32 operand is
+ * split into three bf16 terms and the six leading cross products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16
+ * (relative product error ~2^-23: fp32-grade).  precision 5: two terms, three products (~2^-16; opt-in for weight gradients).
+ * Kernels: gemm_wide_kernel (128 x 256 tiles, 4 waves, A split on the fly, B = pre-split planes `b_pre` copied by LDS-DMA:
+ * the large forward / dgrad shapes), gemm_wgrad_wide_kernel (weight gradients over >= 32 K token rows: row-major staging,
+ * transposing LDS reads, split-K), gemm_split_db_kernel (128 x 128 tiles: everything else).
  * colsum_a (a_kc = 0 only, nullable): receives colsum_a[m] = sum_k A[k][m] - the bias gradient falls out of the
  * weight-gradient GEMM's own operand staging (dW = dy^T x, db = column sums of dy), no extra pass over dy.
  * accumulate = 1: C += result and colsum_a += sums - a weight / bias gradient is accumulated straight into the live
@@ -56,6 +56,9 @@ int npvp_stream_destroy(void* stream);
  * When the tile count is small and K large (weight gradients) the reduction is split over
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);
+/* which kernel npvp_gemm_f32 picks for a shape: 0 gemm_f32_kernel, 1 gemm_split_db_kernel (128 x 128 tiles), 2
+ * gemm_wide_kernel (128 x 256 tiles, weight planes by LDS-DMA), 3 gemm_wgrad_wide_kernel.  Pure function (measurement aid). */
+int npvp_gemm_kernel_id(int a_kc, int b_kc, int M, int N, int K, int precision, int has_planes);
 int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B, long long ldb,
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
@@ -70,7 +73,7 @@ int npvp_frame_stats_finalize(const float* part, int parts_per_frame, float valu
 /* Weights change once per optimiser step but are staged by every tile of three GEMMs: split them ONCE into the bf16
  * term planes the split-precision kernel consumes (3 terms x N*K bf16 each, blocked like the LDS image).
  * F feeds y = x w^T (pass as b_pre with b_kc = 1), D feeds dx = dy w (b_pre with b_kc = 0).  b_pre is optional
- * (NULL = split B on the fly) and only honoured by precision 4 with a_kc = 1. */
+ * (NULL = split B on the fly, 128 x 128 kernel) and only honoured by precision 4 with a_kc = 1. */
 int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void* D, npvp_stream_t stream);
 /* The same for MANY weight views in one launch (after the optimiser step, ref/models/Predictor.py:136 opt.step()): desc is a
  * DEVICE array of `count` records of six 64-bit words {w, ld, N, K, F, D} (pointers as integers). */

@@ -16,6 +16,7 @@ SIGNATURES = {
     "npvp_stream_create_low_priority": (c_p, [c_p, c_p]),
     "npvp_stream_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
+    "npvp_gemm_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
                               c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_frame_stats_finalize": (c_int, [c_p, c_int, c_f, c_p, c_p, c_int, c_f, c_p]),

@@ -15,8 +15,10 @@
 //     ds_write_b64 - half the staging work per MFMA of the 128 x 128 kernel, and 48 MFMAs per wave and barrier
 //     instead of 24;
 //   * fragment reads per MFMA: 18 / 48 instead of 12 / 24;
-//   * the two workgroups of a CU run out of phase: one's prologue, epilogue (a 128 KB C tile leaves through a 20 GB/s
-//     per-CU share of HBM write bandwidth) and barrier waits sit under the other's MFMAs.  (First version: ONE 8-wave
+//   * two independent workgroups per CU: one's barrier waits and fragment-read latency sit under the other's MFMAs
+//     (measured and dropped: delaying the second-slot workgroups by half a tile so that the epilogues - a 128 KB C tile
+//     through a 20 GB/s per-CU share of HBM write bandwidth - interleave: no gain; padding the weight-gradient kernel's
+//     LDS so that only one of its workgroups fits a CU beside the critical path: step time unchanged, -10 % stand-alone).  (First version: ONE 8-wave
 //     workgroup per CU on a 256 x 256 tile - per-tile fixed cost 32-38 us against 39 us per 512 of K: 120 TF at K = 512.)
 // LDS image per operand and term: [k-group of 8][row][8 k] bf16, one conflict-free ds_read_b128 per MFMA fragment (lanes
 // 0-31 = rows of k-group 0, lanes 32-63 = k-group 1).  The A k-groups are skewed by 64 B so that the 16-lane groups of a
@@ -214,17 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_wide_k
   constexpr int ROWA = BM * 2, ROWB = BN * 2;                       // bytes per k-row of a plane
   constexpr int A_PLANE = 16 * ROWA, B_PLANE = 16 * ROWB, A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  // Weight gradients run on the low-priority gradient stream UNDER the critical path.  Two of these workgroups would take
-  // a whole CU (2 x 4 waves x 256 VGPRs, 2 x 72 KB LDS) for ~1 ms each and starve the critical-path kernel that arrives
-  // meanwhile.  The LDS allocation is padded to 84 KB: only ONE weight-gradient workgroup fits a CU, and beside it there
-  // is room for one forward / dgrad workgroup (74.5 KB LDS, 4 waves x 256 VGPRs) or for the low-register waves of the
-  // HBM-bound kernels.  NPVP_WGRAD_LDS_PAD=0 (measurement builds) restores two per CU.
-#ifndef NPVP_WGRAD_LDS_PAD
-#define NPVP_WGRAD_LDS_PAD 1
-#endif
-  constexpr int LDS_BYTES = NPVP_WGRAD_LDS_PAD ? 86016 : 2 * STAGE;
-  static_assert(LDS_BYTES >= 2 * STAGE, "stages must fit");
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
   // ---- (K-chunk z, tile): with splits % 8 == 0 chunk z is owned by XCD z % 8 (its tiles share each row block in ONE L2)
   int z, tl;
@@ -356,7 +348,7 @@ int wide_wgrad_splits(int M, int N, int K) {
   // measured 168 vs 166 TF at 20 480 rows, 144 vs 134 TF at 8 192 rows, 179 vs 189 TF at 114 688 rows.
   if ((K & 15) || M < 64 || N < 128 || K < 32768) return 0;
   const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
-  int s = (512 + tiles - 1) / tiles;
+  int s = (512 + tiles - 1) / tiles;        // (256 / 128 workgroups: c2 step 397 / 366 ms against 336 ms)
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
@@ -383,11 +375,15 @@ static bool wide_pays(int M, int N) {
   return cw <= c128;
 }
 
+// shape test of launch_gemm_wide (also behind npvp_gemm_kernel_id)
+bool gemm_wide_takes(int M, int N, int K) {
+  return !(K & 15) && !(N & 7) && M >= 128 && wide_pays(M, N);
+}
+
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream) {
-  if (!p.b_pre || p.splits != 1 || (p.K & 15) || (p.N & 7) || p.colsum || p.M < 128) return false;
+  if (!p.b_pre || p.splits != 1 || p.colsum || !gemm_wide_takes(p.M, p.N, p.K)) return false;
   if (((uintptr_t)p.b_pre & 15) != 0) return false;
   if (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0)) return false;
-  if (!wide_pays(p.M, p.N)) return false;
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + 255) / 256;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 6, p.tiles_m, p.tiles_n);

@@ -202,8 +202,11 @@ __global__ __launch_bounds__(256, 4) void mlpdw_mid_fwd_kernel(const float* __re
 //   psum[f][block] = (sum g, sum g*hhat) over the block's channels, g = da1 * gelu'(y1) * w1n   (norm1's backward statistics:
 //                    frameln_act_bwd then needs no statistics pass of its own)
 // part[chunk][tap 0..8 | bias][Ch] receives the weight-gradient partial sums (summed by sum_rows_kernel).
+#ifndef NPVP_MID_BWD_WAVES
+#define NPVP_MID_BWD_WAVES 2
+#endif
 template <int VEC>
-__global__ __launch_bounds__(256, 2) void mlpdw_mid_bwd_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
+__global__ __launch_bounds__(256, NPVP_MID_BWD_WAVES) void mlpdw_mid_bwd_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
                                                             const float* __restrict__ mean1, const float* __restrict__ rstd1,
                                                             const float* __restrict__ w1n, const float* __restrict__ b1n,
                                                             const float* __restrict__ wt, float* __restrict__ da1,

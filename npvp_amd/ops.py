@@ -241,10 +241,13 @@ class WeightPlanes:
 
 class GemmProbe:
     """bench.py's live roofline probe: when armed, every GEMM launch is bracketed by a pair of HIP events on the stream
-    it is launched on (no synchronisation; read after the timed region), keyed by operand layout:
-    (1,1) forward, (1,0) dgrad, (0,0) weight gradient."""
+    it is launched on (no synchronisation; read after the timed region), keyed by (layout, kernel): layout (1,1) forward,
+    (1,0) dgrad, (0,0) weight gradient; kernel = npvp_gemm_kernel_id (so the groups line up with the per-kernel rows of a
+    rocprofv3 trace of the same command)."""
     armed = False
-    records = []          # (start_event, end_event, flops, bytes, layout)
+    records = []          # (start_event, end_event, flops, bytes, (layout, kernel id))
+    KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel",
+               3: "npvp::gemm_wgrad_wide_kernel"}
 
     @classmethod
     def arm(cls):
@@ -256,22 +259,12 @@ class GemmProbe:
 
     @classmethod
     def summary(cls):
-        """{layout: (launches, total_ms, total_flops, total_algorithmic_bytes)} - call after torch.cuda.synchronize()."""
+        """{(layout, kernel id): (launches, total_ms, total_flops, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
         out = {}
-        for e0, e1, fl, by, lay in cls.records:
-            n, ms, f, b = out.get(lay, (0, 0.0, 0.0, 0.0))
-            out[lay] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+        for e0, e1, fl, by, key in cls.records:
+            n, ms, f, b = out.get(key, (0, 0.0, 0.0, 0.0))
+            out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
         return out
-
-
-def gemm_kernel_name(layout):
-    """what bench.py prints as the roofline kernel for 'forward' / 'dgrad' / 'wgrad'"""
-    if GEMM_PRECISION == 0:
-        return "npvp::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)"
-    if layout == "wgrad":
-        return "npvp::gemm_split_db_kernel<3,false,false> (128x128 tiles, split-K)"
-    return ("npvp::gemm_wide_kernel (256x256 / 256x128 tiles, 8 waves; A split on the fly, pre-split weight planes by "
-            "LDS-DMA; small shapes fall to npvp::gemm_split_db_kernel) - " + layout)
 
 
 class GradSink:
@@ -442,7 +435,8 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
           "npvp_gemm_f32")
     if probe:
         e1.record()
-        GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), (a_kc, b_kc)))
+        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, GEMM_PRECISION if precision is None else precision, int(b_pre is not None))
+        GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), ((a_kc, b_kc), kid)))
     return out
 
 
