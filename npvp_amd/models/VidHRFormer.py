@@ -117,11 +117,14 @@ class FrameLayerNorm(nn.Module):
             destination[prefix + name] = self.ref_view(p if keep_vars else p.detach())
 
     def _load_from_state_dict(self, state_dict, prefix, *args):
+        local = state_dict
         for name in ("weight", "bias"):
             k = prefix + name
             if k in state_dict and tuple(state_dict[k].shape) == self.normalized_shape:
-                state_dict[k] = state_dict[k].permute(1, 2, 0).reshape(-1)
-        super()._load_from_state_dict(state_dict, prefix, *args)
+                if local is state_dict:
+                    local = dict(state_dict)            # never rewrite the caller's dict
+                local[k] = state_dict[k].permute(1, 2, 0).reshape(-1)
+        super()._load_from_state_dict(local, prefix, *args)
 
     def forward(self, h, residual=None, frames=None, p_drop=0.0, p_dp=0.0, frames_per_sample=1):
         """GELU(LayerNorm(h)) (+dropout, +residual, +drop-path) on channels-last h [frames, H*W*Ch] - the form the

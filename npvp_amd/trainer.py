@@ -310,7 +310,8 @@ def vfi_batch_process(batch, to_list, tp_list):
 _CKPT_PREFIX = {"predictor": "predictor.", "enc": "VPTR_Enc.", "dec": "VPTR_Dec."}
 
 
-def save_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, epoch=0, global_step=0, scheduler_T0=None):
+def save_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, epoch=0, global_step=0, scheduler_T0=None,
+                              scheduler_eta_min=1e-7):
     sd = {}
     for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
         if m is not None:
@@ -318,14 +319,27 @@ def save_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, epo
     ck = {"state_dict": sd, "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "1.6.5"}
     if opt is not None:
         ck["optimizer_states"] = [opt.state_dict(predictor)]
-        ck["lr_schedulers"] = [{"T_0": scheduler_T0, "T_i": scheduler_T0, "T_mult": 1, "T_cur": float(epoch % scheduler_T0),
-                                "last_epoch": float(epoch)}] if scheduler_T0 else []
+        # the full state_dict of torch's CosineAnnealingWarmRestarts (ref/models/Predictor.py:213-215)
+        lr0 = opt.param_groups[0].get("initial_lr", opt.param_groups[0]["lr"])
+        ck["lr_schedulers"] = [{"T_0": scheduler_T0, "T_i": scheduler_T0, "T_mult": 1, "eta_min": scheduler_eta_min,
+                                "T_cur": float(epoch % scheduler_T0), "base_lrs": [lr0], "last_epoch": float(epoch),
+                                "_step_count": int(global_step) + 1, "_last_lr": [opt.param_groups[0]["lr"]],
+                                "_get_lr_called_within_step": False}] if scheduler_T0 else []
+        ck["loops"] = None
     torch.save(ck, path)
 
 
-def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, strict=True):
-    """Load a reference Stage-2 checkpoint (or one written by save_lightning_checkpoint).  Returns (epoch, global_step)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, strict=True, unsafe_pickle=False):
+    """Load a reference Stage-2 checkpoint (or one written by save_lightning_checkpoint).  Returns (epoch, global_step).
+    The file is read with torch.load(weights_only=True); unsafe_pickle=True falls back to full unpickling (arbitrary code
+    execution: trusted files only)."""
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)       # tensors / containers only: no pickle code execution
+    except Exception:
+        if not unsafe_pickle:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True (a Lightning checkpoint may pickle hyper-parameter "
+                               "objects); pass unsafe_pickle=True only for files you trust")
+        ck = torch.load(path, map_location="cpu", weights_only=False)
     sd = ck["state_dict"]
     for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
         if m is None:
