@@ -180,8 +180,11 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe):
         ops.GemmProbe.arm()
     fence()
     t0 = time.perf_counter()
+    host_max = 0.0
     for i in range(steps):
+        ti = time.perf_counter()
         out = step(warmup + i)
+        host_max = max(host_max, time.perf_counter() - ti)
     t_host = time.perf_counter() - t0          # Python + launch time: the host must stay ahead of the GPU
     fence()
     dt = time.perf_counter() - t0
@@ -196,7 +199,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe):
     ms = 1000.0 * dt / steps
     frames = world * B * (To + Tp)
     flops_step = 3 * 2 * forward_macs_per_clip(To, Tp, P["stochastic"]) * B          # per GPU, fwd+bwd
-    log(f"[{key}] {steps} timed steps: {ms:.2f} ms/step (host enqueue {1000.0 * t_host / steps:.2f} ms/step), "
+    log(f"[{key}] {steps} timed steps: {ms:.2f} ms/step (host enqueue {1000.0 * t_host / steps:.2f} ms/step, slowest {1000.0 * host_max:.2f}), "
         f"{frames / (ms * 1e-3):.0f} frames/s")
 
     roof = None

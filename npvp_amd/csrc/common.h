@@ -43,6 +43,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// acc += a * b as exactly one v_fmac_f32 (the optimiser can neither pair it into v_pk_fma_f32 nor split it).
+__device__ __forceinline__ void fmac_scalar(float& acc, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+#else
+  acc = fmaf(a, b, acc);
+#endif
+}
+
 // Block-wide sum for blockDim.x = NW*64 threads; `red` is NW floats of LDS.
 // Every thread gets the total.  Contains two barriers.
 template <int NW>

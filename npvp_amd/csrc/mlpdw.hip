@@ -280,9 +280,12 @@ __global__ __launch_bounds__(256, NPVP_MID_BWD_WAVES) void mlpdw_mid_bwd_kernel(
             acc.v[e] += wv[8 - (kx + 1)].v[e] * g0[ww].v[e] + wv[8 - (3 + kx + 1)].v[e] * g1[ww].v[e] + wv[8 - (6 + kx + 1)].v[e] * g2[ww].v[e];
             // weight gradient: dh2 at the output pixel times a1 at its 3x3 neighbourhood
             const float d = g1[w].v[e];
-            aw[kx + 1].v[e] += d * a0[ww].v[e];
-            aw[3 + kx + 1].v[e] += d * a1r[ww].v[e];
-            aw[6 + kx + 1].v[e] += d * a2[ww].v[e];
+            // one v_fmac_f32 each, kept out of the compiler's v_pk_fma_f32 pairing: the paired form needs 242 VGPRs
+            // (this one 188), is 5 % slower, and its results were not reproducible run to run while a weight-gradient
+            // GEMM shared the CUs
+            fmac_scalar(aw[kx + 1].v[e], d, a0[ww].v[e]);
+            fmac_scalar(aw[3 + kx + 1].v[e], d, a1r[ww].v[e]);
+            fmac_scalar(aw[6 + kx + 1].v[e], d, a2[ww].v[e]);
           }
         }
         stv<VEC>(of + (h * WW + w) * Ch + c, acc);

@@ -1128,13 +1128,10 @@ class _MlpDwbn(torch.autograd.Function):
         dwtb = torch.empty(10, hid, dtype=torch.float32, device=dev)
         psum = torch.empty(frames * (hid // 256) * 2, dtype=torch.float32, device=dev)
         ws, wsn = _ws(L.npvp_mlpdw_mid_bwd_workspace_bytes(frames, hid), dev)
-        # FENCE (kept until the cause is understood): the training step stopped being bitwise reproducible when the gradient
-        # stream was still busy with the weight-gradient / reduction kernels enqueued above while the fused-middle backward
-        # chain below (mid_bwd -> partial reduction -> transposes) ran: 7-9 distinct parameter digests in 12 identical 3-step
-        # runs, always a 64-byte run of one tap row of a depthwise weight gradient; 12 / 12 identical with the gradient
-        # stream off, with GradSink off, with the caching allocator off - and with this wait.  Every tensor the gradient
-        # stream touches is record_stream()ed (holding them until the join changed nothing).  Cost: < 0.5 % of a step
-        # (tests/test_hip_golden.py::test_training_step_is_bitwise_deterministic, DESIGN.md "known issues").
+        # Second line of defence: mlpdw_mid_bwd_kernel's packed-FMA build was not bitwise reproducible
+        # while a weight-gradient GEMM of the gradient stream shared the CUs.  The kernel now accumulates with scalar
+        # v_fmac_f32 and is reproducible without this wait (soak runs in DESIGN.md); the wait costs less than run-to-run
+        # noise, so it stays on by default (NPVP_MID_BWD_FENCE=0 removes it).
         if MID_BWD_FENCE and WgradStream._pending is not None:
             torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
         check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _ptr(stats[0]), _ptr(stats[1]), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
