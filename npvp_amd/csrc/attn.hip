@@ -547,6 +547,166 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
   }
 }
 
+// ---- backward for query sequences of 17..32 rows (the c2 decoder: T = 28): Q, dO and K staged ONCE in LDS.
+// attn_bwd_mfma_kernel<2,NK> needs each of Q / dO / K in both operand layouts and in both phases: ten tile loads in seven
+// dependent load phases at 248 VGPRs (2 waves / SIMD) - 1.0 ms for 1.64 GB at c2 (1.6 TB/s).  Here one wavefront = one
+// workgroup issues ALL its global loads up front (each tile once, 4 rows x 256 B per instruction), parks Q / dO / K in its own
+// (2L + S) x 272 B of LDS and takes every "R" and "G" operand tile from there (row stride 68 floats: both read patterns are
+// bank-conflict free); V is only ever needed as "R" tiles and stays in registers.  No barrier: the wave is alone in its
+// workgroup and LDS operations of one wave execute in order.  22.8 KB of LDS at T = 28 -> 7 waves per CU.
+template <int NIT>
+__device__ __forceinline__ void attn_stage_load(float4 (&r)[NIT], const float* src, long long ld, const AttnParams& p, long long g,
+                                                int nrows, int Tn, int head, int lane) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = 4 * it + (lane >> 4);
+    if (row < nrows) r[it] = ld4(src + attn_row(p, g, row, Tn) * ld + head * HD + (lane & 15) * 4);
+  }
+}
+template <int NIT>
+__device__ __forceinline__ void attn_stage_store(float* dst, const float4 (&r)[NIT], int nrows, int lane) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = 4 * it + (lane >> 4);
+    if (row < nrows) st4(dst + row * LDT + (lane & 15) * 4, r[it]);
+  }
+}
+__device__ __forceinline__ void attn_lds_r(AttnTileR& t, const float* xs, int nrows, int n, int c, int blk) {
+  const float* q = xs + min(16 * blk + n, nrows - 1) * LDT + 16 * c;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const float4 x = ld4(q + 4 * s4);
+    t.v[4 * s4 + 0] = x.x; t.v[4 * s4 + 1] = x.y; t.v[4 * s4 + 2] = x.z; t.v[4 * s4 + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void attn_lds_g(AttnTileG& t, const float* xs, int nrows, int n, int c, int blk) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t.v[i] = ld4(xs + min(16 * blk + 4 * c + i, nrows - 1) * LDT + 4 * n);
+}
+
+template <int NQ, int NK>
+__global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x, n = lane & 15, c = lane >> 4;
+  const long long wid = blockIdx.x;
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  float* Qs = smem;
+  float* Gs = Qs + L * LDT;
+  float* Ks = Gs + L * LDT;
+  AttnTileR vr[NK];
+  {
+    float4 sq[4 * NQ], sg[4 * NQ], sk[4 * NK];
+    attn_stage_load<4 * NK>(sk, p.k, p.ld_k, p, g, S, Tk, head, lane);
+    attn_stage_load<4 * NQ>(sq, p.q, p.ld_q, p, g, L, Tq, head, lane);
+    attn_stage_load<4 * NQ>(sg, p.go, p.ld_o, p, g, L, Tq, head, lane);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) attn_load_r(vr[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
+    __builtin_amdgcn_sched_barrier(0);      // every global load of this wave is in flight before the first wait
+    attn_stage_store<4 * NK>(Ks, sk, S, lane);
+    attn_stage_store<4 * NQ>(Qs, sq, L, lane);
+    attn_stage_store<4 * NQ>(Gs, sg, L, lane);
+  }
+  __syncthreads();                          // one wave per workgroup: orders the LDS writes before the reads below
+  // ---- orientation A per query block: softmax statistics of query 16qb+n (kept for phase B), dQ
+  float mxs[NQ], invs[NQ], rss[NQ];
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    AttnTileR qr, gr;
+    attn_lds_r(qr, Qs, L, n, c, qb);
+    attn_lds_r(gr, Gs, L, n, c, qb);
+    const int q = 16 * qb + n, qn = min(q, L - 1);
+    float sc[NK][4], dp[NK][4], mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      AttnTileR kr;
+      attn_lds_r(kr, Ks, S, n, c, kb);
+      const f32x4_t sa = attn_mm_d(kr, qr), da = attn_mm_d(vr[kb], gr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float s = sa[i] * p.scale;
+        if (j >= S || (p.mask_mode == 1 && j == S - 1 && q < L - 1)) s = -INFINITY;
+        sc[kb][i] = s; dp[kb][i] = da[i]; mx = fmaxf(mx, s);
+      }
+    }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[kb][i] = (sc[kb][i] == -INFINITY) ? 0.f : __expf(sc[kb][i] - mx); sum += sc[kb][i]; }
+    sum = quad_sum(sum);
+    const float inv = 1.f / sum;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float m = 1.f;
+        if (p.drop_thresh && j < S)
+          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+        sc[kb][i] *= inv;
+        dp[kb][i] *= m;
+        rs += dp[kb][i] * sc[kb][i];
+      }
+    rs = quad_sum(rs);
+    mxs[qb] = mx; invs[qb] = inv; rss[qb] = rs;
+    f32x4_t dq[4];
+    attn_zero(dq);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      float ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ds[i] = sc[kb][i] * (dp[kb][i] - rs) * p.scale;
+      AttnTileG kg;
+      attn_lds_g(kg, Ks, S, n, c, kb);
+      attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] += sum_j dS[q][j] K[j][d]
+    }
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb);
+  }
+  // ---- orientation B per key block: register i <-> (query 16qb + 4c+i, key 16kb + n): dK, dV
+#pragma unroll
+  for (int kb = 0; kb < NK; ++kb) {
+    f32x4_t dv[4], dk[4];
+    attn_zero(dv); attn_zero(dk);
+    const int key = 16 * kb + n;
+    AttnTileR kr;
+    attn_lds_r(kr, Ks, S, n, c, kb);
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+      AttnTileR qr, gr;
+      attn_lds_r(qr, Qs, L, n, c, qb);
+      attn_lds_r(gr, Gs, L, n, c, qb);
+      const f32x4_t sb = attn_mm_d(qr, kr), db = attn_mm_d(gr, vr[kb]);
+      float pd[4], ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ql = 4 * c + i, q = 16 * qb + ql;             // statistics of query q live in lane ql of block qb
+        const float mxq = __shfl(mxs[qb], ql, 64), invq = __shfl(invs[qb], ql, 64), rsq = __shfl(rss[qb], ql, 64);
+        const bool dead = key >= S || q >= L || (p.mask_mode == 1 && key == S - 1 && q < L - 1);
+        const float pr = dead ? 0.f : __expf(sb[i] * p.scale - mxq) * invq;
+        float m = 1.f;
+        if (p.drop_thresh && !dead)
+          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + key, p.drop_thresh, p.drop_inv_keep);
+        pd[i] = pr * m;
+        ds[i] = pr * (db[i] * m - rsq) * p.scale;
+      }
+      AttnTileG gg, qg;
+      attn_lds_g(gg, Gs, L, n, c, qb);
+      attn_lds_g(qg, Qs, L, n, c, qb);
+      attn_mm_rows(dv, pd, gg);                                  // dV[j][d] += sum_q Pd[q][j] dO[q][d]
+      attn_mm_rows(dk, ds, qg);                                  // dK[j][d] += sum_q dS[q][j] Q[q][d]
+    }
+    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb);
+    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb);
+  }
+}
+
 static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
                       int Tk, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, bool bwd) {
   if (head_dim != HD) { npvp_set_error("attn: head_dim must be 64"); return NPVP_ERR_ARG; }
@@ -627,13 +787,18 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
   const int L = p.L > p.S ? p.L : p.S;
   static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;
+  static const bool staged = getenv("NPVP_ATTN_BWD_UNSTAGED") == nullptr;   // A/B switch for the measurement in DESIGN.md
+  const size_t staged_lds = (size_t)(2 * p.L + p.S) * LDT * sizeof(float);
+  NPVP_CHECK_ARG(p.total < (1ll << 31), "attn_bwd: too many (group, head) pairs for one launch");
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
   if (!use_lds) {
     if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
     else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
-    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
-    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
+    else if (!staged && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
+    else if (!staged) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
+    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
+    else hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
   } else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();

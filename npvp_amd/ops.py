@@ -408,6 +408,9 @@ class WgradStream:
 
 
 # --------------------------------------------------------------------------- raw kernel wrappers
+GEMM_EXCLUSIVE = os.environ.get("NPVP_GEMM_EXCL", "0") == "1"
+
+
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None,
          replay=False):
@@ -423,6 +426,9 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
     # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
+    if GEMM_EXCLUSIVE and b_pre is not None and WgradStream._pending is not None:
+        # measurement switch: a critical-path GEMM starts only when the gradient stream has drained
+        torch.cuda.current_stream(A.device).wait_stream(WgradStream._pending[1])
     probe = GemmProbe.armed
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
