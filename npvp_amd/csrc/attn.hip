@@ -8,10 +8,13 @@
 //           the enc-dec case; mask_mode 1 = the encoder's "no query but the last sees the last
 //           time-step" mask (:100-102).
 // q/k/v/o carry their own row stride so that the q and k projections can live in one
-// [rows, 2C] buffer.  Sequence lengths are <= 32 and d = 64, so the core is LDS/latency bound,
-// not MFMA work: one wavefront per (group, head), q/k/v tiles staged in LDS with coalesced
-// 256-B row segments, softmax in registers, attention dropout replayed in backward from a
-// counter hash.  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
+// [rows, 2C] buffer.  Sequence lengths are <= 32 and d = 64, so the core is latency bound, not MFMA
+// work: one wavefront per (group, head); the shipped kernels run every 16x16 product on
+// v_mfma_f32_16x16x4_f32 (exact fp32) with operands taken straight from global memory
+// (attn_*_mfma_kernel) or, for the backward of 17..32 query rows, from tiles staged once in LDS
+// (attn_bwd_staged_kernel); softmax in registers, attention dropout replayed in backward from a counter
+// hash.  The first-generation LDS kernels (attn_fwd_kernel / attn_bwd_kernel) stay reachable through
+// NPVP_ATTN_LDS for A/B runs.  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
 #include "common.h"
 #include <cstdlib>
 
