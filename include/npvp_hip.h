@@ -192,6 +192,26 @@ int npvp_adamw_step(float* p, float* g, float* m, float* v, long long n, const f
                     float eps, float weight_decay, const float* clip, long long clip_begin, long long clip_end,
                     int write_back_grad, npvp_stream_t stream);
 
+/* ---- evaluation metrics on device (ref/utils/metrics.py:12-43 PSNR / MSEScore, :46-108 SSIM, called per
+ * predicted time-step by pred_ave_metrics :110-140).  Images are [N][C][H][W] fp32 (per_image = C*H*W); out is N floats.
+ *   sqdiff: out[n] = scale * sum_i ((x[n][i] - y[n][i]) / data_range)^2   (PSNR: scale = 1/per_image, then -10 log10(. + 1e-8)
+ *           on the N results; MSEScore: scale = 1, data_range = 1)
+ *   ssim:   out[n] = mean over (C,H,W) of the SSIM map, zero-padded Gaussian window; `taps` is a HOST array of window_size
+ *           floats (the normalised 1-D Gaussian; the reference's 2-D window is its outer product, :78-83); window_size in
+ *           {3,5,7,11}; N*C < 65536. */
+long long npvp_sqdiff_workspace_bytes(int N, long long per_image);
+int npvp_sqdiff_per_image(const float* x, const float* y, int N, long long per_image, float data_range, float scale, float* out,
+                          void* workspace, long long ws_bytes, npvp_stream_t stream);
+long long npvp_ssim_workspace_bytes(int N, int C, int H, int W);
+int npvp_ssim_per_image(const float* img1, const float* img2, int N, int C, int H, int W, const float* taps /* host */,
+                        int window_size, float* out, void* workspace, long long ws_bytes, npvp_stream_t stream);
+
+/* ---- input frames (ref/utils/dataset.py:835-858 VidToTensor + VidNormalize): uint8 HWC frames as decoded ->
+ * normalised fp32 (frames, C, H, W): dst = (src / 255 - mean[c]) / std[c].  mean / std are HOST arrays of C floats; C in {1,3,4};
+ * frames < 65536. */
+int npvp_u8hwc_to_f32chw(const void* src_u8, float* dst, long long frames, int H, int W, int C, const float* mean,
+                         const float* std, npvp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,10 +12,11 @@ from .trainer import (FlatAdamW, predictor_train_step, full_train_step, cosine_w
                       context_lists, rand_context_collate, rand_context_batch_process, vfi_batch_process,
                       save_lightning_checkpoint, load_lightning_checkpoint, GraphedTrainStep)
 from . import ops
+from . import metrics, data
 
 __all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
            "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
            "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "to_device_layout", "FlatAdamW", "predictor_train_step", "full_train_step", "context_lists",
            "rand_context_collate", "rand_context_batch_process", "vfi_batch_process",
            "save_lightning_checkpoint", "load_lightning_checkpoint", "GraphedTrainStep",
-           "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops"]
+           "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops", "metrics", "data"]

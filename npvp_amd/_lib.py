@@ -56,6 +56,11 @@ SIGNATURES = {
     "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_grad_norm_clip": (c_int, [c_p, c_ll, c_f, c_p, c_p, c_ll, c_p]),
     "npvp_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_ll, c_p, c_f, c_f, c_f, c_f, c_p, c_ll, c_ll, c_int, c_p]),
+    "npvp_sqdiff_workspace_bytes": (c_ll, [c_int, c_ll]),
+    "npvp_sqdiff_per_image": (c_int, [c_p, c_p, c_int, c_ll, c_f, c_f, c_p, c_p, c_ll, c_p]),
+    "npvp_ssim_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
+    "npvp_u8hwc_to_f32chw": (c_int, [c_p, c_p, c_ll, c_int, c_int, c_int, c_p, c_p, c_p]),
+    "npvp_ssim_per_image": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_ll, c_p]),
 }
 
 _lib = None

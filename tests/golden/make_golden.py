@@ -49,6 +49,23 @@ def import_reference():
     return ref_models, ref_vid, ref_sub
 
 
+def import_reference_metrics():
+    """ref/utils/metrics.py executed as-is.  The `utils` package's __init__ pulls in the dataset module (torchvision, cv2:
+    absent here), so the file is loaded as a member of an empty stand-in package whose `train_summary` sibling supplies the
+    one name it imports (`load_ckpt`, only used when a checkpoint path is passed)."""
+    import importlib.util
+    pkg = types.ModuleType('refutils')
+    pkg.__path__ = ['/root/reference/utils']
+    ts = types.ModuleType('refutils.train_summary')
+    ts.load_ckpt = None
+    sys.modules.update({'refutils': pkg, 'refutils.train_summary': ts})
+    spec = importlib.util.spec_from_file_location('refutils.metrics', '/root/reference/utils/metrics.py')
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['refutils.metrics'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 REPORT = []
 
 
@@ -490,6 +507,56 @@ def main():
     check("randctx.gB", mine.nrmlp.B.grad, ref.nrmlp.B.grad)
     save("predictor_randctx_S", out=npy(yr[0]), mu_o=npy(yr[1]), mu_p=npy(yr[3]), g_obs=npy(xr.grad), gB=npy(ref.nrmlp.B.grad),
          g_tied=npy(ref.transformer.norm.weight.grad), meta=np.array([N, T, 141, 142, 143, 144]))
+
+    # ------------------------------------------------------------------ continuous time: reset_pos_coor with fractional
+    # time-steps (ref Predictor.py:352-359, CoorGenerator submodules.py:339-366)
+    N, T = 2, 7
+    tl = torch.linspace(0, T - 1, T)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, dropout=0.0, drop_path=0.0)
+    ref = R.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'SPADE', 'layer', 256, 1, False, 2, norm=nn.LayerNorm(512), **kw)
+    mine = oracle.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'SPADE', 'layer', 256, 1, False, 2, **kw)
+    O.key_hashed_fill(ref, 151); O.key_hashed_fill(mine, 151)
+    to_f, tp_f = torch.tensor([0.0, 1.5, 3.25]), torch.tensor([3.75, 4.5, 5.0, 6.5, 7.0])      # Tp changes from 4 to 5
+    ref.reset_pos_coor(to_f, tp_f); mine.reset_pos_coor(to_f, tp_f)
+    feats = O.synth_features((N, 3, 512, 8, 8), 152)
+    cot = O.seeded_randn((N, 5, 512, 8, 8), 153)
+    ref.train(); mine.train()
+    xr = feats.clone().requires_grad_(); xm = feats.clone().requires_grad_()
+    yr, ym = ref(xr), mine(xm)
+    (yr * yr * cot).sum().backward(); (ym * ym * cot).sum().backward()
+    check("fractime.out", ym, yr); check("fractime.g_obs", xm.grad, xr.grad); check("fractime.gB", mine.nrmlp.B.grad, ref.nrmlp.B.grad)
+    save("predictor_fractime_D", out=npy(yr), g_obs=npy(xr.grad), gB=npy(ref.nrmlp.B.grad),
+         coor_p=npy(ref.predict_coor), meta=np.array([N, T, 151, 152, 153]))
+
+    # ------------------------------------------------------------------ evaluation metrics (ref utils/metrics.py)
+    from oracle import metrics as OM
+    RM = import_reference_metrics()
+    arrays = {}
+    for tag, shape, rng in (("g64", (3, 1, 64, 64), 1.0), ("rgb128", (2, 3, 128, 128), 255.0), ("odd", (2, 3, 45, 70), 1.0)):
+        a = torch.rand(shape, generator=torch.Generator().manual_seed(161)) * rng
+        b = (a + 0.1 * rng * O.seeded_randn(shape, 162)).clamp(0, rng)
+        ps = RM.PSNR(a, b, data_range=rng, mean_flag=False); ms = RM.MSEScore(a, b, mean_flag=False)
+        ss = RM.SSIM()(a / rng, b / rng, mean_flag=False)
+        check(f"metrics.{tag}.psnr", OM.psnr_per_image(a, b, rng), ps); check(f"metrics.{tag}.mse", OM.mse_per_image(a, b), ms)
+        check(f"metrics.{tag}.ssim", OM.ssim_per_image(a / rng, b / rng), ss)
+        arrays.update({f"{tag}_psnr": ps.numpy(), f"{tag}_mse": ms.numpy(), f"{tag}_ssim": ss.numpy(),
+                       f"{tag}_psnr_mean": np.float32(RM.PSNR(a, b, data_range=rng)), f"{tag}_ssim_mean": RM.SSIM()(a / rng, b / rng).numpy(),
+                       f"{tag}_mse_mean": np.float32(RM.MSEScore(a, b))})
+    ss7 = RM.SSIM(window_size=7)(a, b, mean_flag=False)
+    check("metrics.odd.ssim_w7", OM.ssim_per_image(a, b, 7), ss7)
+    arrays["odd_ssim_w7"] = ss7.numpy()
+
+    class _Shift(nn.Module):            # a stand-in "model" with the call convention pred_ave_metrics expects
+        def forward(self, past, fut, mask):
+            return (fut * 0.9 + 0.05 * past[:, -1:],)
+    loader = [(O.synth_features((2, 2, 1, 32, 32), 163 + i), O.synth_features((2, 3, 1, 32, 32), 173 + i)) for i in range(2)]
+    renorm = lambda t: t * 0.5 + 0.25
+    pam = RM.pred_ave_metrics(_Shift(), loader, RM.PSNR, renorm, 3, device='cpu')
+    check("metrics.pred_ave_psnr", torch.tensor(OM.pred_ave_metrics(_Shift(), loader, lambda x, y: OM.psnr_per_image(x, y).mean(), renorm, 3)),
+          torch.tensor(pam))
+    arrays["pred_ave_psnr"] = pam
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **arrays)
+    print("wrote metrics.npz")
 
     with open(os.path.join(HERE, "ORACLE_VS_REFERENCE.txt"), "w") as f:
         f.write("# oracle (CPU restatement) vs imported reference, rel-L2, torch %s, generated by make_golden.py\n" % torch.__version__)

@@ -318,3 +318,23 @@ def case_randctx(impl, dev):
     y = m(x, xp)
     (y[0] * y[0] * cot).sum().backward()
     return dict(out=y[0], mu_o=y[1], mu_p=y[3], g_obs=x.grad, gB=m.nrmlp.B.grad, g_tied=m.transformer.norm.weight.grad)
+
+
+def case_fractime(impl, dev):
+    """Continuous time: a deterministic predictor built for integer steps, re-pointed with reset_pos_coor at fractional
+    context / target times (and a different number of targets)."""
+    N, T = 2, 7
+    h = torch.linspace(0, 7, 8)
+    tl = torch.linspace(0, T - 1, T)
+    m = impl.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'SPADE', 'layer', 256, 1, False, 2, evt_former=True,
+                       learn_evt_token=False, evt_former_num_layers=2, dropout=0.0, drop_path=0.0)
+    O.key_hashed_fill(m, 151)
+    m = m.to(dev)
+    m.reset_pos_coor(torch.tensor([0.0, 1.5, 3.25]), torch.tensor([3.75, 4.5, 5.0, 6.5, 7.0]))
+    feats = O.synth_features((N, 3, 512, 8, 8), 152).to(dev)
+    cot = O.seeded_randn((N, 5, 512, 8, 8), 153).to(dev)
+    m.train()
+    x = feats.clone().requires_grad_()
+    y = m(x)
+    (y * y * cot).sum().backward()
+    return dict(out=y, g_obs=x.grad, gB=m.nrmlp.B.grad, coor_p=m.predict_coor)

@@ -1,0 +1,134 @@
+"""Frame-folder loader: folder walker, sampler and geometric transforms on the CPU; the uint8 -> normalised
+fp32 kernel and the loader end to end on the GPU.  The reference's dataset module needs torchvision / cv2 (absent here), so
+these are restated-semantics and property tests, not reference-vector tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from npvp_amd import data as D            # noqa: E402
+
+DEV = "cuda:0"
+
+
+def make_tree(root, folders=3, frames=(23, 20, 7), size=(140, 160), rgb=True, seed=0):
+    """folders of PNG frames whose pixel values encode (folder, frame) so that order mistakes are visible"""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    truth = {}
+    for f in range(folders):
+        d = root / f"vid_{f:03d}"
+        d.mkdir(parents=True)
+        for t in range(frames[f]):
+            a = rng.integers(0, 256, size=size + ((3,) if rgb else ()), dtype=np.uint8)
+            a[0, 0] = f; a[0, 1] = t
+            Image.fromarray(a, 'RGB' if rgb else 'L').save(d / f"frame_{t:04d}.png")
+            truth[(f, t)] = a
+    return truth
+
+
+def test_frame_folder_clips_centres_the_remainder(tmp_path):
+    make_tree(tmp_path, size=(8, 8))
+    clips = D.frame_folder_clips(tmp_path, 10)
+    # 23 frames -> 2 clips starting at frame 1 (remainder 3: one dropped in front, two behind); 20 -> 2 clips; 7 -> none
+    assert len(clips) == 4
+    assert [p.name for p in clips[0]] == [f"frame_{t:04d}.png" for t in range(1, 11)]
+    assert [p.name for p in clips[1]] == [f"frame_{t:04d}.png" for t in range(11, 21)]
+    assert clips[2][0].parent.name == "vid_001" and clips[3][-1].name == "frame_0019.png"
+
+
+def test_shard_indices_partition_the_epoch():
+    n, bs, world = 103, 4, 3
+    per_rank = [D.shard_indices(n, bs, r, world, seed=5, epoch=2) for r in range(world)]
+    assert len({len(p) for p in per_rank}) == 1 and len(per_rank[0]) == (n // (bs * world)) * bs
+    flat = sorted(i for p in per_rank for i in p)
+    assert len(set(flat)) == len(flat) and set(flat) <= set(range(n))
+    assert per_rank[0] != D.shard_indices(n, bs, 0, world, seed=5, epoch=3)           # reshuffled per epoch
+    assert per_rank[1] == D.shard_indices(n, bs, 1, world, seed=5, epoch=2)           # and reproducible
+    full = [D.shard_indices(10, 4, r, 4, shuffle=False, drop_last=False) for r in range(4)]
+    assert all(len(p) == 3 for p in full) and sorted(set(i for p in full for i in p)) == list(range(10))
+
+
+def test_clip_dataset_geometry(tmp_path):
+    from PIL import Image
+    truth = make_tree(tmp_path, folders=1, frames=(6,), size=(140, 160), rgb=False)
+    clips = D.frame_folder_clips(tmp_path, 6)
+    ds = D.ClipDataset(2, 4, clips, "grey_scale", center_crop=(120, 120), resize=(64, 64))
+    clip = ds[0]
+    assert clip.shape == (6, 64, 64, 1) and clip.dtype == np.uint8
+    ref = Image.fromarray(truth[(0, 3)][10:130, 20:140], 'L').resize((64, 64), Image.BILINEAR)
+    assert np.array_equal(clip[3, :, :, 0], np.asarray(ref))
+    plain = D.ClipDataset(2, 4, clips, "grey_scale")[0]
+    assert np.array_equal(plain[5, :, :, 0], truth[(0, 5)])
+    # flips: one decision per clip and axis, reproducible per (seed, epoch, index), and all four outcomes occur
+    seen = set()
+    for s in range(24):
+        f = D.ClipDataset(2, 4, clips, "grey_scale", flips=True, seed=s)
+        a = f[0]
+        assert np.array_equal(a, f[0])
+        h = np.array_equal(a[:, :, ::-1], plain); v = np.array_equal(a[:, ::-1], plain); hv = np.array_equal(a[:, ::-1, ::-1], plain)
+        assert np.array_equal(a, plain) or h or v or hv
+        seen.add((np.array_equal(a, plain), h, v, hv))
+    assert len(seen) == 4
+    with pytest.raises(ValueError):
+        D.ClipDataset(2, 4, clips, "YUV")
+
+
+def test_dataset_table_matches_reference_constants():
+    assert set(D.DATASETS) == {"KTH", "KITTI", "SMMNIST", "BAIR", "CityScapes"}
+    assert D.DATASETS["KTH"]["norm"] == ((0.6013795,), (2.7570653,)) and D.DATASETS["KTH"]["center_crop"] == (120, 120)
+    assert D.DATASETS["KITTI"]["norm"] != D.DATASETS["KITTI"]["renorm"]            # the reference's two sets differ
+    x = torch.rand(2, 3, 4, 4)
+    n, r = D.VidNormalize(*D.DATASETS["BAIR"]["norm"]), D.VidReNormalize(*D.DATASETS["BAIR"]["renorm"])
+    assert torch.allclose(r(n(x)), x, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(1, 64, 64), (3, 128, 128), (3, 45, 70), (4, 5, 3)])
+def test_u8_to_normalised_kernel(C, H, W):
+    from npvp_amd import ops
+    from npvp_amd._lib import lib
+    F_ = 7
+    rng = np.random.default_rng(C * 100 + H)
+    src = rng.integers(0, 256, size=(F_, H, W, C), dtype=np.uint8)
+    mean = np.linspace(0.2, 0.6, C).astype(np.float32); std = np.linspace(1.1, 2.3, C).astype(np.float32)
+    s = torch.from_numpy(src).to(DEV)
+    out = torch.empty(F_, C, H, W, device=DEV)
+    ops.check(lib().npvp_u8hwc_to_f32chw(s.data_ptr(), out.data_ptr(), F_, H, W, C, mean.ctypes.data, std.ctypes.data,
+                                         ops._stream()), "npvp_u8hwc_to_f32chw")
+    ref = (src.astype(np.float32).transpose(0, 3, 1, 2) / 255.0 - mean[None, :, None, None]) / std[None, :, None, None]
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= 2e-6
+    assert lib().npvp_u8hwc_to_f32chw(s.data_ptr(), out.data_ptr(), F_, H, W, 2, mean.ctypes.data, std.ctypes.data, None) < 0
+
+
+@pytest.mark.gpu
+def test_clip_loader_end_to_end(tmp_path):
+    truth = make_tree(tmp_path, folders=3, frames=(23, 20, 7), size=(64, 64), rgb=True)
+    ds = D.build_dataset("BAIR", tmp_path, 2, 8, train=False)
+    assert len(ds) == 4
+    mean, std = D.DATASETS["BAIR"]["norm"]
+    got = {}
+    for rank in range(2):
+        ld = D.ClipLoader(ds, 1, mean, std, DEV, shuffle=True, rank=rank, world=2, seed=3, num_workers=3)
+        ld.set_epoch(1)
+        assert len(ld) == 2
+        for (past, fut), idx in zip(ld, D.shard_indices(4, 1, rank, 2, seed=3, epoch=1)):
+            assert past.shape == (1, 2, 3, 64, 64) and fut.shape == (1, 8, 3, 64, 64) and past.is_cuda
+            got[idx] = torch.cat([past, fut], 1).cpu()
+    assert sorted(got) == [0, 1, 2, 3]
+    m = torch.tensor(mean).view(1, 1, 3, 1, 1); s = torch.tensor(std).view(1, 1, 3, 1, 1)
+    for idx, clip in got.items():
+        f = 0 if idx < 2 else 1
+        t0 = (1 if f == 0 else 0) + 10 * (idx % 2)
+        ref = np.stack([truth[(f, t0 + t)] for t in range(10)], 0)[None]
+        ref = (torch.from_numpy(ref).float().permute(0, 1, 4, 2, 3) / 255.0 - m) / s
+        assert torch.allclose(clip, ref, atol=2e-6)
+        back = D.VidReNormalize(*D.DATASETS["BAIR"]["renorm"])(clip) * 255.0
+        assert torch.equal(back.round().to(torch.uint8), torch.from_numpy(np.stack([truth[(f, t0 + t)] for t in range(10)], 0)[None]).permute(0, 1, 4, 2, 3))
+    with pytest.raises(RuntimeError):
+        D.ClipLoader(ds, 1, mean, std, "cpu")

@@ -136,6 +136,12 @@ def test_unified_random_context(impl):
     GC.compare(GC.case_randctx(impl, DEV), GC.load("predictor_randctx_S"), TOL, tag=f"randctx[{MODE}]")
 
 
+def test_reset_pos_coor_fractional_times(impl):
+    """continuous-time queries (ref Predictor.py:352-359): fractional context / target times and a new target count on a
+    model built for integer steps, against the reference-generated vectors"""
+    GC.compare(GC.case_fractime(impl, DEV), GC.load("predictor_fractime_D"), TOL, tag=f"fractime[{MODE}]")
+
+
 def test_optimizer_state_is_torch_adamw_format(impl, tmp_path):
     """FlatAdamW.state_dict() is what torch.optim.AdamW / a Lightning checkpoint's optimizer_states[0] hold
     (parameter order = predictor.parameters()): it loads into a stock AdamW and round-trips through a .ckpt."""

@@ -89,6 +89,10 @@ def test_unified_random_context():
     GC.compare(GC.case_randctx(oracle, "cpu"), GC.load("predictor_randctx_S"), TOL)
 
 
+def test_reset_pos_coor_fractional_times():
+    GC.compare(GC.case_fractime(oracle, "cpu"), GC.load("predictor_fractime_D"), TOL)
+
+
 def test_full_step_from_pixels():
     import npvp_amd
     GC.compare(GC.case_full_step(oracle, npvp_amd, "cpu"), GC.load("train_step_full_S"), TOL)
