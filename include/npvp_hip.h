@@ -212,6 +212,15 @@ int npvp_ssim_per_image(const float* img1, const float* img2, int N, int C, int 
 int npvp_u8hwc_to_f32chw(const void* src_u8, float* dst, long long frames, int H, int W, int C, const float* mean,
                          const float* std, npvp_stream_t stream);
 
+/* ---- frozen Stage-1 autoencoder epilogues (SURVEY 8f #1 stage 2; ref/models/ResNetAutoEncoder.py:51-261, submodules.py:9-95):
+ * with BatchNorm folded into the frozen convolution weights, conv -> BN -> ReLU (-> + skip) is MIOpen's convolution plus ONE pass
+ *   out = act(x + bias[c]) + residual      act: 0 none, 1 ReLU, 2 tanh, 3 sigmoid; residual nullable
+ *   layout 0: x [outer][inner = C], channel = column (channels_last memory); layout 1: x [outer = N*C][inner = H*W] (NCHW).
+ * act_bwd: dx = g * act'(.) from the forward output y (no residual), the decoder's input-gradient path. */
+int npvp_bias_act(const float* x, const float* bias, const float* residual, float* out, long long outer, long long inner, int C,
+                  int layout, int act, npvp_stream_t stream);
+int npvp_act_bwd(const float* g, const float* y, float* dx, long long n, int act, npvp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,8 @@ SIGNATURES = {
     "npvp_sqdiff_per_image": (c_int, [c_p, c_p, c_int, c_ll, c_f, c_f, c_p, c_p, c_ll, c_p]),
     "npvp_ssim_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "npvp_u8hwc_to_f32chw": (c_int, [c_p, c_p, c_ll, c_int, c_int, c_int, c_p, c_p, c_p]),
+    "npvp_bias_act": (c_int, [c_p, c_p, c_p, c_p, c_ll, c_ll, c_int, c_int, c_int, c_p]),
+    "npvp_act_bwd": (c_int, [c_p, c_p, c_p, c_ll, c_int, c_p]),
     "npvp_ssim_per_image": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_ll, c_p]),
 }
 

@@ -3,16 +3,106 @@
 FULL training step of Stage 2: frozen encoder on past+future frames (no grad), frozen decoder on the
 predicted features with the gradient flowing through it to the predictor (ref/models/Predictor.py:172-194).
 
-SURVEY 8f "next" row #1, first stage: this is the caller-side of the hot path and runs as STOCK
-PyTorch-ROCm (MIOpen convolutions, rocBLAS matmuls) - no hand-written kernels here yet.  Same class names,
-constructor signatures and state-dict keys as the reference, so Stage-1 checkpoints load.  Only the
-`learn_3d=False` configuration (every shipped config) is supported.
+SURVEY 8f "next" row #1.  Same class names, constructor signatures and state-dict keys as the reference, so Stage-1
+checkpoints load.  Only the `learn_3d=False` configuration (every shipped config) is supported.
+  stage 1: the modules as built run on stock PyTorch-ROCm (MIOpen convolutions, rocBLAS matmuls);
+  stage 2: `to_device_layout` -> `fuse_frozen_autoencoder`: the pair is frozen and in eval mode in Stage 2, so every
+           conv -> BatchNorm -> ReLU (-> + skip) group becomes a `FoldedConvAct`: the convolution with the BatchNorm folded
+           into its weights (MIOpen) + ONE hand-written epilogue pass `npvp_bias_act` (csrc/ae.hip) instead of separate
+           bias / BatchNorm / ReLU / skip-add passes; the decoder's input gradient goes through `npvp_act_bwd`.
 """
 import functools
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
+
+
+_ACT_CODE = {nn.ReLU: 1, nn.Tanh: 2, nn.Sigmoid: 3}
+
+
+def _bn_scale_shift(bn):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return s, bn.bias - bn.running_mean * s
+
+
+class FoldedConvAct(nn.Module):
+    """[pad ->] conv / transposed conv [-> BatchNorm2d (eval)] [-> ReLU / Tanh / Sigmoid] of a FROZEN network as one convolution
+    with folded weights (MIOpen, no bias) and one epilogue pass out = act(conv + bias[c]) (+ residual)  (csrc/ae.hip)."""
+
+    def __init__(self, conv, bn=None, act=None, pad=None):
+        super().__init__()
+        assert isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)) and conv.groups == 1
+        self.transposed = isinstance(conv, nn.ConvTranspose2d)
+        w = conv.weight.detach()
+        b = conv.bias.detach() if conv.bias is not None else torch.zeros(conv.out_channels, dtype=w.dtype, device=w.device)
+        if bn is not None:
+            assert isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.track_running_stats, "fold needs an eval-mode BatchNorm2d"
+            s, t = _bn_scale_shift(bn)
+            w = w * (s.view(1, -1, 1, 1) if self.transposed else s.view(-1, 1, 1, 1))
+            b = b * s + t
+        fmt = torch.channels_last if conv.weight.is_contiguous(memory_format=torch.channels_last) and not conv.weight.is_contiguous() \
+            else torch.contiguous_format
+        self.register_buffer("weight", w.contiguous(memory_format=fmt))
+        self.register_buffer("bias", b.detach().float().contiguous())
+        self.stride, self.padding, self.dilation = conv.stride, conv.padding, conv.dilation
+        self.output_padding = conv.output_padding if self.transposed else None
+        self.act = 0 if act is None else _ACT_CODE[type(act)]
+        self.pad = pad
+
+    def forward(self, x, residual=None):
+        if self.pad is not None:
+            x = self.pad(x)
+        if self.transposed:
+            y = F.conv_transpose2d(x, self.weight, None, self.stride, self.padding, self.output_padding, 1, self.dilation)
+        else:
+            y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, 1)
+        return ops.bias_act(y, self.bias, self.act, residual)
+
+
+def _fold_sequential(seq):
+    """Sequential of [pad] conv [BatchNorm2d] [activation] groups -> Sequential of FoldedConvAct"""
+    out, mods, i = [], list(seq), 0
+    while i < len(mods):
+        pad = None
+        if isinstance(mods[i], (nn.ReflectionPad2d, nn.ReplicationPad2d)):
+            pad = mods[i]; i += 1
+        conv = mods[i]; i += 1
+        assert isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)), f"cannot fold {type(conv).__name__}"
+        bn = act = None
+        if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+            bn = mods[i]; i += 1
+        if i < len(mods) and type(mods[i]) in _ACT_CODE:
+            act = mods[i]; i += 1
+        out.append(FoldedConvAct(conv, bn, act, pad))
+    return nn.Sequential(*out)
+
+
+def fuse_frozen_autoencoder(enc, dec):
+    """In-place module surgery on an eval-mode pair that already holds its final weights; freezes its parameters (do it after load_state_dict:
+    the folded modules no longer carry the reference's state-dict keys).  Returns (enc, dec)."""
+    for m in (enc, dec):
+        assert not m.training, "fuse_frozen_autoencoder: eval mode only (BatchNorm must use its running statistics)"
+        for q in m.parameters():
+            q.requires_grad_(False)          # Stage 2 never trains the pair (ref/models/Predictor.py:17-25)
+    with torch.no_grad():
+        for name, mod in list(enc.named_children()):
+            if isinstance(mod, nn.Sequential):
+                setattr(enc, name, _fold_sequential(mod))
+            elif isinstance(mod, Factorized3DConvAttn):
+                mod.spatial_conv = _fold_sequential(mod.spatial_conv)[0]
+                a = mod.attn2d
+                if isinstance(a.norm_func, nn.BatchNorm2d):      # fold the BatchNorm behind out_proj into the Linear
+                    s, t = _bn_scale_shift(a.norm_func)
+                    a.out_proj.weight.mul_(s.view(-1, 1))
+                    a.out_proj.bias.copy_(a.out_proj.bias * s + t)
+                    a.norm_func = nn.Identity()
+            elif isinstance(mod, ResnetBlock):
+                mod.conv_block = _fold_sequential(mod.conv_block)
+        dec.model = _fold_sequential(dec.model)
+    return enc, dec
 
 
 class NonLocalAttenion2D(nn.Module):
@@ -69,6 +159,11 @@ class Factorized3DConvAttn(nn.Module):
         self.attn1d = None
 
     def forward(self, x, T):
+        if isinstance(self.spatial_conv, FoldedConvAct):       # fused: relu(conv + b) + x in the epilogue pass
+            if self.conv_first:
+                return self.attn2d(self.spatial_conv(x, residual=x)) + x
+            y = self.attn2d(x)
+            return self.spatial_conv(y, residual=y) + x
         if self.conv_first:
             return self.attn2d(self.spatial_conv(x) + x) + x
         y = self.attn2d(x)
@@ -98,6 +193,8 @@ class ResnetBlock(nn.Module):
         self.conv_block = nn.Sequential(*layers)
 
     def forward(self, x):
+        if len(self.conv_block) == 2 and isinstance(self.conv_block[1], FoldedConvAct):      # fused: skip-add in the epilogue
+            return self.conv_block[1](self.conv_block[0](x), residual=x)
         return x + self.conv_block(x)
 
 
@@ -189,4 +286,5 @@ def to_device_layout(enc, dec, device):
     """Move the frozen pair to an MI355X.  The ENCODER runs in torch.channels_last (MIOpen's NHWC kernels: 27.5 -> 24.8 ms
     for 640 frames of 64x64, and its (N*T,H,W,C) output is the predictor's canonical layout, so the layout transpose at
     the predictor's entry disappears); the decoder stays NCHW (NHWC measured slower: 9.0 -> 11.2 ms fwd + input-grad)."""
-    return enc.to(device).to(memory_format=torch.channels_last), dec.to(device)
+    enc, dec = enc.to(device).to(memory_format=torch.channels_last), dec.to(device)
+    return fuse_frozen_autoencoder(enc.eval(), dec.eval())

@@ -1429,3 +1429,41 @@ def canonical_to_nchw(x, N, T, H, W):
 
 def mean_mid(x):
     return _MeanMid.apply(x)
+
+
+# --------------------------------------------------------------------------- frozen autoencoder epilogues (csrc/ae.hip)
+class _BiasAct(torch.autograd.Function):
+    """out = act(x + bias[c]) (+ residual) on an (N,C,H,W) tensor in contiguous or channels_last memory; bias is frozen.
+    Gradient w.r.t. x only (the decoder's input-gradient path), through the saved OUTPUT."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, act):
+        _chk(x, bias, residual)
+        N, C, H, W = x.shape
+        cl = (not x.is_contiguous()) and x.is_contiguous(memory_format=torch.channels_last)
+        if not cl and not x.is_contiguous():
+            x = x.contiguous()
+        if residual is not None and residual.stride() != x.stride():
+            residual = residual.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+        out = torch.empty_like(x)
+        outer, inner, layout = (N * H * W, C, 0) if cl else (N * C, H * W, 1)
+        check(lib().npvp_bias_act(_ptr(x), _ptr(bias), _ptr(residual), _ptr(out), outer, inner, C, layout, act, _stream()),
+              "npvp_bias_act")
+        ctx.act, ctx.cl, ctx.has_res = act, cl, residual is not None
+        if x.requires_grad or (residual is not None and residual.requires_grad):
+            if residual is not None:
+                raise NotImplementedError("bias_act: backward with a fused skip-add is not on the Stage-2 path")
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous(memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)
+        dx = torch.empty_like(y)
+        check(lib().npvp_act_bwd(_ptr(g), _ptr(y), _ptr(dx), y.numel(), ctx.act, _stream()), "npvp_act_bwd")
+        return dx, None, None, None
+
+
+def bias_act(x, bias, act=0, residual=None):
+    return _BiasAct.apply(x, bias, residual, act)

@@ -256,13 +256,20 @@ def case_predictor_full(impl, dev):
     return dict(y_strided=y.flatten()[::7], y_mean=y.mean(), y_std=y.std())
 
 
-def case_ae(impl, dev, tag="64"):
-    """Frozen autoencoder (stock-torch restatement): encoder features, decoder frames, decoder input-gradient."""
+def case_ae(impl, dev, tag="64", device_layout=None):
+    """Frozen autoencoder: encoder features, decoder frames, decoder input-gradient.  device_layout = the product's
+    to_device_layout (channels_last encoder + BatchNorm folding + fused epilogue kernels)."""
     ci, ngf, nd, nres, S, out_layer = {"64": (1, 64, 3, 2, 64, 'Sigmoid'), "128": (3, 32, 4, 3, 128, 'Tanh')}[tag]
     enc = impl.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
     dec = impl.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
     O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122)
-    enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+    enc, dec = enc.eval(), dec.eval()
+    if device_layout is None:
+        enc, dec = enc.to(dev), dec.to(dev)
+    else:
+        for q in list(enc.parameters()) + list(dec.parameters()):
+            q.requires_grad_(False)
+        enc, dec = device_layout(enc, dec, dev)
     x = torch.rand(1, 2, ci, S, S, generator=torch.Generator().manual_seed(123)).to(dev)
     with torch.no_grad():
         feats = enc(x)

@@ -1,5 +1,5 @@
 """Frozen autoencoder (stock PyTorch-ROCm) timing at the c1 full-step size: encoder on 32x20 frames (no grad), decoder
-forward + input-gradient on 32x10 frames; contiguous vs channels_last.  Usage: python tools/ae_bench.py"""
+forward + input-gradient on 32x10 frames; contiguous vs channels_last vs the fused product path.  Usage: python tools/ae_bench.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,11 +20,14 @@ def timeit(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 
-for cl in (False, True):
+for cl in (False, True, "fused"):
     enc, dec = npvp_amd.build_frozen_autoencoder(AE, 1)
-    enc, dec = enc.to(dev), dec.to(dev)
-    if cl:
-        enc, dec = enc.to(memory_format=torch.channels_last), dec.to(memory_format=torch.channels_last)
+    if cl == "fused":          # the product path: channels_last encoder, folded BatchNorm, csrc/ae.hip epilogues
+        enc, dec = npvp_amd.to_device_layout(enc, dec, dev)
+    else:
+        enc, dec = enc.to(dev), dec.to(dev)
+        if cl:
+            enc, dec = enc.to(memory_format=torch.channels_last), dec.to(memory_format=torch.channels_last)
     x = torch.rand(32, 20, 1, 64, 64, device=dev)
     f = torch.rand(32, 10, 512, 8, 8, device=dev, requires_grad=True)
 
