@@ -24,6 +24,7 @@
 // 0-31 = rows of k-group 0, lanes 32-63 = k-group 1).  The A k-groups are skewed by 64 B so that the 16-lane groups of a
 // ds_write_b64 (4 rows x 4 k-quads) cover all 32 banks once.
 #include "gemm.h"
+#include <cstdlib>
 
 // measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_WIDE_ABL=n on the GPU box; results INVALID): 1 = epilogue without its
 // global stores, 2 = no K loop
@@ -375,21 +376,33 @@ static bool wide_pays(int M, int N) {
   return cw <= c128;
 }
 
-// shape test of launch_gemm_wide (also behind npvp_gemm_kernel_id)
-bool gemm_wide_takes(int M, int N, int K) {
-  return !(K & 15) && !(N & 7) && M >= 128 && wide_pays(M, N);
+// Which instantiation takes an [M, N] x K forward / dgrad problem with pre-split planes: 0 none (128 x 128 gemm_split_db_kernel),
+// 1 = 128 x 256 tiles, 2 = 128 x 128 tiles of the same kernel for outputs too small to fill the chip with wide tiles (the
+// per-GPU shards of the multi-GPU configs: 8 192 token rows: 173 / 169 TF forward / dgrad against 155 / 153 TF of the older
+// 128 x 128 kernel; 2 048 rows: 70 / 90 against 58 / 81).  Also behind npvp_gemm_kernel_id.
+static int wide_variant(int M, int N, int K) {
+  if ((K & 15) || (N & 7) || M < 128) return 0;
+  if (wide_pays(M, N)) return 1;
+  return N % 128 == 0 ? 2 : 0;
 }
+bool gemm_wide_takes(int M, int N, int K) { return wide_variant(M, N, K) != 0; }
 
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream) {
-  if (!p.b_pre || p.splits != 1 || p.colsum || !gemm_wide_takes(p.M, p.N, p.K)) return false;
-  if (((uintptr_t)p.b_pre & 15) != 0) return false;
-  if (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0)) return false;
+  if (!p.b_pre || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return false;
+  const int v = wide_variant(p.M, p.N, p.K);
+  if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return false;
+  const int bn = v == 1 ? 256 : 128;
   p.tiles_m = (p.M + 127) / 128;
-  p.tiles_n = (p.N + 255) / 256;
+  p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 6, p.tiles_m, p.tiles_n);
   dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+  if (v == 1) {
+    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+  } else {
+    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
+  }
   return true;
 }
 
