@@ -57,7 +57,8 @@ int npvp_stream_destroy(void* stream);
  * workgroups through `workspace` (npvp_gemm_workspace_bytes; 0 = never split). */
 long long npvp_gemm_workspace_bytes(int M, int N, int K);
 /* which kernel npvp_gemm_f32 picks for a shape: 0 gemm_f32_kernel, 1 gemm_split_db_kernel (128 x 128 tiles), 2
- * gemm_wide_kernel (128 x 256 tiles, weight planes by LDS-DMA), 3 gemm_wgrad_wide_kernel.  Pure function (measurement aid). */
+ * gemm_wide_kernel<2,4,2,2> (128 x 256 tiles, weight planes by LDS-DMA), 3 gemm_wgrad_wide_kernel, 4 gemm_wide_kernel<2,2,2,2>
+ * (the same kernel on 128 x 128 tiles: outputs too small to fill the chip with wide tiles).  Pure function (measurement aid). */
 int npvp_gemm_kernel_id(int a_kc, int b_kc, int M, int N, int K, int precision, int has_planes);
 int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long long lda, const float* B, long long ldb,
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,

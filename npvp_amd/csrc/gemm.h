@@ -196,6 +196,7 @@ inline int pick_colgroups(long long b_bytes, int tiles_m, int tiles_n) {
 // took the launch (shape / operand requirements met), false if the caller should use the 128 x 128 kernel.
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream);
 bool gemm_wide_takes(int M, int N, int K);
+int gemm_wide_variant(int M, int N, int K);      // 0 not taken, 1 = 128 x 256 tiles, 2 = 128 x 128 tiles
 // weight gradients (A = dy [K][M], B = x [K][N], both fp32): split count (0 = shape not taken) and launch; the caller sets
 // p.K / p.C / p.colsum for the split exactly as for the 128 x 128 kernel and runs the split-K reductions afterwards.
 int wide_wgrad_splits(int M, int N, int K);

@@ -520,10 +520,12 @@ extern "C" int npvp_split_weights_batched(const void* desc, int count, hipStream
 
 // Which kernel npvp_gemm_f32 runs for a problem (a pure function of the shape; bench.py groups its live event-pair timings
 // by it so that they line up with the per-kernel rows of a rocprofv3 trace): 0 gemm_f32_kernel, 1 gemm_split_db_kernel,
-// 2 gemm_wide_kernel, 3 gemm_wgrad_wide_kernel.  has_planes = b_pre will be passed.
+// 2 gemm_wide_kernel (128 x 256 tiles), 3 gemm_wgrad_wide_kernel, 4 gemm_wide_kernel's 128 x 128 instantiation.  has_planes = b_pre
+// will be passed.
 extern "C" int npvp_gemm_kernel_id(int a_kc, int b_kc, int M, int N, int K, int precision, int has_planes) {
   if (precision == 0) return 0;
-  if (precision == 4 && a_kc && has_planes && pick_splits(M, N, K) == 1 && gemm_wide_takes(M, N, K)) return 2;
+  if (precision == 4 && a_kc && has_planes && pick_splits(M, N, K) == 1 && gemm_wide_takes(M, N, K))
+    return gemm_wide_variant(M, N, K) == 1 ? 2 : 4;
   if (precision == 4 && !a_kc && !b_kc && wide_wgrad_splits(M, N, K) > 0) return 3;
   return 1;
 }

@@ -386,6 +386,7 @@ static int wide_variant(int M, int N, int K) {
   return N % 128 == 0 ? 2 : 0;
 }
 bool gemm_wide_takes(int M, int N, int K) { return wide_variant(M, N, K) != 0; }
+int gemm_wide_variant(int M, int N, int K) { return wide_variant(M, N, K); }
 
 bool launch_gemm_wide(GemmParams& p, hipStream_t stream) {
   if (!p.b_pre || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return false;

@@ -246,8 +246,8 @@ class GemmProbe:
     rocprofv3 trace of the same command)."""
     armed = False
     records = []          # (start_event, end_event, flops, bytes, (layout, kernel id))
-    KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel",
-               3: "npvp::gemm_wgrad_wide_kernel"}
+    KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel<2, 4, 2, 2>",
+               3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>"}
 
     @classmethod
     def arm(cls):
