@@ -377,13 +377,17 @@ static bool wide_pays(int M, int N) {
 }
 
 // Which instantiation takes an [M, N] x K forward / dgrad problem with pre-split planes: 0 none (128 x 128 gemm_split_db_kernel),
-// 1 = 128 x 256 tiles, 2 = 128 x 128 tiles of the same kernel for outputs too small to fill the chip with wide tiles (the
-// per-GPU shards of the multi-GPU configs: 8 192 token rows: 173 / 169 TF forward / dgrad against 155 / 153 TF of the older
-// 128 x 128 kernel; 2 048 rows: 70 / 90 against 58 / 81).  Also behind npvp_gemm_kernel_id.
+// 1 = 128 x 256 tiles, 2 = 128 x 128 tiles of the same kernel for small outputs (the per-GPU shards of the multi-GPU configs:
+// 8 192 token rows: 173 / 169 TF forward / dgrad against 155 / 153 TF of the older 128 x 128 kernel; 2 048 rows: 70 / 90
+// against 58 / 81).  Also behind npvp_gemm_kernel_id.
 static int wide_variant(int M, int N, int K) {
   if ((K & 15) || (N & 7) || M < 128) return 0;
   if (wide_pays(M, N)) return 1;
-  return N % 128 == 0 ? 2 : 0;
+  // 128 x 128 tiles of this kernel run 2 workgroups per CU, the older 128 x 128 kernel 3: this one wins while all its tiles are
+  // resident at once (<= 512: 6 144 rows 154 / 149 TF against 132 / 140), beyond that the other's third slot does (20 480 rows:
+  // 179 against 182 TF)
+  const int tiles128 = ((M + 127) / 128) * (N / 128);
+  return (N % 128 == 0 && tiles128 <= 512) ? 2 : 0;
 }
 bool gemm_wide_takes(int M, int N, int K) { return wide_variant(M, N, K) != 0; }
 int gemm_wide_variant(int M, int N, int K) { return wide_variant(M, N, K); }
