@@ -95,6 +95,12 @@ int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
 int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate,
                               npvp_stream_t stream);
 
+/* The decoder's final LayerNorm + ReLU writing the reference's (N,T,C,H,W) tensor directly (ref/models/VidHRFormer.py:150-159:
+ * norm, relu_, permute(0,1,4,2,3)).  P must be 64, C 256 or 512; mean / rstd per token row as npvp_layernorm_fwd writes them, so
+ * the backward is npvp_transpose of dy followed by npvp_layernorm_bwd. */
+int npvp_layernorm_nchw_fwd(const float* x, const float* w, const float* b, float* out_nchw, float* mean, float* rstd, int frames,
+                            int P, int C, float eps, int relu, npvp_stream_t stream);
+
 /* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
  * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL
  * (the `+ query_evt` of ref/models/VidHRFormer.py:211,236), beta/gamma [T][per_frame] (gamma NULL for

@@ -26,6 +26,7 @@ SIGNATURES = {
     "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),
     "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_layernorm_bwd_reduce": (c_int, [c_p, c_p, c_p, c_ll, c_int, c_int, c_p]),
+    "npvp_layernorm_nchw_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_int, c_p]),
     "npvp_frameln_act_bwd_reduce": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_frame_stats": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
     "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),

@@ -52,6 +52,54 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 }
 
+// ---- the decoder's FINAL LayerNorm + ReLU writing the reference's (N,T,C,H,W) tensor directly (SURVEY 2b K9;
+// ref/models/VidHRFormer.py:150-159: norm, relu_, permute(0,1,4,2,3)).  Block = one frame of P = 64 token rows: the
+// statistics of the 64 rows first (one wave per row, as ln_fwd_kernel), then 128-channel slabs are normalised into an LDS
+// tile [128 c][64 p] (row stride 65: both the channel-major writes and the pixel-major reads are conflict free) and leave as
+// 256-B rows of the NCHW frame.  One kernel instead of LayerNorm + an LDS-tiled transpose: 8 B/elem instead of 16.
+template <int C>
+__global__ __launch_bounds__(256) void ln_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, float eps, int relu) {
+  constexpr int NV = C / 256, P = 64;
+  __shared__ float tile[128][P + 1];
+  __shared__ float smu[P], srs[P];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long f = blockIdx.x;
+  const float* xf = x + f * P * C;
+  for (int i = 0; i < 16; ++i) {
+    const int p = wave * 16 + i;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { v[k] = ld4(xf + p * C + (k * 64 + lane) * 4); s += v[k].x + v[k].y + v[k].z + v[k].w; }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float a0 = v[k].x - mu, a1 = v[k].y - mu, a2 = v[k].z - mu, a3 = v[k].w - mu;
+      q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+    if (lane == 0) { smu[p] = mu; srs[p] = rs; mean[f * P + p] = mu; rstd[f * P + p] = rs; }
+  }
+  __syncthreads();
+  float* of = out + f * C * P;
+  for (int s0 = 0; s0 < C; s0 += 128) {
+    const float w0 = w[s0 + lane], w1 = w[s0 + 64 + lane], b0 = b[s0 + lane], b1 = b[s0 + 64 + lane];
+    for (int i = 0; i < 16; ++i) {
+      const int p = wave * 16 + i;
+      const float mu = smu[p], rs = srs[p];
+      float y0 = (xf[p * C + s0 + lane] - mu) * rs * w0 + b0, y1 = (xf[p * C + s0 + 64 + lane] - mu) * rs * w1 + b1;
+      if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+      tile[lane][p] = y0; tile[64 + lane][p] = y1;
+    }
+    __syncthreads();
+    for (int j = 0; j < 32; ++j) { const int cl = wave * 32 + j; of[(long long)(s0 + cl) * P + lane] = tile[cl][lane]; }
+    __syncthreads();
+  }
+}
+
 // backward: dx per row; per-block partial dw/db in `partial[blockIdx][2][C]`
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -461,6 +509,19 @@ extern "C" int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float
     npvp_set_error("layernorm_bwd_reduce: launch failed");
     return NPVP_ERR_LAUNCH;
   }
+  return NPVP_OK;
+}
+
+// LayerNorm(C) (+ReLU) over the token rows of `frames` frames of 64 pixels, output in the reference's (frames, C, 8, 8) layout
+// (K9).  C in {256, 512}.  mean / rstd are per token row, as npvp_layernorm_fwd writes them: the backward is npvp_transpose of dy
+// + npvp_layernorm_bwd (a fused backward through the same LDS tile was 3x slower than those two kernels: 771 vs 239 us at c2).
+extern "C" int npvp_layernorm_nchw_fwd(const float* x, const float* w, const float* b, float* out, float* mean, float* rstd,
+                                       int frames, int P, int C, float eps, int relu, hipStream_t stream) {
+  NPVP_CHECK_ARG(x && w && b && out && mean && rstd && frames > 0, "layernorm_nchw_fwd: bad arguments");
+  NPVP_CHECK_ARG(P == 64 && (C == 256 || C == 512), "layernorm_nchw_fwd: 64-pixel frames, C = 256 or 512");
+  if (C == 512) hipLaunchKernelGGL(ln_nchw_fwd_kernel<512>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
+  else hipLaunchKernelGGL(ln_nchw_fwd_kernel<256>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
+  NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
 

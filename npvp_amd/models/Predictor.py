@@ -88,7 +88,7 @@ class Predictor(nn.Module):
             o1.record_stream(main)
             out = torch.cat([o0, o1], dim=0)
         else:
-            out = self.transformer.forward_canonical(zc, memory, op, pp, self.fuser, self.TP)
+            return self.transformer.forward_canonical(zc, memory, op, pp, self.fuser, self.TP, nchw=True)
         return ops.canonical_to_nchw(out, N, self.TP, H, W)
 
     def _nchw(self, t):

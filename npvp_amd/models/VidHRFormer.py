@@ -414,18 +414,22 @@ class VidHRformerDecoderNAR(nn.Module):
                                                          Spatial_FFN_hidden_ratio, dim_feedforward), num_layers)
         self.num_layers, self.norm, self.return_intermediate = num_layers, norm, return_intermediate
 
-    def forward_canonical(self, qe, memory, memory_pos, tgt_pos, pos_fuser, T2):
-        """qe (N,H,W,C), memory (N,T1,H,W,C) canonical -> (N,T2,H,W,C) canonical, after LN + ReLU."""
+    def forward_canonical(self, qe, memory, memory_pos, tgt_pos, pos_fuser, T2, nchw=False):
+        """qe (N,H,W,C), memory (N,T1,H,W,C) canonical -> (N,T2,H,W,C) canonical, after LN + ReLU
+        (nchw=True: the reference's (N,T2,C,H,W) layout instead)."""
         N, H, W, C = qe.shape
         out = torch.zeros(N, T2, H, W, C, dtype=torch.float32, device=qe.device)
         fused_memory = pos_fuser(memory, *memory_pos)
         for layer in self.layers:
             out = layer(out, qe, memory, memory_pos, tgt_pos, pos_fuser, fused_memory)
+        if nchw and self.norm is not None and ops.layernorm_nchw_supported(out, H, W):
+            # K9: the final norm + ReLU writes the reference's (N,T,C,H,W) layout itself (no transpose kernel)
+            return ops.layernorm_nchw(out, self.norm.weight, self.norm.bias, self.norm.eps, True, N, T2, H, W)
         if self.norm is not None:
             out = ops.layernorm(out, self.norm.weight, self.norm.bias, self.norm.eps, relu=True)
         else:
             out = torch.relu(out)
-        return out
+        return ops.canonical_to_nchw(out, N, T2, H, W) if nchw else out
 
     def forward(self, query_evt, memory, memory_pos, tgt_pos, pos_fuser):
         """query_evt (N,T2,C,H,W), memory (N,T1,C,H,W) -> (N,T2,C,H,W)   (reference signature)"""
@@ -433,5 +437,4 @@ class VidHRformerDecoderNAR(nn.Module):
         T1 = memory.shape[1]
         qe = ops.nchw_to_canonical(query_evt[:, :1]).view(N, H, W, C)
         mem = ops.nchw_to_canonical(memory).view(N, T1, H, W, C)
-        out = self.forward_canonical(qe, mem, memory_pos, tgt_pos, pos_fuser, T2)
-        return ops.canonical_to_nchw(out, N, T2, H, W)
+        return self.forward_canonical(qe, mem, memory_pos, tgt_pos, pos_fuser, T2, nchw=True)

@@ -612,6 +612,58 @@ def layernorm(x, w, b, eps=1e-5, relu=False):
     return _LayerNorm.apply(x, w, b, eps, relu)
 
 
+class _LayerNormNchw(torch.autograd.Function):
+    """LayerNorm(C) (+ReLU) over the token rows of canonical x [F, 64, C], result in the reference's (N,T,C,H,W) layout
+    (ref VidHRFormer.py:150-159): one forward kernel instead of LayerNorm + transpose."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, relu, N, T, H, W):
+        _chk(x, w, b)
+        C = x.shape[-1]
+        x3 = _c(x).reshape(N * T, H * W, C)
+        out = torch.empty(N, T, C, H, W, dtype=torch.float32, device=x.device)
+        mean = torch.empty(N * T * H * W, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(lib().npvp_layernorm_nchw_fwd(_ptr(x3), _ptr(w), _ptr(b), _ptr(out), _ptr(mean), _ptr(rstd), N * T, H * W, C, eps,
+                                            int(relu), _stream()), "npvp_layernorm_nchw_fwd")
+        ctx.save_for_backward(x3, w, b, mean, rstd)
+        ctx.relu, ctx.shape = int(relu), x.shape
+        ctx.sink = _ln_sink(w, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        # dy (N,T,C,H,W) -> canonical rows (the LDS-tiled transpose), then the row-wise LayerNorm backward: a fused backward
+        # through the forward kernel's tile was 3x slower than these two kernels
+        x3, w, b, mean, rstd = ctx.saved_tensors
+        F_, P, C = x3.shape
+        L = lib()
+        dy = _c(dy)
+        dy2 = torch.empty(F_ * P, C, dtype=torch.float32, device=dy.device)
+        check(L.npvp_transpose(_ptr(dy), _ptr(dy2), F_, C, P, _stream()), "npvp_transpose")
+        rows = F_ * P
+        x2 = x3.reshape(rows, C)
+        dx = torch.empty_like(x2)
+        sk = ctx.sink
+        dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
+        ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+        check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw), _ptr(db),
+                                   rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+        if sk:
+            _sunk_ln_reduce(sk, ws, rows, C)
+            return (dx.reshape(ctx.shape),) + (None,) * 8
+        return (dx.reshape(ctx.shape), dw, db) + (None,) * 6
+
+
+def layernorm_nchw_supported(x, H, W):
+    return x.is_cuda and H * W == 64 and x.shape[-1] in (256, 512)
+
+
+def layernorm_nchw(x, w, b, eps, relu, N, T, H, W):
+    """canonical (N,T,H,W,C) -> LayerNorm (+ReLU) -> (N,T,C,H,W)"""
+    return _LayerNormNchw.apply(x, w, b, eps, relu, N, T, H, W)
+
+
 class _LayerNormRes(torch.autograd.Function):
     """(x, LN(x)) for the pre-norm residual pattern  x + f(LN(x))  of every sub-layer (ref VidHRFormer.py:87-112).
     Returning x through the Function lets backward fold the residual branch's gradient into the LayerNorm backward

@@ -369,3 +369,31 @@ def test_flat_adamw_matches_torch(K):
         close(o2.grad_norm().reshape(()), n1.reshape(()), tol=1e-5, what="grad norm")
         for (k1, p1), (k2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
             close(p2, p1, tol=1e-5, what=f"step {it} {k1}")
+
+
+@pytest.mark.parametrize("C,relu", [(512, True), (512, False), (256, True)])
+def test_layernorm_writes_nchw(K, C, relu):
+    """K9: the decoder's final LayerNorm (+ReLU) writing (N,T,C,H,W) directly, forward and backward, against
+    LayerNorm + transpose through the separate kernels and against torch on the CPU."""
+    from npvp_amd import ops
+    N, T, H, W = 2, 3, 8, 8
+    x = O.seeded_randn((N, T, H, W, C), 151)
+    w = 1.0 + 0.2 * O.seeded_randn((C,), 152); b = 0.1 * O.seeded_randn((C,), 153)
+    cot = O.seeded_randn((N, T, C, H, W), 154)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5)
+    y = (torch.relu(y) if relu else y).permute(0, 1, 4, 2, 3)
+    ref = torch.autograd.grad((y * cot).sum(), [xr, wr, br])
+    ins = [g(t.clone().requires_grad_()) for t in (x, w, b)]
+    assert ops.layernorm_nchw_supported(ins[0], H, W)
+    yg = ops.layernorm_nchw(ins[0], ins[1], ins[2], 1e-5, relu, N, T, H, W)
+    got = torch.autograd.grad((yg * cot.to(DEV)).sum(), ins)
+    close(yg, y.detach(), tol=1e-6, what="y")
+    for a, b_, n in zip(got, ref, ["dx", "dw", "db"]):
+        close(a, b_, tol=2e-6, what=n)
+    ins2 = [g(t.clone().requires_grad_()) for t in (x, w, b)]
+    y2 = ops.canonical_to_nchw(ops.layernorm(ins2[0], ins2[1], ins2[2], 1e-5, relu=relu), N, T, H, W)
+    got2 = torch.autograd.grad((y2 * cot.to(DEV)).sum(), ins2)
+    close(yg, y2, tol=1e-6, what="y vs two-kernel route")
+    for a, b_, n in zip(got, got2, ["dx", "dw", "db"]):
+        close(a, b_, tol=2e-6, what=n + " vs two-kernel route")
