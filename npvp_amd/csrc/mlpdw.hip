@@ -4,6 +4,7 @@
 // the hidden tensor (the 9 neighbour taps hit L1/L2).  Weights are tap-major [9][Ch] so that a lane's
 // 4 channels are one float4.
 #include "common.h"
+#include <cstdlib>
 
 namespace npvp {
 
@@ -526,7 +527,7 @@ extern "C" int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const flo
   return NPVP_OK;
 }
 
-static int mid_chunks(int frames) { return frames < 128 ? frames : 128; }
+static int mid_chunks(int frames) { return frames < 128 ? frames : 128; }      // 256 / 512 chunks: no change of the c2 step
 
 // workspace of npvp_mlpdw_mid_bwd: weight-gradient partials [chunks][10][Ch]
 extern "C" long long npvp_mlpdw_mid_bwd_workspace_bytes(int frames, int Ch) {

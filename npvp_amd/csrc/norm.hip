@@ -9,6 +9,7 @@
 // and their backward passes.  Algorithmic bytes: one read + one write of the activation per
 // pass (8 B/element); statistics passes re-read a frame that is L2 resident.
 #include "common.h"
+#include <cstdlib>
 
 namespace npvp {
 
@@ -467,7 +468,7 @@ extern "C" int npvp_layernorm_fwd(const float* x, const float* w, const float* b
 
 static int ln_bwd_blocks(long long rows) {
   long long b = (rows + 3) / 4;
-  return (int)(b > 512 ? 512 : b);
+  return (int)(b > 512 ? 512 : b);      // 2048 / 4096 blocks: no change of the c2 step (331.0 / 331.7 / 331.3 ms)
 }
 
 extern "C" long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C) {
@@ -578,7 +579,13 @@ extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const flo
   return NPVP_OK;
 }
 
-static int fln_chunks(int frames) { return frames < 8 ? frames : 8; }
+// frame chunks (grid.y) of the one-pass backward: 32 x 128 = 4096 workgroups.  With 8 (1024 workgroups, each walking 224 frames
+// at c2) the kernel was as fast stand-alone (921 vs 923 us for statistics + apply) but lost CU slots to the co-resident
+// weight-gradient GEMM: c2 step 342.7 -> 338.3 ms (three A/B pairs on one box; 64 chunks: 338.1).  NPVP_FLN_CHUNKS overrides.
+static int fln_chunks(int frames) {
+  static const int want = getenv("NPVP_FLN_CHUNKS") ? atoi(getenv("NPVP_FLN_CHUNKS")) : 32;
+  return frames < want ? frames : want;
+}
 
 extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
   return ((long long)frames * 2 * FLN_PARTS + (long long)fln_chunks(frames) * 2 * per_frame) * 4;
