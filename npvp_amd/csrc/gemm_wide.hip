@@ -349,7 +349,7 @@ int wide_wgrad_splits(int M, int N, int K) {
   // measured 168 vs 166 TF at 20 480 rows, 144 vs 134 TF at 8 192 rows, 179 vs 189 TF at 114 688 rows.
   if ((K & 15) || M < 64 || N < 128 || K < 32768) return 0;
   const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
-  int s = (512 + tiles - 1) / tiles;        // (256 / 128 workgroups: c2 step 397 / 366 ms against 336 ms)
+  int s = (512 + tiles - 1) / tiles;        // (256 / 128 workgroups: c2 step 397 / 366 ms against 336 ms; 1024 / 2048: 335.4 / 338.2 against 332.0)
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
