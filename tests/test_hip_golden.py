@@ -302,6 +302,9 @@ def _evt_relu_margin(ref, past, fut, stochastic):
     return min(vals)
 
 
+_LARGER_ORACLE = {}
+
+
 @pytest.mark.parametrize("variant,N,To,Tp,seed0", [("S", 2, 5, 15, 11), ("D", 2, 2, 18, 91), ("D", 1, 2, 28, 91), ("S", 1, 2, 12, 11),
                                                    ("D", 2, 4, 16, 91), ("S", 1, 10, 10, 11)])
 def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
@@ -313,22 +316,9 @@ def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
     to, tp = torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp)
     kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=4, dropout=0.0, drop_path=0.0)
     args = (8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, stochastic, 8)
-    ref, hip = oracle.Predictor(*args, **kw), impl.Predictor(*args, **kw)
-    O.key_hashed_fill(ref, 7); O.key_hashed_fill(hip, 7)
-    hip = hip.to(DEV)
-    ref.train()
-    # first input seed (seed0 was found offline) whose EventEncoder ReLUs all sit > 1.2e-5 from the kink
-    for seed in range(seed0, seed0 + 2000, 10):
-        past, fut = O.synth_features((N, To, 512, 8, 8), seed), O.synth_features((N, Tp, 512, 8, 8), seed + 1)
-        if _evt_relu_margin(ref, past, fut, stochastic) > 1.2e-5:
-            break
-    for m in ref.modules():                 # the margin probe ran the BatchNorms in train mode: reset their statistics
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.reset_running_stats()
-    O.key_hashed_fill(ref, 7)
     eps, cot = O.seeded_randn((N, 512, 8, 8), 3), O.seeded_randn((N, Tp, 512, 8, 8), 4)
-    outs = []
-    for m, d in ((ref, "cpu"), (hip, DEV)):
+
+    def run(m, d, past, fut):
         if stochastic:
             e = eps.to(d)
             m.evt_prior.eps_fn = m.evt_posterior.eps_fn = (lambda shape, e=e: e)
@@ -337,7 +327,28 @@ def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
         o = m(p, fut.to(d)) if stochastic else m(p)
         y = o[0] if stochastic else o
         (y * y * cot.to(d)).sum().backward()       # smooth at the final ReLU's kink (see make_golden.py)
-        outs.append((y.detach().cpu(), p.grad.cpu(), m.transformer.norm.weight.grad.cpu()))
+        return y.detach().cpu(), p.grad.cpu(), m.transformer.norm.weight.grad.cpu()
+
+    key = (variant, N, To, Tp, seed0)
+    if key not in _LARGER_ORACLE:           # the CPU oracle side (20-30 s) is the same for both GEMM modes: computed once
+        ref = oracle.Predictor(*args, **kw)
+        O.key_hashed_fill(ref, 7)
+        ref.train()
+        # first input seed (seed0 was found offline) whose EventEncoder ReLUs all sit > 1.2e-5 from the kink
+        for seed in range(seed0, seed0 + 2000, 10):
+            past, fut = O.synth_features((N, To, 512, 8, 8), seed), O.synth_features((N, Tp, 512, 8, 8), seed + 1)
+            if _evt_relu_margin(ref, past, fut, stochastic) > 1.2e-5:
+                break
+        for m in ref.modules():             # the margin probe ran the BatchNorms in train mode: reset their statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        O.key_hashed_fill(ref, 7)
+        _LARGER_ORACLE[key] = (seed, past, fut, run(ref, "cpu", past, fut))
+    seed, past, fut, want = _LARGER_ORACLE[key]
+    hip = impl.Predictor(*args, **kw)
+    O.key_hashed_fill(hip, 7)
+    got = run(hip.to(DEV), DEV, past, fut)
+    outs = [want, got]
     for a, b, n in zip(outs[1], outs[0], ["y", "g_past", "g_tied_norm"]):
         e = GC.rel_err(a, b)
         GC.log_err(f"larger_{variant}[{MODE}]", n, e)
