@@ -266,8 +266,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
                     help="primary workload (default c2 = BASELINE configs[2], the largest single-GPU configuration)")
-    ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "bf16x6"), choices=["f32", "bf16x6"],
-                    help="GEMM arithmetic: bf16x6 = three-term bf16 split on the bf16 MFMA (fp32-grade, default); "
+    ap.add_argument("--gemm", default=os.environ.get("NPVP_GEMM", "f16x3"), choices=["f32", "bf16x6", "f16x3"],
+                    help="GEMM arithmetic: f16x3 = two-term fp16 split with amax-scaled operands, 3 MFMAs per product (fp32-grade, "
+                         "default; small shapes run as bf16x6); bf16x6 = three-term bf16 split, 6 MFMAs per product (fp32-grade); "
                          "f32 = exact fp32-input MFMA (parity triage)")
     ap.add_argument("--flavour", default="predictor", choices=["predictor", "full"],
                     help="predictor: feature grids resident in HBM (the BASELINE metric's step); full: SURVEY 8d's second "

@@ -42,9 +42,17 @@ int npvp_stream_destroy(void* stream);
  *   act: 0 none, 1 GELU(erf), 2 ReLU, 3 multiply by GELU'(aux_in), 4 multiply by [aux_in > 0]
  *   drop_mode 0: per element; 1: per row group key=(row/drop_g1)%drop_g2 (DropPath)
  * K % 32 == 0, M % 4 == 0, N % 4 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned.
- * precision 0: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32; parity triage).  precision 4 (default): every fp32 operand is
+ * precision 0: exact fp32-input MFMA (v_mfma_f32_32x32x2_f32; parity triage).  precision 4: every fp32 operand is
  * split into three bf16 terms and the six leading cross products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16
  * (relative product error ~2^-23: fp32-grade).  precision 5: two terms, three products (~2^-16; opt-in for weight gradients).
+ * precision 6 (the path's default): TWO fp16 terms per operand, three products on v_mfma_f32_32x32x16_f16 (~2^-22 per
+ * product: fp32-grade at half the matrix instructions of precision 4).  fp16 has no exponent range to spare, so each operand
+ * comes with an AMAX SLOT (32 floats in device memory whose maximum bounds |operand|; see npvp_amax) and is scaled by the power
+ * of two that puts the bound into [2^14, 2^15) - exact, undone in the epilogue.  It is taken by (a) a_kc = 1 launches with
+ * fp16 planes in `b_pre` (npvp_split_weight_f16) and both a_amax / b_amax, (b) weight gradients (a_kc = b_kc = 0, plain
+ * epilogue, K >= 4096) with both slots; every other launch with precision 6 runs as precision 4 without planes.
+ * c_amax (nullable, any precision, unsplit launches): the kernel adds the bound of the values it stores to C to that slot -
+ * the next GEMM's a_amax, at no extra pass.
  * Kernels: gemm_wide_kernel (128 x 256 tiles, 4 waves, A split on the fly, B = pre-split planes `b_pre` copied by LDS-DMA:
  * the large forward / dgrad shapes), gemm_wgrad_wide_kernel (weight gradients over >= 32 K token rows: row-major staging,
  * transposing LDS reads, split-K), gemm_split_db_kernel (128 x 128 tiles: everything else).
@@ -64,8 +72,8 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   float* C, long long ldc, const float* bias, int act, const float* aux_in, float* aux_out,
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
-                  const void* b_pre, int accumulate, float* rowstats, void* workspace, long long ws_bytes,
-                  npvp_stream_t stream);
+                  const void* b_pre, int accumulate, float* rowstats, const float* a_amax, const float* b_amax,
+                  float* c_amax, void* workspace, long long ws_bytes, npvp_stream_t stream);
 /* rowstats (nullable; default precision, a_kc = b_kc = 1, bias-only epilogue, M % 64 == 0, N % 128 == 0): receives
  * [M/64][N/64][2] partial (mean, M2) statistics of the output per frame of 64 rows and block of 64 columns;
  * npvp_frame_stats_finalize turns them into the frame LayerNorm's (mean, rstd): no statistics pass over C. */
@@ -79,6 +87,18 @@ int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void*
 /* The same for MANY weight views in one launch (after the optimiser step, ref/models/Predictor.py:136 opt.step()): desc is a
  * DEVICE array of `count` records of six 64-bit words {w, ld, N, K, F, D} (pointers as integers). */
 int npvp_split_weights_batched(const void* desc, int count, npvp_stream_t stream);
+/* ---- amax slots (precision 6).  A slot is 32 floats, zero before its tensor is produced; producers raise single words of
+ * it with integer atomic max (the bit pattern of a non-negative float orders like the float: order independent, so
+ * deterministic) and the tensor's bound is the maximum of the 32 words.  npvp_amax is the stand-alone producer for a
+ * [rows][cols] matrix (row stride ld) that no kernel of this library wrote: slot = max(slot, |x|). */
+int npvp_amax(const float* x, long long rows, long long cols, long long ld, float* slot, npvp_stream_t stream);
+/* w [N][K] -> the fp16 planes of precision 6: F[2 terms][K/8][N][8 over k], D[2 terms][N/8][K][8 over n] (2*N*K fp16 each,
+ * either may be null), scaled by the power of two of w's amax, which is (re)computed into amax_slot (zeroed here first).
+ * npvp_split_weights_f16: the same for `count` views in three stream operations; desc is a DEVICE array of records of eight
+ * 64-bit words {w, ld, N, K, F, D, amax_slot, 0}; amax_table / amax_bytes (nullable) name the contiguous memory that holds
+ * all the records' slots and is zeroed first (otherwise the caller zeroes the slots). */
+int npvp_split_weight_f16(const float* w, long long ld, int N, int K, void* F, void* D, float* amax_slot, npvp_stream_t stream);
+int npvp_split_weights_f16(const void* desc, int count, void* amax_table, long long amax_bytes, npvp_stream_t stream);
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.

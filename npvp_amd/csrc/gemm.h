@@ -29,7 +29,35 @@ struct GemmParams {
   long long b_pre_plane;   // bf16 elements per term plane (= N*K)
   int colgroups;           // XCD tiling: 1 = every XCD sweeps all tile columns; G>1 = XCD x owns column group x%G (see tile_of_block)
   int accum;               // 1: C += result and colsum += sums (gradient accumulation into a live .grad slice)
+  // fp16 two-term kernels (gemm_f16.hip): amax slots (32 floats whose maximum bounds |operand|) of A and B; any kernel:
+  // c_amax (nullable) receives the bound of the values this launch stores to C (the next GEMM's a_amax)
+  const float* a_amax; const float* b_amax; float* c_amax;
 };
+
+// ---- amax slots: 32 floats, the tensor's bound is their maximum.  Producers add to a slot with one integer atomic max per
+// wave on the bit pattern of a non-negative float (order independent: deterministic), spread over the 32 words so that the
+// ~10^4 waves of a large launch do not queue on one address; consumers read the 32 words with one load.
+__device__ __forceinline__ float amax_slot_read(const float* slot) {
+  const float v = wave_max(slot[threadIdx.x & 31]);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ void amax_slot_commit(float* slot, float m) {
+  if (!slot) return;
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned int*>(slot) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 31u), __float_as_uint(m));
+}
+// the power of two s with amax * s in [2^14, 2^15) (1 for a zero / tiny / non-finite bound)
+__host__ __device__ __forceinline__ float amax_scale(float amax) {
+  unsigned int u;
+  __builtin_memcpy(&u, &amax, 4);
+  const unsigned int E = (u >> 23) & 0xffu;
+  if (E < 16u || E == 255u) return 1.f;
+  u = (268u - E) << 23;
+  float s;
+  __builtin_memcpy(&s, &u, 4);
+  return s;
+}
 
 __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
   p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
@@ -43,7 +71,7 @@ __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx,
 // cost 40 % of a K = 512 GEMM).  CHECK = false: the tile lies inside the matrix, no per-element bounds tests.
 template <bool CHECK>
 __device__ __forceinline__ void epilogue_tile_impl(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h,
-                                                   int z, unsigned long long seed) {
+                                                   int z, unsigned long long seed, float& cmax) {
   const int col = col0 + r, rowb = row0 + 4 * h;
   if (CHECK && col >= p.N) return;
 #define NPVP_RD(g) (((g) & 3) + 8 * ((g) >> 2))
@@ -100,12 +128,16 @@ __device__ __forceinline__ void epilogue_tile_impl(const GemmParams& p, const f3
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cp[NPVP_RD(g) * ld] = v[g];
+  if (p.c_amax) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cmax = fmaxf(cmax, fabsf(v[g]));
+  }
 #undef NPVP_INB
 #undef NPVP_RD
 }
 
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h, int z,
-                                              unsigned long long seed) {
+                                              unsigned long long seed, float& cmax) {
   // fast path: a tile inside the matrix with a bias-only epilogue (most forward and all plain dgrad GEMMs)
   const bool simple = p.splits == 1 && !p.aux_out && p.act == 0 && !p.drop.thresh && !p.residual && !p.accum;
   if (simple && row0 + 32 <= p.M && col0 + 32 <= p.N) {
@@ -113,11 +145,16 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
     const float bv = p.bias ? p.bias[col] : 0.f;
     float* cp = p.C + (long long)(row0 + 4 * h) * p.ldc + col;
     const long long ld = p.ldc;
+    if (p.c_amax) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { const float v = acc[g] * p.alpha + bv; cp[((g & 3) + 8 * (g >> 2)) * ld] = v; cmax = fmaxf(cmax, fabsf(v)); }
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < 16; ++g) cp[((g & 3) + 8 * (g >> 2)) * ld] = acc[g] * p.alpha + bv;
     return;
   }
-  epilogue_tile_impl<true>(p, acc, row0, col0, r, h, z, seed);
+  epilogue_tile_impl<true>(p, acc, row0, col0, r, h, z, seed, cmax);
 }
 
 // Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
@@ -127,7 +164,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
 // over C.  Sums are taken about the lane's first value and combined across the wave in Chan's form; fixed order,
 // deterministic.  M % 64 == 0 and N % 64 == 0 (checked by the launcher): the block is either inside the matrix or outside.
 __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, const f32x16& a00, const f32x16& a01,
-                                                        const f32x16& a10, const f32x16& a11, int row0, int col0, int r, int h) {
+                                                        const f32x16& a10, const f32x16& a11, int row0, int col0, int r, int h,
+                                                        float& cmax) {
   if (row0 >= p.M || col0 >= p.N) return;
   float shift = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -142,6 +180,7 @@ __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, con
         const int row = row0 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         const float v = acc[g] * p.alpha + bv;
         p.C[(long long)row * p.ldc + col] = v;
+        cmax = fmaxf(cmax, fabsf(v));
         if (tm == 0 && tn == 0 && g == 0) shift = v;
         const float d = v - shift;
         s1 += d; s2 += d * d;
@@ -201,5 +240,10 @@ int gemm_wide_variant(int M, int N, int K);      // 0 not taken, 1 = 128 x 256 t
 // p.K / p.C / p.colsum for the split exactly as for the 128 x 128 kernel and runs the split-K reductions afterwards.
 int wide_wgrad_splits(int M, int N, int K);
 bool launch_gemm_wgrad_wide(GemmParams& p, int splits, hipStream_t stream);
+// gemm_f16.hip: the two-term fp16 forms of the three (precision 6)
+int gemm_f16_variant(int M, int N, int K);       // 0 not taken, 1 = 128 x 256 tiles, 2 = 128 x 128 tiles
+bool launch_gemm_f16(GemmParams& p, hipStream_t stream);
+int f16_wgrad_splits(int M, int N, int K);
+bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream);
 
 }  // namespace npvp

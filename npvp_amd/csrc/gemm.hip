@@ -90,10 +90,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
                                               int r, int h, int z) {
   const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
   const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
-  epilogue_tile(p, acc00, row0, col0, r, h, z, seed);
-  epilogue_tile(p, acc01, row0, col0 + 32, r, h, z, seed);
-  epilogue_tile(p, acc10, row0 + 32, col0, r, h, z, seed);
-  epilogue_tile(p, acc11, row0 + 32, col0 + 32, r, h, z, seed);
+  float cmax = 0.f;
+  epilogue_tile(p, acc00, row0, col0, r, h, z, seed, cmax);
+  epilogue_tile(p, acc01, row0, col0 + 32, r, h, z, seed, cmax);
+  epilogue_tile(p, acc10, row0 + 32, col0, r, h, z, seed, cmax);
+  epilogue_tile(p, acc11, row0 + 32, col0 + 32, r, h, z, seed, cmax);
+  if (p.splits == 1) amax_slot_commit(p.c_amax, cmax);
 }
 
 // 128 x 128 tiles: unsplit launches use the XCD-aware remap of gemm.h; split-K launches (weight gradients) keep all tiles
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
-  if constexpr (ROWSTATS) epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h);
+  if constexpr (ROWSTATS) { float cmax = 0.f; epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h, cmax); amax_slot_commit(p.c_amax, cmax); }
   else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 
@@ -492,8 +494,8 @@ using namespace npvp;
 // split-K partial slabs [splits][M][N] followed by the column-sum partials [splits][M]: the larger of what the 128 x 128
 // kernel and the wide weight-gradient kernel would use for this shape
 extern "C" long long npvp_gemm_workspace_bytes(int M, int N, int K) {
-  const int s = pick_splits(M, N, K), sw = wide_wgrad_splits(M, N, K);
-  const int m = s > sw ? s : sw;
+  const int s = pick_splits(M, N, K), sw = wide_wgrad_splits(M, N, K), sh = f16_wgrad_splits(M, N, K);
+  const int m = (s > sw ? s : sw) > sh ? (s > sw ? s : sw) : sh;
   return m > 1 ? ((long long)m * M * N + (long long)m * M) * 4 : 0;
 }
 
@@ -524,6 +526,11 @@ extern "C" int npvp_split_weights_batched(const void* desc, int count, hipStream
 // will be passed.
 extern "C" int npvp_gemm_kernel_id(int a_kc, int b_kc, int M, int N, int K, int precision, int has_planes) {
   if (precision == 0) return 0;
+  if (precision == 6) {
+    if (a_kc && has_planes && gemm_f16_variant(M, N, K)) return gemm_f16_variant(M, N, K) == 1 ? 5 : 7;
+    if (!a_kc && !b_kc && f16_wgrad_splits(M, N, K) > 0) return 6;
+    return 1;
+  }
   if (precision == 4 && a_kc && has_planes && pick_splits(M, N, K) == 1 && gemm_wide_takes(M, N, K))
     return gemm_wide_variant(M, N, K) == 1 ? 2 : 4;
   if (precision == 4 && !a_kc && !b_kc && wide_wgrad_splits(M, N, K) > 0) return 3;
@@ -536,11 +543,17 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
                              int precision, float* colsum_a, const void* b_pre, int accumulate, float* rowstats,
+                             const float* a_amax, const float* b_amax, float* c_amax,
                              void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  NPVP_CHECK_ARG(precision == 0 || precision == 4 || precision == 5,
+  NPVP_CHECK_ARG(precision == 0 || precision == 4 || precision == 5 || precision == 6,
                  "gemm: precision must be 0 (exact fp32-input MFMA), 4 (three-term bf16 split, 6 MFMAs per product: "
-                 "fp32-grade, the default) or 5 (two-term bf16 split, 3 MFMAs per product, ~2^-16)");
+                 "fp32-grade), 5 (two-term bf16 split, 3 MFMAs per product, ~2^-16) or 6 (two-term fp16 split with amax-scaled "
+                 "operands, 3 MFMAs per product: fp32-grade; shapes it does not take run as 4)");
+  // precision 6 = fp16 two-term kernels where they apply (a row-major A with fp16 planes of B + both amax slots; weight
+  // gradients with both amax slots), the three-term bf16 kernels WITHOUT planes everywhere else
+  const bool want_h = precision == 6;
+  if (want_h) precision = 4;
   NPVP_CHECK_ARG(K % BK == 0, "gemm: K must be a multiple of 32");
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
@@ -564,14 +577,54 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.splits = splits;
   p.colsum = colsum_a;
   p.rowstats = rowstats;
+  p.a_amax = a_amax; p.b_amax = b_amax; p.c_amax = c_amax;
   NPVP_CHECK_ARG(!rowstats || (precision == 4 && a_kc && b_kc && M % 64 == 0 && N % 128 == 0 && act == 0 && !aux_out && !residual &&
                                drop_p == 0.f && !accumulate),
                  "gemm: rowstats needs the default (bf16x6) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");
   p.accum = accumulate ? 1 : 0;
   // pre-split B planes are only consumed by the bf16x6 kernels with a row-major A and an unsplit reduction
+  const void* b_pre_arg = b_pre;
   p.b_pre = (precision == 4 && a_kc && splits == 1 && K % 16 == 0 && N % 8 == 0) ? b_pre : nullptr;
   p.b_pre_plane = (long long)N * K;
   b_pre = p.b_pre;
+
+  if (want_h) {
+    if (b_pre_arg && a_kc && K % 16 == 0 && N % 8 == 0 && a_amax && b_amax) {
+      p.b_pre = b_pre_arg; p.splits = 1;
+      if (launch_gemm_f16(p, stream)) {
+        NPVP_CHECK_LAUNCH();
+        return NPVP_OK;
+      }
+      p.splits = splits;
+    }
+    p.b_pre = b_pre = nullptr;               // fp16 planes are not what the bf16 kernels read
+    if (!a_kc && !b_kc && a_amax && b_amax && !bias && act == 0 && !aux_out && !residual && drop_p == 0.f && !rowstats &&
+        N % 4 == 0 && M % 4 == 0) {
+      const int sh = f16_wgrad_splits(M, N, K);
+      if (sh == 1 || (sh > 1 && workspace && ws_bytes >= ((long long)sh * M * N + (long long)sh * M) * 4)) {
+        splits = sh; p.splits = sh;
+        p.colgroups = 1;
+        if (sh > 1) {
+          p.K = K / sh; p.C = (float*)workspace; p.ldc = N;
+          if (colsum_a) p.colsum = (float*)workspace + (long long)sh * M * N;
+        }
+        launch_gemm_wgrad_f16(p, sh, stream);
+        NPVP_CHECK_LAUNCH();
+        if (sh > 1) {
+          const long long total4 = (long long)M * N / 4;
+          int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
+                             sh, alpha, p.accum);
+          NPVP_CHECK_LAUNCH();
+          if (colsum_a && launch_sum_rows(p.colsum, colsum_a, sh, M, M, stream, p.accum)) {
+            npvp_set_error("gemm: column-sum reduce launch failed");
+            return NPVP_ERR_LAUNCH;
+          }
+        }
+        return NPVP_OK;
+      }
+    }
+  }
 
   // large forward / dgrad shapes: 256 x 256 tiles (gemm_wide.hip); it declines what it is not built for
   if (b_pre && launch_gemm_wide(p, stream)) {

@@ -1,0 +1,461 @@
+// Two-term fp16 split GEMMs ("f16x3"): the fp32-grade arithmetic of the large forward / dgrad / weight-gradient GEMMs at
+// THREE matrix instructions per product instead of the six of the three-term bf16 split (gemm_wide.hip).
+//
+//     x * s = hi + lo + eps,   hi = rne_f16(x s),  lo = rne_f16(x s - hi),   |eps| <= 2^-23 |x s|  (while lo is a normal)
+//     a b  ~=  (hi_a hi_b + hi_a lo_b + lo_a hi_b) / (s_a s_b)              on v_mfma_f32_32x32x16_f16, fp32 accumulate
+//
+// fp16 carries 11 significand bits, so two terms reach 2^-22 where bf16 needs three; the dropped lo_a lo_b term is
+// <= 2^-22 relative.  Representation error of a whole product sum against fp64: 7.6e-8 rel-L2 (tools/f16_emulate.py; an fp32
+// GEMM's own accumulation error is 3e-7).  What fp16 does NOT have is fp32's exponent range, so every operand tensor comes
+// with an AMAX SLOT - 32 floats whose maximum bounds |x| over the tensor - and is multiplied by the power of two s that
+// puts that bound into [2^14, 2^15): nothing overflows (max 65504), and an element 2^-18 below the bound still has a
+// NORMAL low term.  Smaller elements lose low-term bits gradually (fp16 subnormals: gfx950 converts to them and its MFMA
+// multiplies them exactly - tools/f16_probe.hip), i.e. they carry an ABSOLUTE error of 2^-40 of the tensor's bound, which
+// no dot product that contains the larger elements can see.  The slots are filled by the producers of the tensors (an
+// epilogue max + one atomic per wave, order independent and therefore deterministic) or by npvp_amax; weights are split
+// once per optimiser step into scaled planes (F / D, laid out like the LDS image, copied HBM -> LDS by LDS-DMA).
+//
+// Kernel organisation = gemm_wide.hip's (128 x 256 or 128 x 128 tile, 4 waves, K-step 16, two LDS stages, two workgroups
+// per CU) with two planes per operand: 24.8 KB per stage instead of 36.4, 24 MFMAs and ~20 VALU of splitting per wave and
+// K-step instead of 48 and ~60.
+#include "gemm.h"
+
+namespace npvp {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// x (already scaled) -> (hi, lo)
+__device__ __forceinline__ void split_f16(const f32x4 v, f16x4& hi, f16x4& lo) {
+  hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
+  lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[1] - (float)hi[1]);
+  lo[2] = (_Float16)(v[2] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
+}
+
+template <int TM, int TN, int WM, int WN, bool ROWSTATS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(GemmParams p) {
+  constexpr int NW = WM * WN, THREADS = 64 * NW;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int APASS = BM / (THREADS / 4);
+  static_assert(APASS == 2 && BN % 64 == 0, "A staging is written for two row passes");
+  constexpr int KGS_A = BM * 16 + 64, A_PLANE = 2 * KGS_A, A_BYTES = 2 * A_PLANE;
+  constexpr int KGS_B = BN * 16, B_PLANE = 2 * KGS_B, B_BYTES = 2 * B_PLANE;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int CPS = BN / 64;                       // 1 KB glds chunks per (term, k-group) slab
+  constexpr int NCHUNK = 4 * CPS, CPW = (NCHUNK + NW - 1) / NW;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+  int tile_m, tile_n;
+  tile_of_block_unsplit(p, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+  const int nk = p.K >> 4;
+  const float sa = amax_scale(amax_slot_read(p.a_amax));
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  const int quad = t & 3, rl = t >> 2;
+  const float* a_src0 = p.A + (long long)min(m0 + rl, p.M - 1) * p.lda + 4 * quad;
+  const float* a_src1 = p.A + (long long)min(m0 + rl + BM / 2, p.M - 1) * p.lda + 4 * quad;
+  const int a_dst = (quad >> 1) * KGS_A + (quad & 1) * 8 + rl * 16;
+  const uint4* b_src[CPW];
+  int b_dst[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int c = wave + NW * i;
+    const int slab = c / CPS, part = c - slab * CPS, s = slab >> 1, kg = slab & 1;
+    const int col = min(n0 + part * 64 + lane, p.N - 1);
+    b_src[i] = reinterpret_cast<const uint4*>(p.b_pre) + (long long)s * (p.b_pre_plane >> 3) + (long long)kg * p.N + col;
+    b_dst[i] = A_BYTES + s * B_PLANE + kg * KGS_B + part * 1024;
+  }
+  const long long b_step = 2ll * p.N;
+
+  const int fa_off = h * KGS_A + (wm * TM * 32 + r) * 16;
+  const int fb_off = A_BYTES + h * KGS_B + (wn * TN * 32 + r) * 16;
+
+  f32x4 ra0, ra1;
+#define NPVP_H_ALOAD(KT)                                                                 \
+  { const int k_ = min((KT), nk - 1) << 4; ra0 = *reinterpret_cast<const f32x4*>(a_src0 + k_); ra1 = *reinterpret_cast<const f32x4*>(a_src1 + k_); }
+#define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
+  { f16x4 hi_, lo_; split_f16((V) * sa, hi_, lo_);                                       \
+    *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
+    *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
+#define NPVP_H_BLOAD(ST, KT)                                                             \
+  { const long long ko_ = (long long)min((KT), nk - 1) * b_step;                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < CPW; ++i_)                                   \
+      if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK)                                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i_] + ko_), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
+
+  NPVP_H_BLOAD(lds, 0)
+  NPVP_H_ALOAD(0)
+  NPVP_H_ASTORE(lds, ra0, 0)
+  NPVP_H_ASTORE(lds, ra1, (BM / 2) * 16)
+  NPVP_H_ALOAD(1)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+#define NPVP_H_STEP(KT, CUR, NXT)                                                                          \
+  {                                                                                                        \
+    const char* st_ = lds + (CUR) * STAGE;                                                                 \
+    char* nx_ = lds + (NXT) * STAGE;                                                                       \
+    asm volatile("" : "+v"(ra0), "+v"(ra1));                                                               \
+    NPVP_H_BLOAD(nx_, (KT) + 1)                                                                            \
+    f16x8 fb_[2][TN];                                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                    \
+        fb_[s_][j_] = *reinterpret_cast<const f16x8*>(st_ + fb_off + s_ * B_PLANE + j_ * 512);             \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                    \
+      f16x8 fa_[2];                                                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
+        fa_[s_] = *reinterpret_cast<const f16x8*>(st_ + fa_off + s_ * A_PLANE + i_ * 512);                 \
+      if (i_ == 0) NPVP_H_ASTORE(nx_, ra0, 0)                                                              \
+      if (i_ == 1) { NPVP_H_ASTORE(nx_, ra1, (BM / 2) * 16) NPVP_H_ALOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); } \
+      /* smallest terms first */                                                                           \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
+    }                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+  }
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    NPVP_H_STEP(kt, 0, 1)
+    NPVP_H_STEP(kt + 1, 1, 0)
+  }
+  if (kt < nk) NPVP_H_STEP(kt, 0, 1)
+#undef NPVP_H_STEP
+#undef NPVP_H_BLOAD
+#undef NPVP_H_ASTORE
+#undef NPVP_H_ALOAD
+
+  // back to the operands' own scale (exact: powers of two; two factors so that neither product of scales can underflow)
+  const float ia = 1.f / sa, ib = 1.f / amax_scale(amax_slot_read(p.b_amax));
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = acc[i][j][g] * ia * ib;
+
+  const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
+  float cmax = 0.f;
+  if constexpr (ROWSTATS) {
+    static_assert(!ROWSTATS || (TN % 2 == 0 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
+#pragma unroll
+    for (int i = 0; i < TM; i += 2)
+#pragma unroll
+      for (int j = 0; j < TN; j += 2)
+        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, r, h, cmax);
+  } else {
+    const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, 0, seed, cmax);
+  }
+  amax_slot_commit(p.c_amax, cmax);
+}
+
+// =====================================================================================================
+// Weight gradients, dW[M,N] = A^T B with A = dy [K][M], B = x [K][N]: gemm_wgrad_wide_kernel's organisation (row-major
+// staging, transposing LDS reads, split-K with one K-chunk per XCD, bias gradient from the staging registers) on two fp16
+// planes per operand; both operands are split on the fly, each with the scale of its own amax slot.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16x8 lds_read_tr_pair_h(const char* a, int second_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + second_off));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, v);
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_kernel(GemmParams p) {
+  constexpr int NW = WM * WN, THREADS = 64 * NW;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(THREADS == 256 && BM == 128 && BN == 256, "staging maps are written for 256 threads on a 128 x 256 tile");
+  constexpr int ROWA = BM * 2, ROWB = BN * 2;
+  constexpr int A_PLANE = 16 * ROWA, B_PLANE = 16 * ROWB, A_BYTES = 2 * A_PLANE, B_BYTES = 2 * B_PLANE;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+  int z, tl;
+  {
+    const int tiles = gridDim.x;
+    if (p.splits > 1 && (p.splits & 7) == 0) {
+      const int lin = blockIdx.x + tiles * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+      const int g = slot / tiles;
+      tl = slot - g * tiles; z = g * 8 + xcd;
+    } else { z = blockIdx.y; tl = blockIdx.x; }
+  }
+  const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* A = p.A + (long long)z * p.K * p.lda;
+  const float* B = p.B + (long long)z * p.K * p.ldb;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+  const int nk = p.K >> 4;
+  const float sa = amax_scale(amax_slot_read(p.a_amax)), sb = amax_scale(amax_slot_read(p.b_amax));
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  const int ka = t >> 5, cqa = t & 31, kb = t >> 6, cqb = t & 63;
+  const float* a_src = A + (long long)ka * p.lda + min(m0 + 4 * cqa, p.M - 4);
+  const float* b_src = B + (long long)kb * p.ldb + min(n0 + 4 * cqb, p.N - 4);
+  const long long a_row8 = 8 * p.lda, b_row4 = 4 * p.ldb, a_step = 16 * p.lda, b_step = 16 * p.ldb;
+  const int a_dst = ka * ROWA + ((8 * cqa) ^ ((ka & 3) << 6));
+  const int b_dst = A_BYTES + kb * ROWB + ((8 * cqb) ^ ((kb & 3) << 6));
+  const int q = (lane >> 2) & 3, pp = lane & 3, cg = 16 * ((lane >> 4) & 1) + 4 * pp;
+  int fa[TM], fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i] = (8 * h + q) * ROWA + (((wm * TM * 32 + i * 32 + cg) * 2) ^ (q << 6));
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j] = A_BYTES + (8 * h + q) * ROWB + (((wn * TN * 32 + j * 32 + cg) * 2) ^ (q << 6));
+
+  const bool want_cs = p.colsum && tile_n == 0;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[2], rb[4];
+#define NPVP_G_LOAD(KT)                                                                                     \
+  { const int kt_ = min((KT), nk - 1);                                                                      \
+    const float* pa_ = a_src + (long long)kt_ * a_step; const float* pb_ = b_src + (long long)kt_ * b_step; \
+    ra[0] = *reinterpret_cast<const f32x4*>(pa_); ra[1] = *reinterpret_cast<const f32x4*>(pa_ + a_row8);    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) rb[i_] = *reinterpret_cast<const f32x4*>(pb_ + i_ * b_row4); }
+#define NPVP_G_STORE(DST, V, SC, PLANE)                                                                     \
+  { f16x4 hi_, lo_; split_f16((V) * (SC), hi_, lo_);                                                        \
+    *reinterpret_cast<f16x4*>(DST) = hi_; *reinterpret_cast<f16x4*>((DST) + (PLANE)) = lo_; }
+#define NPVP_G_STORE_A(ST) { NPVP_G_STORE((ST) + a_dst, ra[0], sa, A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], sa, A_PLANE) }
+#define NPVP_G_STORE_B(ST, I) NPVP_G_STORE((ST) + b_dst + (I) * 4 * ROWB, rb[I], sb, B_PLANE)
+
+  NPVP_G_LOAD(0)
+  if (want_cs) cs += ra[0] + ra[1];
+  NPVP_G_STORE_A(lds)
+  NPVP_G_STORE_B(lds, 0) NPVP_G_STORE_B(lds, 1) NPVP_G_STORE_B(lds, 2) NPVP_G_STORE_B(lds, 3)
+  NPVP_G_LOAD(1)
+  __syncthreads();
+
+#define NPVP_G_STEP(KT, CUR, NXT)                                                                            \
+  {                                                                                                          \
+    const char* st_ = lds + (CUR) * STAGE;                                                                   \
+    char* nx_ = lds + (NXT) * STAGE;                                                                         \
+    if (want_cs && (KT) + 1 < nk) cs += ra[0] + ra[1];                                                       \
+    f16x8 fa_[TM][2];                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) fa_[i_][s_] = lds_read_tr_pair_h(st_ + fa[i_] + s_ * A_PLANE, 4 * ROWA); \
+    _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) {                                                      \
+      f16x8 fb_[2];                                                                                          \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) fb_[s_] = lds_read_tr_pair_h(st_ + fb[j_] + s_ * B_PLANE, 4 * ROWB); \
+      if (j_ == 0) { NPVP_G_STORE_A(nx_) NPVP_G_STORE_B(nx_, 0) }                                            \
+      if (j_ == 1) { NPVP_G_STORE_B(nx_, 1) NPVP_G_STORE_B(nx_, 2) }                                         \
+      if (j_ == 2) { NPVP_G_STORE_B(nx_, 3) NPVP_G_LOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); }       \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][1], fb_[0], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[1], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[0], acc[i_][j_], 0, 0, 0); \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+  }
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    NPVP_G_STEP(kt, 0, 1)
+    NPVP_G_STEP(kt + 1, 1, 0)
+  }
+  if (kt < nk) NPVP_G_STEP(kt, 0, 1)
+#undef NPVP_G_STEP
+#undef NPVP_G_STORE_B
+#undef NPVP_G_STORE_A
+#undef NPVP_G_STORE
+#undef NPVP_G_LOAD
+
+  if (want_cs) {
+    float* red = reinterpret_cast<float*>(lds);
+    *reinterpret_cast<f32x4*>(red + (t >> 5) * 128 + cqa * 4) = cs;
+    __syncthreads();
+    if (t < 128 && m0 + t < p.M) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += red[i * 128 + t];
+      store_colsum(p, (long long)z * p.M + m0 + t, sum);
+    }
+  }
+  const float ia = 1.f / sa, ib = 1.f / sb;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = acc[i][j][g] * ia * ib;
+  const unsigned long long seed = 0ull;
+  const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
+  float cmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, z, seed, cmax);
+}
+
+// split count of the fp16 weight-gradient kernel: ~512 workgroups, >= 16 K-steps per split; 0 = shape not taken
+int f16_wgrad_splits(int M, int N, int K) {
+  if ((K & 15) || M < 64 || N < 128 || K < 4096) return 0;
+  const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
+  int s = (512 + tiles - 1) / tiles;
+  const int maxs = K / 256;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  if (s >= 8) s &= ~7;
+  while (s > 1 && (K % (s * 16)) != 0) --s;
+  return s < 1 ? 1 : s;
+}
+
+bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream) {
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 255) / 256;
+  dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+  hipLaunchKernelGGL((gemm_wgrad_f16_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
+  return true;
+}
+
+// forward / dgrad with scaled fp16 planes: 1 = 128 x 256 tiles, 2 = 128 x 128 tiles (outputs that 128 x 256 tiles do not
+// fill the chip with), 0 = shape not taken (the caller falls back to the three-term bf16 kernels WITHOUT planes)
+int gemm_f16_variant(int M, int N, int K) {
+  if ((K & 15) || (N & 7) || M < 128) return 0;
+  const int tw = ((M + 127) / 128) * ((N + 255) / 256);
+  if (N % 128 != 0 || tw >= 512) return 1;
+  return 2;
+}
+
+bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
+  if (!p.b_pre || !p.a_amax || !p.b_amax || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return false;
+  const int v = gemm_f16_variant(p.M, p.N, p.K);
+  if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return false;
+  const int bn = v == 1 ? 256 : 128;
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + bn - 1) / bn;
+  p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
+  dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (v == 1) {
+    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+  } else {
+    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
+  }
+  return true;
+}
+
+// ---- amax of a tensor: slot[32] = max(slot, |x|) --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n4, long long ldq, long long cols4, float* slot) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / cols4, c = i - row * cols4;
+    const float4 v = ld4(x + 4 * (row * ldq + c));
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax_slot_commit(slot, m);
+}
+
+// ---- weights -> scaled fp16 planes: F[term][K/8][N][8 over k], D[term][N/8][K][8 over n] -----------------------------
+struct SplitDescH { const float* w; long long ld; long long N; long long K; _Float16* F; _Float16* D; float* amax; long long pad; };
+
+__global__ __launch_bounds__(256) void weights_amax_kernel(const SplitDescH* __restrict__ desc, SplitDescH one) {
+  const SplitDescH d = desc ? desc[blockIdx.y] : one;
+  const int K4 = (int)d.K / 4;
+  const long long total = d.N * K4;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / K4; const int k4 = (int)(i - n * K4);
+    const float4 v = ld4(d.w + n * d.ld + 4 * k4);
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax_slot_commit(d.amax, m);
+}
+
+__global__ __launch_bounds__(256) void split_weights_f16_kernel(const SplitDescH* __restrict__ desc, SplitDescH one) {
+  const SplitDescH d = desc ? desc[blockIdx.y] : one;
+  const int N = (int)d.N, K = (int)d.K;
+  const long long slots = (long long)N * K / 8, plane = (long long)N * K;
+  const float s = amax_scale(amax_slot_read(d.amax));
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * slots; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    _Float16* out;
+    if (i < slots) {
+      if (!d.F) continue;
+      const int n = (int)(i % N), kb = (int)(i / N);
+      const float4 a = ld4(d.w + (long long)n * d.ld + kb * 8), b = ld4(d.w + (long long)n * d.ld + kb * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      out = d.F + i * 8;
+    } else {
+      if (!d.D) continue;
+      const long long j = i - slots;
+      const int k = (int)(j % K), nb = (int)(j / K);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = d.w[(long long)(nb * 8 + e) * d.ld + k];
+      out = d.D + j * 8;
+    }
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float x = v[e] * s; hi[e] = (_Float16)x; lo[e] = (_Float16)(x - (float)hi[e]); }
+    *reinterpret_cast<f16x8*>(out) = hi;
+    *reinterpret_cast<f16x8*>(out + plane) = lo;
+  }
+}
+
+}  // namespace npvp
+
+using namespace npvp;
+
+// See include/npvp_hip.h.
+extern "C" int npvp_amax(const float* x, long long rows, long long cols, long long ld, float* slot, hipStream_t stream) {
+  NPVP_CHECK_ARG(x && slot && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols, "amax: cols and ld must be multiples of 4");
+  NPVP_CHECK_ARG(((uintptr_t)x % 16) == 0, "amax: x must be 16-byte aligned");
+  const long long n4 = rows * (cols / 4);
+  long long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, ld / 4, cols / 4, slot);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_split_weights_f16(const void* desc, int count, void* amax_table, long long amax_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(desc && count > 0, "split_weights_f16: empty table");
+  if (amax_table && amax_bytes > 0) {
+    if (hipMemsetAsync(amax_table, 0, (size_t)amax_bytes, stream) != hipSuccess) { npvp_set_error("split_weights_f16: memset failed"); return NPVP_ERR_LAUNCH; }
+  }
+  SplitDescH none = {};
+  hipLaunchKernelGGL(weights_amax_kernel, dim3(16, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(split_weights_f16_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_split_weight_f16(const float* w, long long ld, int N, int K, void* F, void* D, float* amax_slot, hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ld % 4 == 0, "split_weight_f16: N, K must be multiples of 8");
+  NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0 && amax_slot, "split_weight_f16: w must be 16-byte aligned, amax_slot non-null");
+  if (hipMemsetAsync(amax_slot, 0, 128, stream) != hipSuccess) { npvp_set_error("split_weight_f16: memset failed"); return NPVP_ERR_LAUNCH; }
+  SplitDescH one = {w, ld, N, K, (_Float16*)F, (_Float16*)D, amax_slot, 0};
+  hipLaunchKernelGGL(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
+  NPVP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(split_weights_f16_kernel, dim3(128, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}

@@ -17,6 +17,64 @@ def _ptr(t):
     return _p(0) if t is None else _p(t.data_ptr())
 
 
+class AmaxSlot:
+    """One amax slot (32 floats of device memory, see include/npvp_hip.h): the bound of |x| over a tensor that feeds a
+    precision-6 GEMM.  Slots are cut from zero-filled chunks (one torch.zeros per 4096 slots); a slot keeps its chunk alive,
+    so a saved-for-backward slot is valid until the node that holds it is freed."""
+    __slots__ = ("ptr", "chunk")
+    CHUNK = 4096
+    _cur = None
+    _next = 0
+
+    def __init__(self, ptr, chunk):
+        self.ptr, self.chunk = ptr, chunk
+
+    def data_ptr(self):
+        return self.ptr
+
+    def read(self):
+        """host value (synchronises; tests and diagnostics only)"""
+        i = (self.ptr - self.chunk.data_ptr()) // 128
+        return float(self.chunk[i].max())
+
+    @classmethod
+    def new(cls, dev):
+        ch = cls._cur
+        if ch is None or cls._next >= cls.CHUNK or ch.device != dev:
+            ch = cls._cur = torch.zeros(cls.CHUNK, 32, dtype=torch.float32, device=dev)
+            cls._next = 0
+            if WgradStream.enabled:
+                ch.record_stream(WgradStream.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
+        s = cls(ch.data_ptr() + 128 * cls._next, ch)
+        cls._next += 1
+        return s
+
+
+def amax_of(t, slot=None):
+    """the amax slot of a 2-D fp32 matrix: the one its producer attached (`t._npvp_amax`), else a fresh slot filled by
+    the stand-alone reduction kernel (one read of t)"""
+    if slot is not None:
+        return slot
+    tag = getattr(t, "_npvp_amax", None)
+    if tag is not None and tag[1] == t._version:        # (an in-place update after the slot was filled voids it)
+        return tag[0]
+    s = AmaxSlot.new(t.device)
+    t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1:
+        t2 = t2.contiguous()
+    check(lib().npvp_amax(_ptr(t2), t2.shape[0], t2.shape[1], t2.stride(0), _ptr(s), _stream()), "npvp_amax")
+    t._npvp_amax = (s, t._version)
+    return s
+
+
+def tag_amax(t, slot):
+    """attach a producer-filled slot to the tensor object that carries the values on (also across autograd nodes: the
+    engine hands the next node the same Python object unless it had to sum two gradients)"""
+    if slot is not None:
+        t._npvp_amax = (slot, t._version)
+    return t
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -132,8 +190,11 @@ class DropRecorder:
 #          shapes, weight gradients)
 #   f32    exact fp32-input MFMA (v_mfma_f32_32x32x2_f32), 1/16 of the bf16 rate: parity triage
 #   bf16x3 two-term split, 3 MFMAs per product, ~2^-16: only ever used for weight gradients, opt-in (NPVP_WGRAD=bf16x3)
-GEMM_MODES = {"f32": 0, "bf16x6": 4, "bf16x6db": 4, "bf16x3": 5, "bf16x3db": 5}
-GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "bf16x6")]
+#   f16x3  two fp16 terms per operand, 3 MFMAs per product, ~2^-22: fp32-grade at half the matrix work of bf16x6.  Operands
+#          are scaled by the power of two of their amax slot (csrc/gemm_f16.hip); taken by the large forward / dgrad shapes
+#          (weights as scaled fp16 planes) and the weight gradients, everything else runs as bf16x6
+GEMM_MODES = {"f32": 0, "bf16x6": 4, "bf16x6db": 4, "bf16x3": 5, "bf16x3db": 5, "f16x3": 6}
+GEMM_PRECISION = GEMM_MODES[os.environ.get("NPVP_GEMM", "f16x3")]
 
 
 # Arithmetic of the WEIGHT-GRADIENT GEMMs.  Default: the same six-term split as forward / dgrad (fp32-grade, what the
@@ -150,22 +211,33 @@ def set_gemm_precision(name):
 
 
 class WeightPlanes:
-    """The pre-split bf16 planes of every weight that is a GEMM B operand (npvp_split_weight): F planes for the forward
-    GEMM, D planes for dgrad.  A weight changes once per optimiser step but is staged by every tile of two GEMMs, so it is
-    split ONCE per step, into the exact layout of the GEMM's LDS image - the wide GEMM kernel copies it HBM -> LDS by LDS-DMA
-    and spends no VALU or VGPR on it.
-      * A view registers itself on first use (split there and then, one small launch).
-      * `refresh_all()` (FlatAdamW.step, right after the AdamW kernel) re-splits EVERY registered view with ONE launch
-        (npvp_split_weights_batched over a device table) - not ~350 small launches per step, and no per-call bookkeeping.
+    """The pre-split planes of every weight that is a GEMM B operand: F planes for the forward GEMM (B = w as [N][K]), D planes
+    for dgrad (B = w as [K][N]).  A weight changes once per optimiser step but is staged by every tile of two GEMMs, so it
+    is split ONCE per step, into the exact layout of the GEMM's LDS image - the wide GEMM kernels copy it HBM -> LDS by
+    LDS-DMA and spend no VALU or VGPR on it.  Format by GEMM mode: bf16x6 = three bf16 term planes (npvp_split_weight),
+    f16x3 = two fp16 planes scaled by the power of two of the weight's amax, which lives in the entry's amax slot
+    (npvp_split_weight_f16).
+      * A view registers itself on first use (split there and then).
+      * `refresh_all()` (FlatAdamW.step, right after the AdamW kernel) re-splits EVERY registered view in one batched call
+        per format over a device table - not ~350 small launches per step, and no per-call bookkeeping.
       * An in-place torch update (load_state_dict, a test's fill) is caught by the tensor version counter: that view is
         re-split lazily.
     The cache lives ON the owning tensor object (the Parameter, or the flat parameter buffer it is a view of), never in a
-    table keyed by device address: a freed weight's address is reused by the next model's weights.
-    NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly, 128 x 128 kernel only)."""
+    table keyed by device address alone: a freed weight's address is reused by the next model's weights.  The key holds the
+    view's device address too: re-pointing `p.data` (FlatBuffers does) makes a NEW entry, and entries whose storage is no longer
+    the owner's are dropped.
+    NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly, bf16x6 128 x 128 kernel only)."""
     enabled = os.environ.get("NPVP_PRESPLIT", "1") == "1"
     _owners = []            # weak references to tensors that carry a `_npvp_planes` store
-    _table = None           # (device table tensor, [entries]) - rebuilt when a view registers or an owner dies
+    _tables = None          # [(fmt, device table, amax table or None, [entries])] - rebuilt when `_dirty`
     _dirty = True
+
+    class Entry:
+        __slots__ = ("fmt", "version", "planes", "w", "amax", "amax_t")
+
+    @classmethod
+    def _owner_died(cls, _ref):
+        cls._dirty = True
 
     @classmethod
     def invalidate(cls):
@@ -173,9 +245,28 @@ class WeightPlanes:
         cls.refresh_all()
 
     @classmethod
+    def forget(cls, owner):
+        """drop the planes cached on `owner` (FlatBuffers re-points parameter storage: the old planes mirror dead memory)"""
+        if owner.__dict__.pop("_npvp_planes", None) is not None:
+            cls._dirty = True
+
+    @staticmethod
+    def _split(ent):
+        w = ent.w
+        N, K = w.shape
+        F, D = _p(ent.planes[0].data_ptr()), _p(ent.planes[1].data_ptr())
+        if ent.fmt == 6:
+            check(lib().npvp_split_weight_f16(_ptr(w), w.stride(0), N, K, F, D, _ptr(ent.amax), _stream()), "npvp_split_weight_f16")
+        else:
+            check(lib().npvp_split_weight(_ptr(w), w.stride(0), N, K, F, D, _stream()), "npvp_split_weight")
+        ent.version = w._version
+
+    @classmethod
     def get(cls, w, want):
-        """want = 'F' (forward, B = w as [N][K]) or 'D' (dgrad, B = w as [K][N]); returns a device buffer or None."""
-        if not cls.enabled or GEMM_PRECISION != 4 or w.dim() != 2 or w.shape[0] % 8 or w.shape[1] % 8 or w.stride(1) != 1:
+        """want = 'F' (forward, B = w as [N][K]) or 'D' (dgrad, B = w as [K][N]); returns (planes buffer, amax slot or None)
+        or None when this weight has no planes."""
+        fmt = GEMM_PRECISION
+        if not cls.enabled or fmt not in (4, 6) or w.dim() != 2 or w.shape[0] % 8 or w.shape[1] % 8 or w.stride(1) != 1:
             return None
         owner = w._base if w._base is not None else w
         if not owner.is_leaf and owner.grad_fn is not None:
@@ -184,59 +275,82 @@ class WeightPlanes:
         if store is None:
             import weakref
             store = owner.__dict__["_npvp_planes"] = {}
-            cls._owners.append(weakref.ref(owner))
-        key = (w.storage_offset(), tuple(w.shape), w.stride(0))
+            cls._owners.append(weakref.ref(owner, cls._owner_died))
+        key = (fmt, w.data_ptr(), tuple(w.shape), w.stride(0))
         ent = store.get(key)
-        if ent is None or ent[0] != w._version:
+        if ent is None:
+            live = owner.untyped_storage().data_ptr()
+            for k in [k for k, e in store.items() if e.w.untyped_storage().data_ptr() != live]:
+                del store[k]                # entries of a storage this owner no longer has (p.data was re-pointed)
             N, K = w.shape
-            planes = ent[1] if ent is not None else torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
-            check(lib().npvp_split_weight(_ptr(w), w.stride(0), N, K, _p(planes[0].data_ptr()), _p(planes[1].data_ptr()),
-                                          _stream()), "npvp_split_weight")
-            if ent is None:
-                cls._dirty = True
-            ent = store[key] = [w._version, planes, w.detach()]
-        return ent[1][0 if want == "F" else 1]
+            ent = cls.Entry()
+            ent.fmt, ent.w = fmt, w.detach()
+            if fmt == 6:
+                ent.planes = torch.empty(2, 2 * N * K, dtype=torch.float16, device=w.device)
+                ent.amax_t = torch.zeros(32, dtype=torch.float32, device=w.device)
+                ent.amax = AmaxSlot(ent.amax_t.data_ptr(), ent.amax_t)
+            else:
+                ent.planes = torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
+                ent.amax = ent.amax_t = None
+            cls._split(ent)
+            store[key] = ent
+            cls._dirty = True
+        elif ent.version != w._version:
+            cls._split(ent)
+        return ent.planes[0 if want == "F" else 1], ent.amax
+
+    @classmethod
+    def _entries(cls):
+        live = []
+        for ref in cls._owners:
+            owner = ref()
+            if owner is None:
+                continue
+            live.append(ref)
+            for ent in owner.__dict__.get("_npvp_planes", {}).values():
+                yield ent
+        cls._owners = live
 
     @classmethod
     def refresh_if_stale(cls):
         """re-split everything if any registered weight was updated in place behind the planes' back (GraphedTrainStep calls
         this before a replay: the captured step refreshes the planes only after ITS optimiser step)"""
-        for ref in cls._owners:
-            owner = ref()
-            if owner is not None and any(ent[0] != ent[2]._version for ent in owner.__dict__.get("_npvp_planes", {}).values()):
-                cls.refresh_all()
-                return
+        if any(ent.version != ent.w._version for ent in cls._entries()):
+            cls.refresh_all()
 
     @classmethod
     def refresh_all(cls):
         if not cls.enabled:
             return
-        if cls._dirty or cls._table is None:
-            rows, ents, live = [], [], []
-            for ref in cls._owners:
-                owner = ref()
-                if owner is None:
-                    continue
-                live.append(ref)
-                for ent in owner.__dict__.get("_npvp_planes", {}).values():
-                    ver, planes, w = ent
-                    if not w.is_cuda:
-                        continue
-                    N, K = w.shape
-                    rows.append([w.data_ptr(), w.stride(0), N, K, planes[0].data_ptr(), planes[1].data_ptr()])
-                    ents.append(ent)
-            cls._owners = live
-            by_dev = {}
-            for r, e in zip(rows, ents):
-                by_dev.setdefault(e[2].device, ([], []))
-                by_dev[e[2].device][0].append(r); by_dev[e[2].device][1].append(e)
-            cls._table = [(torch.tensor(r, dtype=torch.int64).to(dev), e) for dev, (r, e) in by_dev.items()]
+        if cls._dirty or cls._tables is None:
+            groups = {}
+            for ent in cls._entries():
+                if ent.w.is_cuda:
+                    groups.setdefault((ent.fmt, ent.w.device), []).append(ent)
+            cls._tables = []
+            for (fmt, dev), ents in groups.items():
+                amax_t = None
+                if fmt == 6:             # one contiguous slot table per device: zeroed by ONE memset in the batched call
+                    amax_t = torch.zeros(len(ents), 32, dtype=torch.float32, device=dev)
+                    for i, ent in enumerate(ents):
+                        ent.amax_t = amax_t
+                        ent.amax.ptr, ent.amax.chunk = amax_t.data_ptr() + 128 * i, amax_t
+                rows = []
+                for ent in ents:
+                    N, K = ent.w.shape
+                    r = [ent.w.data_ptr(), ent.w.stride(0), N, K, ent.planes[0].data_ptr(), ent.planes[1].data_ptr()]
+                    rows.append(r + [ent.amax.ptr, 0] if fmt == 6 else r)
+                cls._tables.append((fmt, torch.tensor(rows, dtype=torch.int64).to(dev), amax_t, ents))
             cls._dirty = False
-        for table, ents in cls._table:
+        for fmt, table, amax_t, ents in cls._tables:
             with torch.cuda.device(table.device):
-                check(lib().npvp_split_weights_batched(_p(table.data_ptr()), table.shape[0], _stream()), "npvp_split_weights_batched")
+                if fmt == 6:
+                    check(lib().npvp_split_weights_f16(_p(table.data_ptr()), table.shape[0], _p(amax_t.data_ptr()),
+                                                       amax_t.numel() * 4, _stream()), "npvp_split_weights_f16")
+                else:
+                    check(lib().npvp_split_weights_batched(_p(table.data_ptr()), table.shape[0], _stream()), "npvp_split_weights_batched")
             for ent in ents:
-                ent[0] = ent[2]._version
+                ent.version = ent.w._version
 
 
 class GemmProbe:
@@ -247,7 +361,8 @@ class GemmProbe:
     armed = False
     records = []          # (start_event, end_event, flops, bytes, (layout, kernel id))
     KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel<2, 4, 2, 2>",
-               3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>"}
+               3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>", 5: "npvp::gemm_f16_kernel<2, 4, 2, 2>",
+               6: "npvp::gemm_wgrad_f16_kernel", 7: "npvp::gemm_f16_kernel<2, 2, 2, 2>"}
 
     @classmethod
     def arm(cls):
@@ -413,10 +528,29 @@ GEMM_EXCLUSIVE = os.environ.get("NPVP_GEMM_EXCL", "0") == "1"
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None,
-         replay=False):
-    """replay=True: `drop` replays a forward site's mask in backward (not a new site for ops.DropRecorder)"""
+         replay=False, a_amax=None, b_amax=None, c_amax=None):
+    """replay=True: `drop` replays a forward site's mask in backward (not a new site for ops.DropRecorder).
+    b_pre = WeightPlanes.get(...) = (planes, weight amax slot) or None; a_amax / b_amax: the operands' amax slots (f16x3; a
+    missing slot of A - or of B for a weight gradient - is filled by the stand-alone reduction); c_amax: slot that receives
+    the bound of the values stored to `out`."""
     _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
+    prec = GEMM_PRECISION if precision is None else precision
+    planes = None
+    if b_pre is not None:
+        planes, b_amax = b_pre
+    if prec == 6:
+        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, 6, int(planes is not None))
+        if kid == 5 or kid == 7:                # fp16 forward / dgrad kernel
+            if a_amax is None:
+                a_amax = amax_of(A)
+        elif kid == 6:                          # fp16 weight-gradient kernel
+            if a_amax is None:
+                a_amax = amax_of(A)
+            if b_amax is None:
+                b_amax = amax_of(B)
+        else:                                   # runs as bf16x6 without planes
+            planes = None
     wsb = L.npvp_gemm_workspace_bytes(M, N, K)
     ws, wsn = (None, 0)
     if wsb > 0:
@@ -426,7 +560,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
     # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
-    if GEMM_EXCLUSIVE and b_pre is not None and WgradStream._pending is not None:
+    if GEMM_EXCLUSIVE and planes is not None and WgradStream._pending is not None:
         # measurement switch: a critical-path GEMM starts only when the gradient stream has drained
         torch.cuda.current_stream(A.device).wait_stream(WgradStream._pending[1])
     probe = GemmProbe.armed
@@ -435,41 +569,51 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         e0.record()
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
-                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha,
-                          GEMM_PRECISION if precision is None else precision, _ptr(colsum_a),
-                          _ptr(b_pre), int(accumulate), _ptr(rowstats), _ptr(ws), wsn, _stream()),
+                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, prec, _ptr(colsum_a),
+                          _ptr(planes), int(accumulate), _ptr(rowstats), _ptr(a_amax), _ptr(b_amax), _ptr(c_amax),
+                          _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
-        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, GEMM_PRECISION if precision is None else precision, int(b_pre is not None))
+        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, prec, int(planes is not None))
         GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), ((a_kc, b_kc), kid)))
     return out
 
 
-def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP, rowstats=None):
-    """y[R,N] = epilogue(x[R,K] w[N,K]^T); rowstats [R/64, N/64, 2] receives the frame-statistics partials of y"""
+def _planes(w, want, R):
+    return WeightPlanes.get(w, want) if R >= 256 else None
+
+
+def _new_slot(dev, want=True):
+    """a fresh amax slot for a tensor a kernel is about to produce, when the GEMM mode uses them"""
+    return AmaxSlot.new(dev) if (want and GEMM_PRECISION == 6) else None
+
+
+def linear_fwd(x, w, b, act=0, aux_out=None, residual=None, drop=NO_DROP, rowstats=None, x_amax=None, y_amax=None):
+    """y[R,N] = epilogue(x[R,K] w[N,K]^T); rowstats [R/64, N/64, 2] receives the frame-statistics partials of y;
+    x_amax: x's amax slot if its producer filled one; y_amax: slot to receive the bound of y"""
     R, K = x.shape
     N = w.shape[0]
     y = torch.empty(R, N, dtype=torch.float32, device=x.device)
     return gemm(1, 1, R, N, K, x, x.stride(0), w, w.stride(0), y, bias=b, act=act, aux_out=aux_out, residual=residual,
-                drop=drop, b_pre=WeightPlanes.get(w, "F") if R >= 256 else None, rowstats=rowstats)
+                drop=drop, b_pre=_planes(w, "F", R), rowstats=rowstats, a_amax=x_amax, c_amax=y_amax)
 
 
 def linear_frame_stats_supported(R, N):
     """the forward GEMM can emit the frame-LayerNorm statistics of its output (frames of 64 token rows)"""
-    return GEMM_PRECISION == 4 and R % 64 == 0 and N % 128 == 0
+    return GEMM_PRECISION in (4, 6) and R % 64 == 0 and N % 128 == 0
 
 
-def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP):
+def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None):
     """dx[R,K] = epilogue(dy[R,N] w[N,K])"""
     R, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
-    return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop,
-                b_pre=WeightPlanes.get(w, "D") if R >= 256 else None, replay=True)
+    return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop, residual=residual,
+                b_pre=_planes(w, "D", R), replay=True, a_amax=dy_amax, c_amax=dx_amax)
 
 
-def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None):
+def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None):
     """dw[N,K] = dy[R,N]^T x[R,K]; with_bias_grad also returns db[N] = column sums of dy, accumulated by the same
     kernel while it stages dy (no separate reduction pass).  into / into_b: ACCUMULATE into these existing
     gradient slices instead of allocating results (GradSink)."""
@@ -479,7 +623,7 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None):
     dw = into if acc else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = (into_b if acc else torch.empty(N, dtype=torch.float32, device=dy.device)) if with_bias_grad else None
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc,
-         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None)
+         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None, a_amax=dy_amax, b_amax=x_amax)
     return (dw, db) if with_bias_grad else dw
 
 
@@ -811,9 +955,19 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, dres, None, None
 
 
-def _sunk_wgrad(dy, x, with_b, sk):
+def _wgrad_slots(dy, x, dy_amax=None, x_amax=None):
+    """the amax slots of a weight-gradient GEMM's operands when the fp16 kernel will take it, filled on the CURRENT stream
+    (the GEMM itself may run on the gradient stream, which is ordered after this one; a slot first filled over there would
+    be read here without any ordering)"""
+    if GEMM_PRECISION == 6 and lib().npvp_gemm_kernel_id(0, 0, dy.shape[1], x.shape[1], dy.shape[0], 6, 0) == 6:
+        return amax_of(dy, dy_amax), amax_of(x, x_amax)
+    return None, None
+
+
+def _sunk_wgrad(dy, x, with_b, sk, dy_amax=None, x_amax=None):
     """accumulate dW (and db) of one linear into its gradient slots - on the wgrad stream when enabled"""
-    fn = lambda: linear_wgrad(dy, x, with_b, into=sk[0][0], into_b=sk[1][0] if with_b else None)
+    dy_amax, x_amax = _wgrad_slots(dy, x, dy_amax, x_amax)
+    fn = lambda: linear_wgrad(dy, x, with_b, into=sk[0][0], into_b=sk[1][0] if with_b else None, dy_amax=dy_amax, x_amax=x_amax)
     if WgradStream.enabled:
         WgradStream.run(fn, dy, x)
     else:
@@ -1092,7 +1246,7 @@ class _MlpDwbn(torch.autograd.Function):
         # fc1 (+ frame statistics of h1)
         h1 = torch.empty(R, hid, dtype=f32, device=dev)
         part = torch.empty(frames * (hid // 64) * 2, dtype=f32, device=dev)
-        gemm(1, 1, R, hid, C, x, x.stride(0), w1, w1.stride(0), h1, bias=b1, b_pre=WeightPlanes.get(w1, "F") if R >= 256 else None,
+        gemm(1, 1, R, hid, C, x, x.stride(0), w1, w1.stride(0), h1, bias=b1, b_pre=_planes(w1, "F", R),
              rowstats=part)
         stats = torch.empty(6, frames, dtype=f32, device=dev)               # mean1, rstd1, mean2, rstd2, mean3, rstd3
         check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _ptr(stats[0]), _ptr(stats[1]), frames, 1e-5, st),
@@ -1116,7 +1270,7 @@ class _MlpDwbn(torch.autograd.Function):
         # fc2 (+ statistics), norm3 + GELU + dropout + residual + drop-path
         h3 = torch.empty(R, Co, dtype=f32, device=dev)
         part3 = torch.empty(frames * (Co // 64) * 2, dtype=f32, device=dev)
-        gemm(1, 1, R, Co, hid, a2, hid, w2, w2.stride(0), h3, bias=b2, b_pre=WeightPlanes.get(w2, "F") if R >= 256 else None,
+        gemm(1, 1, R, Co, hid, a2, hid, w2, w2.stride(0), h3, bias=b2, b_pre=_planes(w2, "F", R),
              rowstats=part3)
         check(L.npvp_frame_stats_finalize(_ptr(part3), Co // 64, 4096.0, _ptr(stats[4]), _ptr(stats[5]), frames, 1e-5, st),
               "npvp_frame_stats_finalize")
@@ -1207,7 +1361,7 @@ class _MlpDwbn(torch.autograd.Function):
 
 
 def mlpdwbn_fused_supported(R, C, hid, Co, H, W):
-    return (GEMM_PRECISION == 4 and H == 8 and W == 8 and R % 64 == 0 and hid % 512 == 0 and Co % 128 == 0 and hid % 128 == 0
+    return (GEMM_PRECISION in (4, 6) and H == 8 and W == 8 and R % 64 == 0 and hid % 512 == 0 and Co % 128 == 0 and hid % 128 == 0
             and C % 32 == 0)
 
 
@@ -1323,7 +1477,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
         # dx1 = dv Wv + du: the second consumer's gradient rides in as the dgrad GEMM's residual input (no separate add)
         dx1 = torch.empty_like(x1)
         gemm(1, 0, dv.shape[0], C, C, dv, dv.stride(0), wv, wv.stride(0), dx1, residual=du,
-             b_pre=WeightPlanes.get(wv, "D") if dv.shape[0] >= 256 else None, replay=True)
+             b_pre=_planes(wv, "D", dv.shape[0]), replay=True)
         gwv, gbv = _lin_grads(dv, x1, wv, bv, s_v)
         dx, glw, glb = _raw_ln_bwd(dx1, x2, lw, lb, lst, dy2, s_ln)
         return (dx.view(xshape), glw, glb, None, dbeta, dgamma, dadd, gwqk, gbqk, gwv, gbv, gwo, gbo, None, None, None, None)

@@ -482,9 +482,25 @@ def main():
     kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, rand_context=True, dropout=0.0, drop_path=0.0)
     ref = R.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, True, 2, norm=nn.LayerNorm(512), **kw)
     mine = oracle.Predictor(8, 8, T, h, h, tl[:3], tl[3:], 512, 'Add', 'layer', 256, 1, True, 2, **kw)
-    O.key_hashed_fill(ref, 141); O.key_hashed_fill(mine, 141)
-    clip = O.synth_features((N, T, 512, 8, 8), 142)
     idx_o, idx_p = torch.tensor([4, 0, 6, 2]), torch.tensor([5, 1, 3])          # unsorted on purpose
+    # Fill seed: d/d nrmlp.B jumps by ~3e-3 when ONE NRMLP hidden unit changes sides of its ReLU, and fp32-grade arithmetic
+    # paths differ by ~1e-6 in a pre-activation.  This case evaluates 448 coordinates x 3 x 512 units, too many for the 1e-5
+    # margin of the stand-alone NRMLP vectors (seed 141 leaves a unit at 2.3e-6): take the first seed of 141, 1141, ... whose
+    # closest unit is > 7e-6 from the kink (the search fills only the NRMLP, under its full-model state-dict keys).
+    holder = nn.Module(); holder.nrmlp = ref.nrmlp
+    best = (-1.0, 141)
+    for seed_rc in range(141, 400141, 1000):
+        O.key_hashed_fill(holder, seed_rc)
+        with torch.no_grad():
+            mg = min(nrmlp_margin(ref.nrmlp, ref.all_coor[idx_o, ...].flatten(0, 2)), nrmlp_margin(ref.nrmlp, ref.all_coor[idx_p, ...].flatten(0, 2)))
+        best = max(best, (mg, seed_rc))
+        if mg > 7e-6:
+            break
+    mg, seed_rc = best
+    print(f"  randctx: fill seed {seed_rc}, smallest NRMLP |pre-activation| {mg:.2e}")
+    O.key_hashed_fill(ref, seed_rc)
+    O.key_hashed_fill(mine, seed_rc)
+    clip = O.synth_features((N, T, 512, 8, 8), 142)
     batch = (clip[:, idx_o], clip[:, idx_p], idx_o, idx_p)
     # reference side of rand_context_batch_process (Predictor.py:241-251) on the reference module
     ref.observed_coor = ref.all_coor[idx_o, ...].flatten(0, 2)
@@ -506,7 +522,7 @@ def main():
     check("randctx.out", ym[0], yr[0]); check("randctx.mu_p", ym[3], yr[3]); check("randctx.g_obs", xm.grad, xr.grad)
     check("randctx.gB", mine.nrmlp.B.grad, ref.nrmlp.B.grad)
     save("predictor_randctx_S", out=npy(yr[0]), mu_o=npy(yr[1]), mu_p=npy(yr[3]), g_obs=npy(xr.grad), gB=npy(ref.nrmlp.B.grad),
-         g_tied=npy(ref.transformer.norm.weight.grad), meta=np.array([N, T, 141, 142, 143, 144]))
+         g_tied=npy(ref.transformer.norm.weight.grad), meta=np.array([N, T, seed_rc, 142, 143, 144]))
 
     # ------------------------------------------------------------------ continuous time: reset_pos_coor with fractional
     # time-steps (ref Predictor.py:352-359, CoorGenerator submodules.py:339-366)

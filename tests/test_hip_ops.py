@@ -33,7 +33,7 @@ def close(a, b, tol=TOL, what=""):
 
 
 # the exact fp32-MFMA kernel, the default three-term split (wide + 128x128 kernels) and its two-term sibling (opt-in wgrad mode)
-MODES = ["f32", "bf16x6", "bf16x3"]
+MODES = ["f32", "f16x3", "bf16x6", "bf16x3"]
 
 
 @pytest.fixture(scope="module", params=MODES)
@@ -45,7 +45,7 @@ def K(request):
     ops.rng.manual_seed(1234, torch.device(DEV))
     ops.set_gemm_precision(request.param)
     yield ops
-    ops.set_gemm_precision("bf16x6")
+    ops.set_gemm_precision("f16x3")
 
 
 def g(t):
