@@ -47,7 +47,7 @@ int npvp_stream_destroy(void* stream);
  * (relative product error ~2^-23: fp32-grade).  precision 5: two terms, three products (~2^-16; opt-in for weight gradients).
  * precision 6 (the path's default): TWO fp16 terms per operand, three products on v_mfma_f32_32x32x16_f16 (~2^-22 per
  * product: fp32-grade at half the matrix instructions of precision 4).  fp16 has no exponent range to spare, so each operand
- * comes with an AMAX SLOT (32 floats in device memory whose maximum bounds |operand|; see npvp_amax) and is scaled by the power
+ * comes with an AMAX SLOT (2 KB of device memory holding 32 words whose maximum bounds |operand|; see npvp_amax) and is scaled by the power
  * of two that puts the bound into [2^14, 2^15) - exact, undone in the epilogue.  It is taken by (a) a_kc = 1 launches with
  * fp16 planes in `b_pre` (npvp_split_weight_f16) and both a_amax / b_amax, (b) weight gradients (a_kc = b_kc = 0, plain
  * epilogue, K >= 4096) with both slots; every other launch with precision 6 runs as precision 4 without planes.
@@ -87,8 +87,9 @@ int npvp_split_weight(const float* w, long long ld, int N, int K, void* F, void*
 /* The same for MANY weight views in one launch (after the optimiser step, ref/models/Predictor.py:136 opt.step()): desc is a
  * DEVICE array of `count` records of six 64-bit words {w, ld, N, K, F, D} (pointers as integers). */
 int npvp_split_weights_batched(const void* desc, int count, npvp_stream_t stream);
-/* ---- amax slots (precision 6).  A slot is 32 floats, zero before its tensor is produced; producers raise single words of
- * it with integer atomic max (the bit pattern of a non-negative float orders like the float: order independent, so
+/* ---- amax slots (precision 6).  A slot is 2 KB of device memory, zero before its tensor is produced: 32 words, 64 bytes
+ * apart (word i at float offset 16 i; the rest is padding that keeps every word in its own memory sector).  Producers raise
+ * single words with integer atomic max (the bit pattern of a non-negative float orders like the float: order independent, so
  * deterministic) and the tensor's bound is the maximum of the 32 words.  npvp_amax is the stand-alone producer for a
  * [rows][cols] matrix (row stride ld) that no kernel of this library wrote: slot = max(slot, |x|). */
 int npvp_amax(const float* x, long long rows, long long cols, long long ld, float* slot, npvp_stream_t stream);
@@ -99,18 +100,20 @@ int npvp_amax(const float* x, long long rows, long long cols, long long ld, floa
  * all the records' slots and is zeroed first (otherwise the caller zeroes the slots). */
 int npvp_split_weight_f16(const float* w, long long ld, int N, int K, void* F, void* D, float* amax_slot, npvp_stream_t stream);
 int npvp_split_weights_f16(const void* desc, int count, void* amax_table, long long amax_bytes, npvp_stream_t stream);
+/* Producer-side slots: every entry point below whose output can be the A operand of a GEMM takes a nullable `amax` slot
+ * (after its last data argument) and adds the bound of the values it stores to it - no pass over the tensor is spent on it. */
 
 /* ---- token LayerNorm(C) (ref/models/VidHRFormer.py:65-66,69,77,175-176,179,189,194-195; shared final
  * norm :47-48,150-151; relu=1 fuses the decoder's F.relu_ :159).  C in {256,512,768,1024}.
  * mean/rstd [rows] are saved for backward (nullable in fwd). */
 int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, long long rows,
-                       int C, float eps, int relu, npvp_stream_t stream);
+                       int C, float eps, int relu, float* y_amax, npvp_stream_t stream);
 long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C);
 int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                        const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
                        const float* dres /* nullable: dx += dres, the residual branch's gradient */,
-                       int accumulate /* 1: dw, db +=; 2: leave the partial sums in workspace */, void* workspace,
-                       long long ws_bytes, npvp_stream_t stream);
+                       int accumulate /* 1: dw, db +=; 2: leave the partial sums in workspace */, float* dx_amax,
+                       void* workspace, long long ws_bytes, npvp_stream_t stream);
 /* second stage of npvp_layernorm_bwd(accumulate = 2), on a stream of the caller's choice (the gradient stream) */
 int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate,
                               npvp_stream_t stream);
@@ -128,7 +131,7 @@ int npvp_layernorm_nchw_fwd(const float* x, const float* w, const float* b, floa
 int npvp_frame_stats(const float* x, const float* add, float* mean, float* rstd, int frames, int T, int per_frame,
                      float eps, npvp_stream_t stream);
 int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y, float* mean,
-                     float* rstd, int N, int T, int per_frame, float eps, npvp_stream_t stream);
+                     float* rstd, int N, int T, int per_frame, float eps, float* y_amax, npvp_stream_t stream);
 int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
                      const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
                      long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
@@ -139,13 +142,13 @@ int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const fl
 int npvp_frameln_act_fwd(const float* h, const float* mean, const float* rstd, const float* w, const float* b,
                          const float* res, float* out, int frames, int per_frame, float drop_p, unsigned int salt,
                          float dp_p, unsigned int dp_salt, int frames_per_sample, const unsigned long long* seed,
-                         npvp_stream_t stream);
+                         float* out_amax, npvp_stream_t stream);
 long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame);
 int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                          const float* b, float* dh, float* dw, float* db, int frames, int per_frame, float drop_p,
                          unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
                          const unsigned long long* seed, int accumulate /* 1: dw, db +=; 2: leave partials */,
-                         void* workspace, long long ws_bytes, npvp_stream_t stream);
+                         float* dh_amax, void* workspace, long long ws_bytes, npvp_stream_t stream);
 int npvp_frameln_act_bwd_reduce(const void* workspace, float* dw, float* db, int frames, int per_frame, int accumulate,
                                 npvp_stream_t stream);
 /* depthwise 3x3, zero pad 1 (ref/models/VidHRFormer.py:351-358); wt is tap-major [9][Ch]; flip=1 gives the
@@ -175,7 +178,8 @@ int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, 
  * psum [frames][nparts][2]; workspace as npvp_frameln_act_bwd. */
 int npvp_frameln_act_bwd_apply(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                                const float* b, const float* psum, int nparts, float* dh, float* dw, float* db, int frames,
-                               int per_frame, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                               int per_frame, int accumulate, float* dh_amax, void* workspace, long long ws_bytes,
+                               npvp_stream_t stream);
 
 /* im2col / col2im of the EventEncoder's dense 3x3 conv (ref/models/submodules.py:376), channels-last:
  * col2im=0: in [F][H*W][C] -> out [F*H*W][9*C] (tap-major columns); col2im=1: the adjoint. */
@@ -192,15 +196,18 @@ int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dwt_db, int f
  *   mask_mode 1 = encoder quirk ref :100-102.  q NOT pre-scaled; head_dim must be 64; L,S <= 32. */
 int npvp_attn_fwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v, float* o,
                   long long ld_o, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads, int head_dim,
-                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, float* o_amax,
+                  npvp_stream_t stream);
 int npvp_attn_bwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v,
                   const float* go, long long ld_o, float* dq, long long ld_dq, float* dk, long long ld_dk, float* dv,
                   long long ld_dv, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads, int head_dim,
-                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+                  int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, float* dq_amax,
+                  float* dk_amax /* may equal dq_amax: one slot for a packed q|k gradient */, float* dv_amax,
+                  npvp_stream_t stream);
 
 /* ---- layout / reductions / masks */
 int npvp_drop_apply(const float* x, float* out, long long rows, int ncols, float p, int mode, int g1, int g2,
-                    const unsigned long long* seed, unsigned int salt, npvp_stream_t stream);
+                    const unsigned long long* seed, unsigned int salt, float* out_amax, npvp_stream_t stream);
 int npvp_transpose(const float* in, float* out, int batch, int R, int C, npvp_stream_t stream); /* [B][R][C]->[B][C][R] */
 int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);

@@ -25,34 +25,34 @@ SIGNATURES = {
     "npvp_frame_stats_finalize": (c_int, [c_p, c_int, c_f, c_p, c_p, c_int, c_f, c_p]),
     "npvp_split_weight": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p]),
     "npvp_split_weights_batched": (c_int, [c_p, c_int, c_p]),
-    "npvp_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_f, c_int, c_p]),
+    "npvp_layernorm_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_f, c_int, c_p, c_p]),
     "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),
-    "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_int, c_p, c_ll, c_p]),
+    "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_layernorm_bwd_reduce": (c_int, [c_p, c_p, c_p, c_ll, c_int, c_int, c_p]),
     "npvp_layernorm_nchw_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_int, c_p]),
     "npvp_frameln_act_bwd_reduce": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_frame_stats": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
-    "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),
+    "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p, c_p]),
     "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
-    "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p]),
+    "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p, c_p]),
     "npvp_frameln_act_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_frameln_act_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
-                                     c_p, c_int, c_p, c_ll, c_p]),
+                                     c_p, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_dwconv3x3": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_mlpdw_mid_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_bwd_reduce": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
-    "npvp_frameln_act_bwd_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_frameln_act_bwd_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_im2col3x3": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_wgrad_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_dwconv3x3_wgrad": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_attn_fwd": (c_int, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_int, c_int, c_int, c_f, c_p, c_u, c_p]),
+                              c_int, c_int, c_int, c_f, c_p, c_u, c_p, c_p]),
     "npvp_attn_bwd": (c_int, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_int, c_int,
-                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f, c_p, c_u, c_p]),
-    "npvp_drop_apply": (c_int, [c_p, c_p, c_ll, c_int, c_f, c_int, c_int, c_int, c_p, c_u, c_p]),
+                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f, c_p, c_u, c_p, c_p, c_p, c_p]),
+    "npvp_drop_apply": (c_int, [c_p, c_p, c_ll, c_int, c_f, c_int, c_int, c_int, c_p, c_u, c_p, c_p]),
     "npvp_transpose": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_broadcast_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),

@@ -39,6 +39,7 @@ struct AttnParams {
   const unsigned long long* seed;
   long long total;                // groups * heads
   int wpb, per_wave_floats;
+  float* o_amax; float* dq_amax; float* dk_amax; float* dv_amax;     // nullable amax slots of the outputs (common.h)
 };
 
 __device__ __forceinline__ long long attn_row(const AttnParams& p, long long g, int m, int Tn) {
@@ -61,12 +62,16 @@ __device__ __forceinline__ void load_tile(float* dst, const float* src, long lon
     st4(dst + r * LDT + c4, ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + c4));
   }
 }
-__device__ __forceinline__ void store_tile(const float* src, float* dst, long long ld, const AttnParams& p, long long g,
-                                           int nrows, int Tn, int head, int lane) {
+__device__ __forceinline__ float store_tile(const float* src, float* dst, long long ld, const AttnParams& p, long long g,
+                                            int nrows, int Tn, int head, int lane) {
+  float am = 0.f;
   for (int idx = lane; idx < nrows * 16; idx += 64) {
     const int r = idx >> 4, c4 = (idx & 15) * 4;
-    st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + c4, ld4(src + r * LDT + c4));
+    const float4 v = ld4(src + r * LDT + c4);
+    st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + c4, v);
+    am = amax4(am, v);
   }
+  return am;
 }
 
 __device__ __forceinline__ float dot64(const float4* a, const float* b) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int c4 = 0; c4 < CW / 4; ++c4) st4(Qs + i * LDT + part * CW + c4 * 4, acc[c4]);
   }
   __syncthreads();
-  if (active) store_tile(Qs, p.o, p.ld_o, p, g, L, Tq, head, lane);
+  if (active) amax_slot_commit(p.o_amax, store_tile(Qs, p.o, p.ld_o, p, g, L, Tq, head, lane), 0u);
 }
 
 template <int PARTS>
@@ -297,9 +302,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
   __syncthreads();
   if (active) {
-    store_tile(Qs, p.dq, p.ld_dq, p, g, L, Tq, head, lane);
-    store_tile(Ks, p.dk, p.ld_dk, p, g, S, Tk, head, lane);
-    store_tile(Vs, p.dv, p.ld_dv, p, g, S, Tk, head, lane);
+    amax_slot_commit(p.dq_amax, store_tile(Qs, p.dq, p.ld_dq, p, g, L, Tq, head, lane), 0u);
+    amax_slot_commit(p.dk_amax, store_tile(Ks, p.dk, p.ld_dk, p, g, S, Tk, head, lane), 0u);
+    amax_slot_commit(p.dv_amax, store_tile(Vs, p.dv, p.ld_dv, p, g, S, Tk, head, lane), 0u);
   }
 }
 
@@ -346,11 +351,15 @@ __device__ __forceinline__ void attn_load_g(AttnTileG& t, const float* src, long
 }
 // D rows 16 blk + 4c+i, columns d = 4n + b: one float4 per row
 __device__ __forceinline__ void attn_store_d(const f32x4_t (&acc)[4], float* dst, long long ld, const AttnParams& p, long long g,
-                                             int nrows, int Tn, int head, int n, int c, int blk) {
+                                             int nrows, int Tn, int head, int n, int c, int blk, float& am) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 16 * blk + 4 * c + i;
-    if (r < nrows) st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n, make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]));
+    if (r < nrows) {
+      const float4 v = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+      st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n, v);
+      am = amax4(am, v);
+    }
   }
 }
 __device__ __forceinline__ float blk_of(const float4& x, int b) { return b == 0 ? x.x : b == 1 ? x.y : b == 2 ? x.z : x.w; }
@@ -389,6 +398,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
   AttnTileR kr[NK];
   AttnTileG vg[NK];
+  float am_o = 0.f;
+  const unsigned int pk_o = amax_peek_wave(p.o_amax);
 #pragma unroll
   for (int kb = 0; kb < NK; ++kb) {
     attn_load_r(kr[kb], p.k, p.ld_k, p, g, S, Tk, head, n, c, kb);
@@ -434,8 +445,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       }
       attn_mm_rows(o, sc[kb], vg[kb]);
     }
-    attn_store_d(o, p.o, p.ld_o, p, g, L, Tq, head, n, c, qb);
+    attn_store_d(o, p.o, p.ld_o, p, g, L, Tq, head, n, c, qb, am_o);
   }
+  amax_slot_commit(p.o_amax, am_o, pk_o);
 }
 
 template <int NQ, int NK>
@@ -455,7 +467,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
     attn_load_r(vr[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
   }
   // ---- orientation A per query block: softmax statistics of query 16qb+n (kept for phase B), dQ
-  float mxs[NQ], invs[NQ], rss[NQ];
+  float mxs[NQ], invs[NQ], rss[NQ], am_q = 0.f, am_k = 0.f, am_v = 0.f;
+  const unsigned int pk_q = amax_peek_wave(p.dq_amax), pk_k = amax_peek_wave(p.dk_amax), pk_v = amax_peek_wave(p.dv_amax);
   AttnTileR qr, gr;               // with a single query block the tiles of phase A are reused by phase B
 #pragma unroll
   for (int qb = 0; qb < NQ; ++qb) {
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
       for (int i = 0; i < 4; ++i) ds[i] = sc[kb][i] * (dp[kb][i] - rs) * p.scale;
       attn_mm_rows(dq, ds, kg[kb]);                              // dQ[q][d] += sum_j dS[q][j] K[j][d]
     }
-    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb);
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb, am_q);
   }
   // ---- orientation B per key block: register i <-> (query 16qb + 4c+i, key 16kb + n): dK, dV
 #pragma unroll
@@ -545,9 +558,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
       attn_mm_rows(dv, pd, gg);                                  // dV[j][d] += sum_q Pd[q][j] dO[q][d]
       attn_mm_rows(dk, ds, qg);                                  // dK[j][d] += sum_q dS[q][j] Q[q][d]
     }
-    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb);
-    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb);
+    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb, am_v);
+    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb, am_k);
   }
+  amax_slot_commit(p.dq_amax, am_q, pk_q);
+  amax_slot_commit(p.dk_amax, am_k, pk_k);
+  amax_slot_commit(p.dv_amax, am_v, pk_v);
 }
 
 // ---- backward for query sequences of 17..32 rows (the c2 decoder: T = 28): Q, dO and K staged ONCE in LDS.
@@ -615,7 +631,8 @@ __global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
   }
   __syncthreads();                          // one wave per workgroup: orders the LDS writes before the reads below
   // ---- orientation A per query block: softmax statistics of query 16qb+n (kept for phase B), dQ
-  float mxs[NQ], invs[NQ], rss[NQ];
+  float mxs[NQ], invs[NQ], rss[NQ], am_q = 0.f, am_k = 0.f, am_v = 0.f;
+  const unsigned int pk_q = amax_peek_wave(p.dq_amax), pk_k = amax_peek_wave(p.dk_amax), pk_v = amax_peek_wave(p.dv_amax);
 #pragma unroll
   for (int qb = 0; qb < NQ; ++qb) {
     AttnTileR qr, gr;
@@ -670,7 +687,7 @@ __global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
       attn_lds_g(kg, Ks, S, n, c, kb);
       attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] += sum_j dS[q][j] K[j][d]
     }
-    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb);
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb, am_q);
   }
   // ---- orientation B per key block: register i <-> (query 16qb + 4c+i, key 16kb + n): dK, dV
 #pragma unroll
@@ -705,9 +722,12 @@ __global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
       attn_mm_rows(dv, pd, gg);                                  // dV[j][d] += sum_q Pd[q][j] dO[q][d]
       attn_mm_rows(dk, ds, qg);                                  // dK[j][d] += sum_q dS[q][j] Q[q][d]
     }
-    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb);
-    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb);
+    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb, am_v);
+    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb, am_k);
   }
+  amax_slot_commit(p.dq_amax, am_q, pk_q);
+  amax_slot_commit(p.dk_amax, am_k, pk_k);
+  amax_slot_commit(p.dv_amax, am_v, pk_v);
 }
 
 static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
@@ -749,10 +769,11 @@ using namespace npvp;
 extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v,
                              float* o, long long ld_o, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads,
                              int head_dim, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt,
-                             hipStream_t stream) {
+                             float* o_amax, hipStream_t stream) {
   AttnParams p = {};
   const int rc = attn_setup(p, mode, heads, head_dim, dim0, P, W, ws, Tq, Tk, mask_mode, drop_p, seed, salt, false);
   if (rc) return rc;
+  p.o_amax = o_amax;
   NPVP_CHECK_ARG(dim0 > 0, "attn: empty batch");
   NPVP_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0, "attn: row strides must be multiples of 4");
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o;
@@ -777,10 +798,11 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
                              const float* go, long long ld_o, float* dq, long long ld_dq, float* dk, long long ld_dk,
                              float* dv, long long ld_dv, int mode, int dim0, int P, int W, int ws, int Tq, int Tk,
                              int heads, int head_dim, int mask_mode, float drop_p, const unsigned long long* seed,
-                             unsigned int salt, hipStream_t stream) {
+                             unsigned int salt, float* dq_amax, float* dk_amax, float* dv_amax, hipStream_t stream) {
   AttnParams p = {};
   const int rc = attn_setup(p, mode, heads, head_dim, dim0, P, W, ws, Tq, Tk, mask_mode, drop_p, seed, salt, true);
   if (rc) return rc;
+  p.dq_amax = dq_amax; p.dk_amax = dk_amax; p.dv_amax = dv_amax;
   NPVP_CHECK_ARG(dim0 > 0, "attn_bwd: empty batch");
   NPVP_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0 && ld_dq % 4 == 0 && ld_dk % 4 == 0 &&
                      ld_dv % 4 == 0, "attn_bwd: row strides must be multiples of 4");

@@ -43,6 +43,66 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- amax slots (precision-6 GEMM operands, include/npvp_hip.h): the tensor's bound is the maximum of 32 words that lie
+// 64 bytes apart (a slot is 2 KB: each word in its own memory sector).  Producers raise single words with an integer atomic
+// max on the bit pattern of a non-negative float (order independent: deterministic); consumers read the 32 words with one
+// strided load.  Same-address atomics - and L1-bypassing loads of one line - queue at ~10 ns each, and a large launch has
+// 10^4..10^5 waves, hence: 32 words, one sector each; look before raising; one commit per BLOCK where every thread reaches
+// the end of the kernel (amax_slot_commit_block), per wave otherwise.
+constexpr int AMAX_WORDS = 32, AMAX_STRIDE = 16;
+__device__ __forceinline__ float amax_slot_read(const float* slot) {
+  const float v = wave_max(slot[(threadIdx.x & (AMAX_WORDS - 1)) * AMAX_STRIDE]);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+// Raising a word: an atomic only when the bound is above what the word held when the wave / block STARTED (amax_peek_*: an
+// L1-bypassing load issued first thing, its latency hidden under the kernel's work; a load at the end of the kernel would
+// sit in the memory queue behind the kernel's own streaming stores).  After the first resident set of a launch almost no
+// bound is above the word, so a launch costs about one atomic per resident wave / block.  A stale peek costs an unnecessary
+// atomic, never a wrong bound.  A null slot peeks as "already at the maximum".
+__device__ __forceinline__ unsigned int amax_peek(const float* slot, unsigned int idx) {
+  if (!slot) return 0xffffffffu;
+  return __hip_atomic_load(reinterpret_cast<const unsigned int*>(slot) + (idx & (AMAX_WORDS - 1)) * AMAX_STRIDE, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int amax_peek_wave(const float* slot) { return amax_peek(slot, blockIdx.x * 4u + (threadIdx.x >> 6)); }
+__device__ __forceinline__ unsigned int amax_peek_block(const float* slot) { return amax_peek(slot, blockIdx.x); }
+__device__ __forceinline__ void amax_word_raise(float* slot, unsigned int idx, float m, unsigned int peeked) {
+  const unsigned int bits = __float_as_uint(m);
+  if (bits > peeked) atomicMax(reinterpret_cast<unsigned int*>(slot) + (idx & (AMAX_WORDS - 1)) * AMAX_STRIDE, bits);
+}
+__device__ __forceinline__ void amax_slot_commit(float* slot, float m, unsigned int peeked) {          // per wave (wave-uniform call)
+  if (!slot) return;
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) amax_word_raise(slot, blockIdx.x * 4u + (threadIdx.x >> 6), m, peeked);
+}
+// per block: EVERY thread of the block must call it; red = blockDim.x / 64 floats of LDS that nobody else is using
+__device__ __forceinline__ void amax_slot_commit_block(float* slot, float m, float* red, unsigned int peeked) {
+  if (!slot) return;
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned int i = 1; i < (blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    amax_word_raise(slot, blockIdx.x, m, peeked);
+  }
+}
+// the power of two s with amax * s in [2^14, 2^15) (1 for a zero / tiny / non-finite bound)
+__host__ __device__ __forceinline__ float amax_scale(float amax) {
+  unsigned int u;
+  __builtin_memcpy(&u, &amax, 4);
+  const unsigned int E = (u >> 23) & 0xffu;
+  if (E < 16u || E == 255u) return 1.f;
+  u = (268u - E) << 23;
+  float s;
+  __builtin_memcpy(&s, &u, 4);
+  return s;
+}
+
+// running bound of four stored values
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+  return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 // acc += a * b as exactly one v_fmac_f32 (the optimiser can neither pair it into v_pk_fma_f32 nor split it).
 __device__ __forceinline__ void fmac_scalar(float& acc, float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)

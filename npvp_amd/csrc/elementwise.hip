@@ -10,9 +10,12 @@
 namespace npvp {
 
 __global__ void drop_apply_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int ncols,
-                                  DropSpec d, const unsigned long long* __restrict__ seedp) {
+                                  DropSpec d, const unsigned long long* __restrict__ seedp, float* __restrict__ amax) {
   const unsigned long long seed = *seedp;
   const int c4n = ncols / 4;
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  float am = 0.f;
   const long long total4 = rows * c4n;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / c4n;
@@ -28,7 +31,9 @@ __global__ void drop_apply_kernel(const float* __restrict__ x, float* __restrict
       v.x *= s; v.y *= s; v.z *= s; v.w *= s;
     }
     st4(out + row * ncols + col, v);
+    am = amax4(am, v);
   }
+  amax_slot_commit_block(amax, am, ared, peek);
 }
 
 // in [B][R][C] -> out [B][C][R], 32x32 LDS tiles, 256 threads (32 x 8)
@@ -155,12 +160,12 @@ static inline int ew_blocks(long long total, int threads) {
 using namespace npvp;
 
 extern "C" int npvp_drop_apply(const float* x, float* out, long long rows, int ncols, float p, int mode, int g1, int g2,
-                               const unsigned long long* seed, unsigned int salt, hipStream_t stream) {
+                               const unsigned long long* seed, unsigned int salt, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0 && ncols % 4 == 0, "drop_apply: bad shape");
   NPVP_CHECK_ARG(p > 0.f && p < 1.f && seed, "drop_apply: needs 0 < p < 1 and a device seed");
   const DropSpec d = make_drop_spec(p, salt, mode, g1, g2);
   hipLaunchKernelGGL(drop_apply_kernel, dim3(ew_blocks(rows * (ncols / 4), 256)), dim3(256), 0, stream, x, out, rows, ncols,
-                     d, seed);
+                     d, seed, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -34,31 +34,6 @@ struct GemmParams {
   const float* a_amax; const float* b_amax; float* c_amax;
 };
 
-// ---- amax slots: 32 floats, the tensor's bound is their maximum.  Producers add to a slot with one integer atomic max per
-// wave on the bit pattern of a non-negative float (order independent: deterministic), spread over the 32 words so that the
-// ~10^4 waves of a large launch do not queue on one address; consumers read the 32 words with one load.
-__device__ __forceinline__ float amax_slot_read(const float* slot) {
-  const float v = wave_max(slot[threadIdx.x & 31]);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ void amax_slot_commit(float* slot, float m) {
-  if (!slot) return;
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0)
-    atomicMax(reinterpret_cast<unsigned int*>(slot) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 31u), __float_as_uint(m));
-}
-// the power of two s with amax * s in [2^14, 2^15) (1 for a zero / tiny / non-finite bound)
-__host__ __device__ __forceinline__ float amax_scale(float amax) {
-  unsigned int u;
-  __builtin_memcpy(&u, &amax, 4);
-  const unsigned int E = (u >> 23) & 0xffu;
-  if (E < 16u || E == 255u) return 1.f;
-  u = (268u - E) << 23;
-  float s;
-  __builtin_memcpy(&s, &u, 4);
-  return s;
-}
-
 __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
   p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
 }

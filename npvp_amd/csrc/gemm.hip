@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
   epilogue_tile(p, acc01, row0, col0 + 32, r, h, z, seed, cmax);
   epilogue_tile(p, acc10, row0 + 32, col0, r, h, z, seed, cmax);
   epilogue_tile(p, acc11, row0 + 32, col0 + 32, r, h, z, seed, cmax);
-  if (p.splits == 1) amax_slot_commit(p.c_amax, cmax);
+  if (p.splits == 1) amax_slot_commit(p.c_amax, cmax, 0u);        // (small shapes only: no peek)
 }
 
 // 128 x 128 tiles: unsplit launches use the XCD-aware remap of gemm.h; split-K launches (weight gradients) keep all tiles
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
     }
   }
-  if constexpr (ROWSTATS) { float cmax = 0.f; epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h, cmax); amax_slot_commit(p.c_amax, cmax); }
+  if constexpr (ROWSTATS) { float cmax = 0.f; epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h, cmax); amax_slot_commit(p.c_amax, cmax, 0u); }
   else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
 }
 

@@ -7,7 +7,7 @@
 // fp16 carries 11 significand bits, so two terms reach 2^-22 where bf16 needs three; the dropped lo_a lo_b term is
 // <= 2^-22 relative.  Representation error of a whole product sum against fp64: 7.6e-8 rel-L2 (tools/f16_emulate.py; an fp32
 // GEMM's own accumulation error is 3e-7).  What fp16 does NOT have is fp32's exponent range, so every operand tensor comes
-// with an AMAX SLOT - 32 floats whose maximum bounds |x| over the tensor - and is multiplied by the power of two s that
+// with an AMAX SLOT - 32 words (64 bytes apart) whose maximum bounds |x| over the tensor - and is multiplied by the power of two s that
 // puts that bound into [2^14, 2^15): nothing overflows (max 65504), and an element 2^-18 below the bound still has a
 // NORMAL low term.  Smaller elements lose low-term bits gradually (fp16 subnormals: gfx950 converts to them and its MFMA
 // multiplies them exactly - tools/f16_probe.hip), i.e. they carry an ABSOLUTE error of 2^-40 of the tensor's bound, which
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   const int nk = p.K >> 4;
   const float sa = amax_scale(amax_slot_read(p.a_amax));
+  const unsigned int cpeek = amax_peek_block(p.c_amax);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
 #pragma unroll
       for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, 0, seed, cmax);
   }
-  amax_slot_commit(p.c_amax, cmax);
+  amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
 
 // =====================================================================================================
@@ -363,13 +364,14 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
 
 // ---- amax of a tensor: slot[32] = max(slot, |x|) --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n4, long long ldq, long long cols4, float* slot) {
+  __shared__ float ared[4];
+  const unsigned int peek = amax_peek_block(slot);
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / cols4, c = i - row * cols4;
-    const float4 v = ld4(x + 4 * (row * ldq + c));
-    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = amax4(m, ld4(x + 4 * (row * ldq + c)));
   }
-  amax_slot_commit(slot, m);
+  amax_slot_commit_block(slot, m, ared, peek);
 }
 
 // ---- weights -> scaled fp16 planes: F[term][K/8][N][8 over k], D[term][N/8][K][8 over n] -----------------------------
@@ -379,13 +381,14 @@ __global__ __launch_bounds__(256) void weights_amax_kernel(const SplitDescH* __r
   const SplitDescH d = desc ? desc[blockIdx.y] : one;
   const int K4 = (int)d.K / 4;
   const long long total = d.N * K4;
+  __shared__ float ared[4];
+  const unsigned int peek = amax_peek_block(d.amax);
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / K4; const int k4 = (int)(i - n * K4);
-    const float4 v = ld4(d.w + n * d.ld + 4 * k4);
-    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = amax4(m, ld4(d.w + n * d.ld + 4 * k4));
   }
-  amax_slot_commit(d.amax, m);
+  amax_slot_commit_block(d.amax, m, ared, peek);
 }
 
 __global__ __launch_bounds__(256) void split_weights_f16_kernel(const SplitDescH* __restrict__ desc, SplitDescH one) {
@@ -451,7 +454,7 @@ extern "C" int npvp_split_weights_f16(const void* desc, int count, void* amax_ta
 extern "C" int npvp_split_weight_f16(const float* w, long long ld, int N, int K, void* F, void* D, float* amax_slot, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ld % 4 == 0, "split_weight_f16: N, K must be multiples of 8");
   NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0 && amax_slot, "split_weight_f16: w must be 16-byte aligned, amax_slot non-null");
-  if (hipMemsetAsync(amax_slot, 0, 128, stream) != hipSuccess) { npvp_set_error("split_weight_f16: memset failed"); return NPVP_ERR_LAUNCH; }
+  if (hipMemsetAsync(amax_slot, 0, AMAX_WORDS * AMAX_STRIDE * 4, stream) != hipSuccess) { npvp_set_error("split_weight_f16: memset failed"); return NPVP_ERR_LAUNCH; }
   SplitDescH one = {w, ld, N, K, (_Float16*)F, (_Float16*)D, amax_slot, 0};
   hipLaunchKernelGGL(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
   NPVP_CHECK_LAUNCH();

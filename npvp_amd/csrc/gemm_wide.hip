@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: SGPR
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   const int nk = p.K >> 4;
+  const unsigned int cpeek = amax_peek_block(p.c_amax);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
 #pragma unroll
       for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, 0, seed, cmax);
   }
-  amax_slot_commit(p.c_amax, cmax);
+  amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
 
 // =====================================================================================================

@@ -18,39 +18,48 @@ template <int NV>   // C = NV*256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long long rows,
-                                                     float eps, int relu) {
+                                                     float eps, int relu, float* __restrict__ amax) {
   constexpr int C = NV * 256;
+  __shared__ float ared[4];
+  const unsigned int peek = amax_peek_block(amax);
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float4 v[NV];
-  float s = 0.f;
+  float4 ww[NV], bb[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    v[i] = ld4(x + row * C + (i * 64 + lane) * 4);
-    s += v[i].x + v[i].y + v[i].z + v[i].w;
-  }
-  const float mu = wave_sum(s) * (1.f / C);
-  float q = 0.f;
+  for (int i = 0; i < NV; ++i) { ww[i] = ld4(w + (i * 64 + lane) * 4); bb[i] = ld4(b + (i * 64 + lane) * 4); }
+  float am = 0.f;
+  // one wave per row, a few rows per wave (grid capped by the launcher): the parameters are loaded once per wave and the
+  // amax commit at the end is one per block
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    float4 v[NV];
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-    q += a * a + bb * bb + c * c + d * d;
-  }
-  const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+    for (int i = 0; i < NV; ++i) {
+      v[i] = ld4(x + row * C + (i * 64 + lane) * 4);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c0 = (i * 64 + lane) * 4;
-    const float4 ww = ld4(w + c0), bb = ld4(b + c0);
-    float4 o;
-    o.x = (v[i].x - mu) * rs * ww.x + bb.x;
-    o.y = (v[i].y - mu) * rs * ww.y + bb.y;
-    o.z = (v[i].z - mu) * rs * ww.z + bb.z;
-    o.w = (v[i].w - mu) * rs * ww.w + bb.w;
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    st4(y + row * C + c0, o);
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[i].x - mu, b2 = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += a * a + b2 * b2 + c * c + d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      float4 o;
+      o.x = (v[i].x - mu) * rs * ww[i].x + bb[i].x;
+      o.y = (v[i].y - mu) * rs * ww[i].y + bb[i].y;
+      o.z = (v[i].z - mu) * rs * ww[i].z + bb[i].z;
+      o.w = (v[i].w - mu) * rs * ww[i].w + bb[i].w;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      st4(y + row * C + c0, o);
+      am = amax4(am, o);
+    }
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
   }
-  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  amax_slot_commit_block(amax, am, ared, peek);
 }
 
 // ---- the decoder's FINAL LayerNorm + ReLU writing the reference's (N,T,C,H,W) tensor directly (SURVEY 2b K9;
@@ -107,9 +116,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      float* __restrict__ dx, float* __restrict__ partial, long long rows,
-                                                     int relu, const float* __restrict__ dres) {
+                                                     int relu, const float* __restrict__ dres, float* __restrict__ amax) {
   constexpr int C = NV * 256;
   __shared__ float red[4][2 * C];
+  __shared__ float ared[4];
+  const unsigned int peek = amax_peek_block(amax);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ww[NV], bb[NV], aw[NV], ab[NV];
 #pragma unroll
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     aw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float am = 0.f;
   for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NV], g[NV];
@@ -154,8 +166,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       o.w = rs * (g[i].w - s1 - xh[i].w * s2);
       if (dres) { const float4 e = ld4(dres + row * C + c0); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
       st4(dx + row * C + c0, o);
+      am = amax4(am, o);
     }
   }
+  amax_slot_commit_block(amax, am, ared, peek);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c0 = (i * 64 + lane) * 4;
@@ -231,8 +245,11 @@ __global__ __launch_bounds__(512) void frame_stats_kernel(const float* __restric
 __global__ void posfuse_apply_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                      const float* __restrict__ beta, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                     float* __restrict__ y, int T, int per_frame, long long total4) {
+                                     float* __restrict__ y, int T, int per_frame, long long total4, float* __restrict__ amax) {
   const int pf4 = per_frame / 4;
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  float am = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const long long f = i / pf4;
     const int e = (int)(i - f * pf4) * 4;
@@ -249,7 +266,9 @@ __global__ void posfuse_apply_kernel(const float* __restrict__ x, const float* _
     }
     o.x += bt.x; o.y += bt.y; o.z += bt.z; o.w += bt.w;
     st4(y + f * per_frame + e, o);
+    am = amax4(am, o);
   }
+  amax_slot_commit_block(amax, am, ared, peek);
 }
 
 // backward statistics: s1[f] = mean(g), s2[f] = mean(g * uhat), g = dy * (1 + gamma)
@@ -328,8 +347,11 @@ __device__ __forceinline__ float fln_scale(const FlnParams& p, unsigned long lon
   return sc;
 }
 
-__global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out) {
+__global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out, float* __restrict__ amax) {
   const int pf4 = p.per_frame / 4;
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  float am = 0.f;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.total4; i += (long long)gridDim.x * blockDim.x) {
     const long long f = i / pf4;
@@ -344,7 +366,9 @@ __global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out) {
     o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, f, g0 + 3);
     if (p.res) { const float4 r = ld4(p.res + g0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     st4(out + g0, o);
+    am = amax4(am, o);
   }
+  amax_slot_commit_block(amax, am, ared, peek);
 }
 
 // dy_ln = dout * scale * gelu'(y);  g = dy_ln * w;  s1 = mean(g), s2 = mean(g*hhat)
@@ -382,9 +406,12 @@ __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p,
 // (summed by sum_rows_kernel).  Saves the separate apply pass of the first version (a full re-read of dout and h).
 __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restrict__ dout, const float* __restrict__ psum,
                                              float* __restrict__ dh, float* __restrict__ part, int frames,
-                                             int frames_per_chunk, int nparts) {
+                                             int frames_per_chunk, int nparts, float* __restrict__ amax) {
   const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e >= p.per_frame) return;
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  float am = 0.f;
+  if (e >= p.per_frame) { amax_slot_commit_block(amax, am, ared, peek); return; }      // (every thread joins the block's commit)
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
   const float4 ww = ld4(p.w + e), bb = ld4(p.b + e);
   float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,7 +435,9 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
     o.x = rs * (dx_ * ww.x - a1 - hx * a2); o.y = rs * (dy_ * ww.y - a1 - hy * a2);
     o.z = rs * (dz_ * ww.z - a1 - hz * a2); o.w = rs * (dw_ * ww.w - a1 - hw * a2);
     st4(dh + g0, o);
+    am = amax4(am, o);
   }
+  amax_slot_commit_block(amax, am, ared, peek);
   float* o = part + (long long)blockIdx.y * 2 * p.per_frame;
   st4(o + e, aw);
   st4(o + p.per_frame + e, ab);
@@ -452,15 +481,17 @@ static void fill_fln(FlnParams& p, const float* h, const float* mean, const floa
 using namespace npvp;
 
 extern "C" int npvp_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
-                                  long long rows, int C, float eps, int relu, hipStream_t stream) {
+                                  long long rows, int C, float eps, int relu, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0, "layernorm: no rows");
   NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm: C must be 256, 512, 768 or 1024");
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  // <= 4096 blocks (16 waves per CU x 4 rounds): short waves would pay the per-block amax commit and the parameter loads per row
+  const long long nb = (rows + 3) / 4;
+  dim3 grid((unsigned)(nb > 4096 ? 4096 : nb)), block(256);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
-    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
-    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
-    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu); break;
+    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
   }
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -477,7 +508,7 @@ extern "C" long long npvp_layernorm_bwd_workspace_bytes(long long rows, int C) {
 
 extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mean,
                                   const float* rstd, float* dx, float* dw, float* db, long long rows, int C, int relu,
-                                  const float* dres, int accumulate, void* workspace, long long ws_bytes,
+                                  const float* dres, int accumulate, float* amax, void* workspace, long long ws_bytes,
                                   hipStream_t stream) {
   NPVP_CHECK_ARG(rows > 0, "layernorm_bwd: no rows");
   NPVP_CHECK_ARG(C % 256 == 0 && C >= 256 && C <= 1024, "layernorm_bwd: C must be 256, 512, 768 or 1024");
@@ -486,10 +517,10 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   float* part = (float*)workspace;
   dim3 grid(nb), block(256);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]
@@ -536,14 +567,14 @@ extern "C" int npvp_frame_stats(const float* x, const float* add, float* mean, f
 }
 
 extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y,
-                                float* mean, float* rstd, int N, int T, int per_frame, float eps, hipStream_t stream) {
+                                float* mean, float* rstd, int N, int T, int per_frame, float eps, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse: bad shape");
   const int frames = N * T;
   hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
   NPVP_CHECK_LAUNCH();
   const long long total4 = (long long)frames * per_frame / 4;
   hipLaunchKernelGGL(posfuse_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, x, add, beta, gamma,
-                     (const float*)mean, (const float*)rstd, y, T, per_frame, total4);
+                     (const float*)mean, (const float*)rstd, y, T, per_frame, total4, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -569,12 +600,12 @@ extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* ad
 extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const float* rstd, const float* w, const float* b,
                                     const float* res, float* out, int frames, int per_frame, float drop_p,
                                     unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
-                                    const unsigned long long* seed, hipStream_t stream) {
+                                    const unsigned long long* seed, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0, "frameln_act: bad shape");
   NPVP_CHECK_ARG((drop_p == 0.f && dp_p == 0.f) || seed, "frameln_act: dropout needs a device seed");
   FlnParams p;
   fill_fln(p, h, mean, rstd, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
-  hipLaunchKernelGGL(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out);
+  hipLaunchKernelGGL(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -595,7 +626,7 @@ extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_fr
 extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                                     const float* b, float* dh, float* dw, float* db, int frames, int per_frame,
                                     float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt,
-                                    int frames_per_sample, const unsigned long long* seed, int accumulate,
+                                    int frames_per_sample, const unsigned long long* seed, int accumulate, float* amax,
                                     void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0, "frameln_act_bwd: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
@@ -609,7 +640,7 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
-                     dout, (const float*)psum, dh, part, frames, fpc, FLN_PARTS);
+                     dout, (const float*)psum, dh, part, frames, fpc, FLN_PARTS, amax);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
@@ -624,8 +655,8 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
 // workspace: same layout and size as npvp_frameln_act_bwd (the first frames*2*FLN_PARTS floats stay unused).
 extern "C" int npvp_frameln_act_bwd_apply(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
                                           const float* b, const float* psum, int nparts, float* dh, float* dw, float* db,
-                                          int frames, int per_frame, int accumulate, void* workspace, long long ws_bytes,
-                                          hipStream_t stream) {
+                                          int frames, int per_frame, int accumulate, float* amax, void* workspace,
+                                          long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && per_frame % 4 == 0 && psum && nparts > 0, "frameln_act_bwd_apply: bad arguments");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
                  "frameln_act_bwd_apply: workspace too small");
@@ -635,7 +666,7 @@ extern "C" int npvp_frameln_act_bwd_apply(const float* dout, const float* h, con
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
   hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
-                     dout, psum, dh, part, frames, fpc, nparts);
+                     dout, psum, dh, part, frames, fpc, nparts, amax);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {

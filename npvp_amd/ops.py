@@ -18,11 +18,11 @@ def _ptr(t):
 
 
 class AmaxSlot:
-    """One amax slot (32 floats of device memory, see include/npvp_hip.h): the bound of |x| over a tensor that feeds a
-    precision-6 GEMM.  Slots are cut from zero-filled chunks (one torch.zeros per 4096 slots); a slot keeps its chunk alive,
-    so a saved-for-backward slot is valid until the node that holds it is freed."""
+    """One amax slot (2 KB of device memory: 32 words, 64 bytes apart, see include/npvp_hip.h): the bound of |x| over a tensor
+    that feeds a precision-6 GEMM.  Slots are cut from zero-filled chunks (one torch.zeros per 1024 slots); a slot keeps its
+    chunk alive, so a saved-for-backward slot is valid until the node that holds it is freed."""
     __slots__ = ("ptr", "chunk")
-    CHUNK = 4096
+    CHUNK, BYTES, FLOATS = 1024, 2048, 512
     _cur = None
     _next = 0
 
@@ -34,18 +34,18 @@ class AmaxSlot:
 
     def read(self):
         """host value (synchronises; tests and diagnostics only)"""
-        i = (self.ptr - self.chunk.data_ptr()) // 128
-        return float(self.chunk[i].max())
+        i = (self.ptr - self.chunk.data_ptr()) // self.BYTES
+        return float(self.chunk.view(-1, self.FLOATS)[i].max())
 
     @classmethod
     def new(cls, dev):
         ch = cls._cur
         if ch is None or cls._next >= cls.CHUNK or ch.device != dev:
-            ch = cls._cur = torch.zeros(cls.CHUNK, 32, dtype=torch.float32, device=dev)
+            ch = cls._cur = torch.zeros(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev)
             cls._next = 0
             if WgradStream.enabled:
                 ch.record_stream(WgradStream.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
-        s = cls(ch.data_ptr() + 128 * cls._next, ch)
+        s = cls(ch.data_ptr() + cls.BYTES * cls._next, ch)
         cls._next += 1
         return s
 
@@ -55,9 +55,10 @@ def amax_of(t, slot=None):
     the stand-alone reduction kernel (one read of t)"""
     if slot is not None:
         return slot
-    tag = getattr(t, "_npvp_amax", None)
-    if tag is not None and tag[1] == t._version:        # (an in-place update after the slot was filled voids it)
-        return tag[0]
+    for cand in (t, t._base):               # a view is bounded by the slot of the tensor it is a view of
+        tag = getattr(cand, "_npvp_amax", None) if cand is not None else None
+        if tag is not None and tag[1] == cand._version:     # (an in-place update after the slot was filled voids it)
+            return tag[0]
     s = AmaxSlot.new(t.device)
     t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1])
     if t2.stride(1) != 1:
@@ -287,7 +288,7 @@ class WeightPlanes:
             ent.fmt, ent.w = fmt, w.detach()
             if fmt == 6:
                 ent.planes = torch.empty(2, 2 * N * K, dtype=torch.float16, device=w.device)
-                ent.amax_t = torch.zeros(32, dtype=torch.float32, device=w.device)
+                ent.amax_t = torch.zeros(AmaxSlot.FLOATS, dtype=torch.float32, device=w.device)
                 ent.amax = AmaxSlot(ent.amax_t.data_ptr(), ent.amax_t)
             else:
                 ent.planes = torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
@@ -331,10 +332,10 @@ class WeightPlanes:
             for (fmt, dev), ents in groups.items():
                 amax_t = None
                 if fmt == 6:             # one contiguous slot table per device: zeroed by ONE memset in the batched call
-                    amax_t = torch.zeros(len(ents), 32, dtype=torch.float32, device=dev)
+                    amax_t = torch.zeros(len(ents), AmaxSlot.FLOATS, dtype=torch.float32, device=dev)
                     for i, ent in enumerate(ents):
                         ent.amax_t = amax_t
-                        ent.amax.ptr, ent.amax.chunk = amax_t.data_ptr() + 128 * i, amax_t
+                        ent.amax.ptr, ent.amax.chunk = amax_t.data_ptr() + AmaxSlot.BYTES * i, amax_t
                 rows = []
                 for ent in ents:
                     N, K = ent.w.shape
@@ -638,9 +639,10 @@ def colsum(x):
 
 def drop_apply(x2d, drop):
     out = torch.empty_like(x2d)
+    slot = _new_slot(x2d.device)
     check(lib().npvp_drop_apply(_ptr(x2d), _ptr(out), x2d.shape[0], x2d.shape[1], drop.p, drop.mode, drop.g1, drop.g2,
-                                _ptr(rng.seed_tensor(x2d.device)), drop.salt, _stream()), "npvp_drop_apply")
-    return out
+                                _ptr(rng.seed_tensor(x2d.device)), drop.salt, _ptr(slot), _stream()), "npvp_drop_apply")
+    return tag_amax(out, slot)
 
 
 def transpose(x):
@@ -707,8 +709,10 @@ class _LayerNorm(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        slot = _new_slot(x.device)
         check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, C, eps,
-                                       int(relu), _stream()), "npvp_layernorm_fwd")
+                                       int(relu), _ptr(slot), _stream()), "npvp_layernorm_fwd")
+        tag_amax(y, slot)
         ctx.save_for_backward(x2, w, b, mean, rstd)
         ctx.relu, ctx.shape = int(relu), x.shape
         ctx.sink = _ln_sink(w, b)
@@ -724,9 +728,11 @@ class _LayerNorm(torch.autograd.Function):
         sk = ctx.sink
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
         ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+        slot = _new_slot(x2.device)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
-                                   _ptr(db), rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(ws), wsn, _stream()),
+                                   _ptr(db), rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()),
               "npvp_layernorm_bwd")
+        tag_amax(dx, slot)
         if sk:
             _sunk_ln_reduce(sk, ws, rows, C)
             return dx.reshape(ctx.shape), None, None, None, None
@@ -791,8 +797,10 @@ class _LayerNormNchw(torch.autograd.Function):
         sk = ctx.sink
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
         ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+        slot = _new_slot(x2.device)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw), _ptr(db),
-                                   rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+                                   rows, C, ctx.relu, _p(0), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+        tag_amax(dx, slot)
         if sk:
             _sunk_ln_reduce(sk, ws, rows, C)
             return (dx.reshape(ctx.shape),) + (None,) * 8
@@ -822,8 +830,10 @@ class _LayerNormRes(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        slot = _new_slot(x.device)
         check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, C, eps, 0,
-                                       _stream()), "npvp_layernorm_fwd")
+                                       _ptr(slot), _stream()), "npvp_layernorm_fwd")
+        tag_amax(y, slot)
         ctx.save_for_backward(x2, w, b, mean, rstd)
         ctx.shape = x.shape
         ctx.sink = _ln_sink(w, b)
@@ -842,9 +852,11 @@ class _LayerNormRes(torch.autograd.Function):
         ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
         dy2 = _c(dy).reshape(rows, C)
         dr2 = None if dres is None else _c(dres).reshape(rows, C)
+        slot = _new_slot(x2.device)
         check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
-                                   _ptr(db), rows, C, 0, _ptr(dr2), _sink_mode(sk), _ptr(ws), wsn, _stream()),
+                                   _ptr(db), rows, C, 0, _ptr(dr2), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()),
               "npvp_layernorm_bwd")
+        tag_amax(dx, slot)
         if sk:
             _sunk_ln_reduce(sk, ws, rows, C)
             return dx.reshape(ctx.shape), None, None, None
@@ -870,8 +882,10 @@ class _PosFuse(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(F_, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        slot = _new_slot(x.device)
         check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add_c), _ptr(beta), _ptr(gamma_c), _ptr(y), _ptr(mean), _ptr(rstd), N, T,
-                                     PF, 1e-5, _stream()), "npvp_posfuse_fwd")
+                                     PF, 1e-5, _ptr(slot), _stream()), "npvp_posfuse_fwd")
+        tag_amax(y, slot)
         ctx.save_for_backward(x, add_c, gamma_c, mean, rstd)
         ctx.N, ctx.T, ctx.PF = N, T, PF
         ctx.beta_shape = beta.shape
@@ -1007,7 +1021,8 @@ class _FFN(torch.autograd.Function):
         R, Fh = xn2.shape[0], w1.shape[0]
         d2, d3 = Drop(p), Drop(p)
         h = torch.empty(R, Fh, dtype=torch.float32, device=xn.device)
-        a = linear_fwd(xn2, w1, b1, act=1, aux_out=h, drop=d2)
+        a_slot = _new_slot(xn.device)
+        a = tag_amax(linear_fwd(xn2, w1, b1, act=1, aux_out=h, drop=d2, y_amax=a_slot), a_slot)
         y = linear_fwd(a, w2, b2, residual=x2, drop=d3)
         ctx.save_for_backward(xn2, h, a, w1, w2)
         ctx.d2, ctx.d3, ctx.shape = d2, d3, x.shape
@@ -1055,18 +1070,29 @@ def _attn_fwd(q, k, v, o, cfg):
         L_, S_ = (cfg.ws * cfg.ws, cfg.ws * cfg.ws) if cfg.mode == 0 else (cfg.Tq, cfg.Tk)
         groups = cfg.dim0 * (cfg.P // (cfg.ws * cfg.ws)) if cfg.mode == 0 else cfg.dim0 * cfg.P
         DropRecorder.note(cfg.drop, "elem", groups * cfg.heads * L_ * S_)
+    slot = _new_slot(q.device)
     check(lib().npvp_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
                               cfg.mode, cfg.dim0, cfg.P, cfg.W, cfg.ws, cfg.Tq, cfg.Tk, cfg.heads, hd, cfg.mask_mode,
-                              cfg.drop.p, _ptr(seed), cfg.drop.salt, _stream()), "npvp_attn_fwd")
+                              cfg.drop.p, _ptr(seed), cfg.drop.salt, _ptr(slot), _stream()), "npvp_attn_fwd")
+    tag_amax(o, slot)
 
 
-def _attn_bwd(q, k, v, go, dq, dk, dv, cfg):
+def _attn_bwd(q, k, v, go, dq, dk, dv, cfg, packed=None):
+    """packed: the [R, 2C] tensor dq and dk are the halves of (one amax slot for both, tagged on it)"""
     hd = go.shape[1] // cfg.heads
     seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    sq = _new_slot(q.device)
+    sk = sq if packed is not None else _new_slot(q.device)
+    sv = _new_slot(q.device)
     check(lib().npvp_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(go), go.stride(0),
                               _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), cfg.mode, cfg.dim0,
                               cfg.P, cfg.W, cfg.ws, cfg.Tq, cfg.Tk, cfg.heads, hd, cfg.mask_mode, cfg.drop.p, _ptr(seed),
-                              cfg.drop.salt, _stream()), "npvp_attn_bwd")
+                              cfg.drop.salt, _ptr(sq), _ptr(sk), _ptr(sv), _stream()), "npvp_attn_bwd")
+    if packed is not None:
+        tag_amax(packed, sq)
+    else:
+        tag_amax(dq, sq); tag_amax(dk, sk)
+    tag_amax(dv, sv)
 
 
 class _AttnPacked(torch.autograd.Function):
@@ -1088,7 +1114,7 @@ class _AttnPacked(torch.autograd.Function):
         C = v.shape[1]
         go = _c(go)
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
-        _attn_bwd(qk[:, :C], qk[:, C:], v, go, dqk[:, :C], dqk[:, C:], dv, ctx.cfg)
+        _attn_bwd(qk[:, :C], qk[:, C:], v, go, dqk[:, :C], dqk[:, C:], dv, ctx.cfg, packed=dqk)
         return dqk, dv, None
 
 
@@ -1141,9 +1167,11 @@ class _FrameLnAct(torch.autograd.Function):
         DropRecorder.note(dp, "group", frames // max(1, frames_per_sample))
         out = torch.empty_like(h)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        slot = _new_slot(h.device)
         check(L.npvp_frameln_act_fwd(_ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(res_c), _ptr(out), frames,
-                                     PF, d.p, d.salt, dp.p, dp.salt, frames_per_sample, _ptr(seed), _stream()),
+                                     PF, d.p, d.salt, dp.p, dp.salt, frames_per_sample, _ptr(seed), _ptr(slot), _stream()),
               "npvp_frameln_act_fwd")
+        tag_amax(out, slot)
         ctx.save_for_backward(h, mean, rstd, w_cl, b_cl)
         ctx.cfg = (frames, PF, d, dp, frames_per_sample, res is not None)
         ctx.sink = _ln_sink(w_cl, b_cl)
@@ -1160,9 +1188,11 @@ class _FrameLnAct(torch.autograd.Function):
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w_cl), torch.empty_like(b_cl))
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), h.device)
         seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        slot = _new_slot(h.device)
         check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(dh), _ptr(dw),
-                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), _sink_mode(sk), _ptr(ws),
-                                     wsn, _stream()), "npvp_frameln_act_bwd")
+                                     _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), _sink_mode(sk), _ptr(slot),
+                                     _ptr(ws), wsn, _stream()), "npvp_frameln_act_bwd")
+        tag_amax(dh, slot)
         if sk:
             if WgradStream.enabled:
                 WgradStream.run(lambda: check(L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1,
@@ -1265,8 +1295,10 @@ class _MlpDwbn(torch.autograd.Function):
         DropRecorder.note(d2, "elem", R * hid)
         seed = rng.seed_tensor(dev) if (d2.on or dp.on) else None
         a2 = torch.empty(R, hid, dtype=f32, device=dev)
+        a2_slot = _new_slot(dev)
         check(L.npvp_frameln_act_fwd(_ptr(h2), _ptr(stats[2]), _ptr(stats[3]), _ptr(n2w), _ptr(n2b), _p(0), _ptr(a2), frames, PFh,
-                                     d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), st), "npvp_frameln_act_fwd")
+                                     d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), _ptr(a2_slot), st), "npvp_frameln_act_fwd")
+        tag_amax(a2, a2_slot)
         # fc2 (+ statistics), norm3 + GELU + dropout + residual + drop-path
         h3 = torch.empty(R, Co, dtype=f32, device=dev)
         part3 = torch.empty(frames * (Co // 64) * 2, dtype=f32, device=dev)
@@ -1278,29 +1310,31 @@ class _MlpDwbn(torch.autograd.Function):
         DropRecorder.note(dp, "group", frames // max(1, T))
         out = torch.empty(R, Co, dtype=f32, device=dev)
         check(L.npvp_frameln_act_fwd(_ptr(h3), _ptr(stats[4]), _ptr(stats[5]), _ptr(n3w), _ptr(n3b), _ptr(res), _ptr(out), frames,
-                                     PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed), st), "npvp_frameln_act_fwd")
+                                     PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed), _p(0), st), "npvp_frameln_act_fwd")
         ctx.save_for_backward(x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b)
         ctx.cfg = (frames, T, d2, d3, dp, res is not None, b1 is not None, b2 is not None)
         ctx.sinks = (_wb_sink(w1, b1), _wb_sink(w2, b2), _ln_sink(n1w, n1b), _ln_sink(n2w, n2b), _ln_sink(n3w, n3b))
         return out
 
     @staticmethod
-    def _fln_bwd(L, dout, h, mean, rstd, w, b, frames, PF, d, dp, T, sk, psum=None, nparts=0):
+    def _fln_bwd(L, dout, h, mean, rstd, w, b, frames, PF, d, dp, T, sk, psum=None, nparts=0, want_amax=True):
         """frame-LN backward (with its own statistics pass, or with the producer's `psum`); parameter gradients into the
-        sink (partials reduced on the gradient stream) or returned"""
+        sink (partials reduced on the gradient stream) or returned; want_amax: dh feeds a GEMM (gets an amax slot)"""
         dev = h.device
         dh = torch.empty_like(h)
+        slot = _new_slot(dev, want_amax)
+        tag_amax(dh, slot)
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), dev)
         mode = _sink_mode(sk)
         if psum is None:
             seed = rng.seed_tensor(dev) if (d.on or dp.on) else None
             check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(dh), _ptr(dw), _ptr(db),
-                                         frames, PF, d.p, d.salt, dp.p, dp.salt, T, _ptr(seed), mode, _ptr(ws), wsn, _stream()),
-                  "npvp_frameln_act_bwd")
+                                         frames, PF, d.p, d.salt, dp.p, dp.salt, T, _ptr(seed), mode, _ptr(slot), _ptr(ws), wsn,
+                                         _stream()), "npvp_frameln_act_bwd")
         else:
             check(L.npvp_frameln_act_bwd_apply(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(psum), nparts,
-                                               _ptr(dh), _ptr(dw), _ptr(db), frames, PF, mode, _ptr(ws), wsn, _stream()),
+                                               _ptr(dh), _ptr(dw), _ptr(db), frames, PF, mode, _ptr(slot), _ptr(ws), wsn, _stream()),
                   "npvp_frameln_act_bwd_apply")
         if sk:
             if WgradStream.enabled:
@@ -1333,7 +1367,8 @@ class _MlpDwbn(torch.autograd.Function):
         F_ = _MlpDwbn
         dh3, gn3w, gn3b = F_._fln_bwd(L, dout, h3, stats[4], stats[5], n3w, n3b, frames, 64 * Co, d3, dp, T, s_n3)
         da2, gw2, gb2 = F_._lin_bwd(dh3, a2, w2, s_fc2, has_b2)
-        dh2, gn2w, gn2b = F_._fln_bwd(L, da2, h2, stats[2], stats[3], n2w, n2b, frames, 64 * hid, d2, NO_DROP, 1, s_n2)
+        dh2, gn2w, gn2b = F_._fln_bwd(L, da2, h2, stats[2], stats[3], n2w, n2b, frames, 64 * hid, d2, NO_DROP, 1, s_n2,
+                                      want_amax=False)
         del da2
         # fused middle backward: da1, depthwise weight / bias gradient (a1 recomputed from h1), norm1's backward statistics
         da1 = torch.empty_like(h1)
@@ -1379,9 +1414,10 @@ def _raw_ln_fwd(x2, w, b, eps):
     rows, C = x2.shape
     y = torch.empty_like(x2)
     st = torch.empty(2, rows, dtype=torch.float32, device=x2.device)
-    check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(st[0]), _ptr(st[1]), rows, C, eps, 0, _stream()),
-          "npvp_layernorm_fwd")
-    return y, st
+    slot = _new_slot(x2.device)
+    check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(st[0]), _ptr(st[1]), rows, C, eps, 0, _ptr(slot),
+                                   _stream()), "npvp_layernorm_fwd")
+    return tag_amax(y, slot), st
 
 
 def _raw_ln_bwd(dy2, x2, w, b, st, dres, sk):
@@ -1391,8 +1427,10 @@ def _raw_ln_bwd(dy2, x2, w, b, st, dres, sk):
     dx = torch.empty_like(x2)
     dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
     ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
+    slot = _new_slot(x2.device)
     check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(st[0]), _ptr(st[1]), _ptr(dx), _ptr(dw), _ptr(db), rows, C,
-                               0, _ptr(dres), _sink_mode(sk), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+                               0, _ptr(dres), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+    tag_amax(dx, slot)
     if sk:
         _sunk_ln_reduce(sk, ws, rows, C)
         return dx, None, None
@@ -1403,9 +1441,10 @@ def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
     PF = x.numel() // (N * T)
     y = torch.empty_like(x)
     st = torch.empty(2, N * T, dtype=torch.float32, device=x.device)
+    slot = _new_slot(x.device)
     check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add), _ptr(beta), _ptr(gamma), _ptr(y), _ptr(st[0]), _ptr(st[1]), N, T, PF, 1e-5,
-                                 _stream()), "npvp_posfuse_fwd")
-    return y, st
+                                 _ptr(slot), _stream()), "npvp_posfuse_fwd")
+    return tag_amax(y, slot), st
 
 
 def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
@@ -1470,7 +1509,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
         do = linear_dgrad(dz, wo)
         gwo, gbo = _lin_grads(dz, o, wo, bo, s_o)
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
-        _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg)
+        _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg, packed=dqk)
         dfused = linear_dgrad(dqk, wqk)
         gwqk, gbqk = _lin_grads(dqk, fused, wqk, bqk, s_qk)
         du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dfused, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
@@ -1545,7 +1584,8 @@ class _FfnSublayer(torch.autograd.Function):
         R, Fh = x2.shape[0], w1.shape[0]
         d2, d3 = Drop(p), Drop(p)
         h = torch.empty(R, Fh, dtype=torch.float32, device=x.device)
-        a = linear_fwd(xn, w1, b1, act=1, aux_out=h, drop=d2)
+        a_slot = _new_slot(x.device)
+        a = tag_amax(linear_fwd(xn, w1, b1, act=1, aux_out=h, drop=d2, y_amax=a_slot), a_slot)
         y = linear_fwd(a, w2, b2, residual=x2, drop=d3)
         ctx.save_for_backward(x2, xn, lst, h, a, lw, lb, w1, b1, w2, b2)
         ctx.cfg = (d2, d3, x.shape)
@@ -1560,7 +1600,8 @@ class _FfnSublayer(torch.autograd.Function):
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
         dz2 = drop_apply(dy2, d3) if d3.on else dy2
-        dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2)
+        dh_slot = _new_slot(dy2.device)
+        dh = tag_amax(linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2, dx_amax=dh_slot), dh_slot)
         gw2, gb2 = _lin_grads(dz2, a, w2, b2, s2)
         dxn = linear_dgrad(dh, w1)
         gw1, gb1 = _lin_grads(dh, xn, w1, b1, s1)

@@ -42,6 +42,7 @@ class FlatBuffers:
                     tail_begin = off
                 self.flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
+                ops.WeightPlanes.forget(p)               # planes cached for the storage p just left mirror dead memory
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 self.views.append(p.grad)
                 p.__dict__["_npvp_flat"] = True          # ops.GradSink may accumulate into p.grad in place

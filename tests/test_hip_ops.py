@@ -397,3 +397,117 @@ def test_layernorm_writes_nchw(K, C, relu):
     close(yg, y2, tol=1e-6, what="y vs two-kernel route")
     for a, b_, n in zip(got, got2, ["dx", "dw", "db"]):
         close(a, b_, tol=2e-6, what=n + " vs two-kernel route")
+
+
+# ------------------------------------------------------------------------------- f16x3: amax slots, operand ranges, planes
+def _f16(K):
+    if K.GEMM_PRECISION != 6:
+        pytest.skip("amax slots belong to the f16x3 mode")
+
+
+def test_amax_slots_are_exact(K):
+    """Every producer's amax slot holds exactly max|x| of the tensor it wrote (an integer atomic max of float bit patterns),
+    views inherit their base's slot, and an in-place update voids a slot."""
+    _f16(K)
+    ops = K
+    torch.manual_seed(3)
+    dev = torch.device(DEV)
+
+    def slot_of(t):
+        tag = getattr(t, "_npvp_amax", None) or getattr(t._base, "_npvp_amax", None)
+        assert tag is not None, "producer did not tag its output"
+        return tag[0].read()
+
+    x = torch.randn(1000, 512, device=dev) * 3.0
+    w = torch.rand(512, device=dev) + 0.5; b = torch.randn(512, device=dev)
+    y = ops.layernorm(x, w, b)
+    assert slot_of(y) == float(y.abs().max())
+    y2, st = ops._raw_ln_fwd(x, w, b, 1e-5)
+    assert slot_of(y2) == float(y2.abs().max())
+    # stand-alone reduction, strided rows, view lookup
+    big = torch.randn(640, 1024, device=dev) * 1e-6
+    s = ops.amax_of(big[:, :512])
+    assert s.read() == float(big[:, :512].abs().max())
+    s2 = ops.amax_of(big)
+    assert ops.amax_of(big.view(-1, 1024)[5:]) is s2, "a view is bounded by its base's slot"
+    big.mul_(2.0)
+    assert ops.amax_of(big) is not s2, "an in-place update must void the slot"
+    # drop_apply, posfuse, frame-LN, GEMM epilogue, attention
+    d = ops.drop_apply(x, ops.Drop(0.3))
+    assert slot_of(d) == float(d.abs().max())
+    xf = torch.randn(6, 64 * 512, device=dev)
+    beta = torch.randn(3, 64 * 512, device=dev)
+    pf = ops.posfuse(xf, None, beta, None, 2, 3)
+    assert slot_of(pf) == float(pf.abs().max())
+    h = torch.randn(320, 2048, device=dev)
+    a = ops.frameln_act(h, torch.rand(64 * 2048, device=dev) + 0.5, torch.randn(64 * 2048, device=dev), None, 5, p_drop=0.1)
+    assert slot_of(a) == float(a.abs().max())
+    wl = torch.nn.Parameter(torch.randn(1024, 512, device=dev) / 22.0)
+    sl = ops.AmaxSlot.new(dev)
+    yl = ops.linear_fwd(x[:768], wl, None, act=1, y_amax=sl)
+    assert sl.read() == float(yl.abs().max())
+    qk = torch.randn(4 * 64, 1024, device=dev); v = torch.randn(4 * 64, 512, device=dev)
+    o = torch.empty_like(v)
+    cfg = ops.AttnCfg(0, 4, 64, 8, 4, 0, 0, 8, 0, 0.0)
+    ops._attn_fwd(qk[:, :512], qk[:, 512:], v, o, cfg)
+    assert slot_of(o) == float(o.abs().max())
+    go = torch.randn_like(o); dqk = torch.empty_like(qk); dv = torch.empty_like(v)
+    ops._attn_bwd(qk[:, :512], qk[:, 512:], v, go, dqk[:, :512], dqk[:, 512:], dv, cfg, packed=dqk)
+    assert slot_of(dqk) == float(dqk.abs().max()) and slot_of(dv) == float(dv.abs().max())
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-8, 3e4, 1e-30])
+def test_f16x3_operand_ranges(K, scale):
+    """fp32-grade results wherever the operands live in fp32's range: gradient-sized (1e-8), large (3e4: above fp16's
+    maximum once multiplied) and tiny operands, heavy-tailed rows; bar 1e-6 rel-L2 against fp64 (torch's fp32 GEMM: ~3e-7 ..
+    6e-7 on these shapes)."""
+    _f16(K)
+    R = 4096
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for N, K_ in ((512, 512), (2048, 512), (512, 2048)):
+        w = torch.nn.Parameter(torch.randn(N, K_, device=DEV, generator=g) / math.sqrt(K_))
+        x = torch.randn(R, K_, device=DEV, generator=g) * scale
+        dy = torch.randn(R, N, device=DEV, generator=g) * torch.exp(1.5 * torch.randn(R, N, device=DEV, generator=g)) * scale
+        close(K.linear_fwd(x, w, None), (x.double() @ w.double().T).float(), tol=1e-6, what=f"fwd {N}x{K_} scale {scale}")
+        close(K.linear_dgrad(dy, w), (dy.double() @ w.double()).float(), tol=1e-6, what=f"dgrad {N}x{K_} scale {scale}")
+        close(K.linear_wgrad(dy, x), (dy.double().T @ x.double()).float(), tol=1e-6, what=f"wgrad {N}x{K_} scale {scale}")
+
+
+def test_f16x3_nonfinite_operands_stay_nonfinite(K):
+    """an inf / NaN in an operand must come out as inf / NaN (as in fp32), never as a finite number"""
+    _f16(K)
+    w = torch.nn.Parameter(torch.randn(512, 512, device=DEV) / 22.0)
+    for bad in (float("inf"), float("nan")):
+        x = torch.randn(1024, 512, device=DEV)
+        x[7, 3] = bad
+        y = K.linear_fwd(x, w, None)
+        assert not bool(torch.isfinite(y[7]).all())
+        assert bool(torch.isfinite(y[8:]).all()) or bad != bad      # (a NaN amax turns the scale to 1: other rows stay finite)
+
+
+def test_weight_planes_follow_repointed_storage(K):
+    """FlatBuffers re-points p.data; planes cached for the old storage must not be used (or refreshed) for the new
+    one.  Forward -> optimiser #1 steps -> optimiser #2 (new flat buffers on the same module) steps with lr > 0 -> forward
+    must see the weights optimiser #2 wrote."""
+    if K.GEMM_PRECISION not in (4, 6):
+        pytest.skip("planes exist in the split-precision modes")
+    import npvp_amd
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 512).to(DEV)
+    x = torch.randn(1024, 512, device=DEV)
+
+    def fwd():
+        return K.linear(x, lin.weight, lin.bias)
+
+    def ref():
+        return (x.double() @ lin.weight.detach().double().T + lin.bias.detach().double()).float()
+
+    close(fwd(), ref(), tol=1e-5, what="before any optimiser")
+    for round_ in range(2):
+        opt = npvp_amd.FlatAdamW(lin, lr=1e-2)
+        for _ in range(2):
+            opt.zero_grad()
+            fwd().square().mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        close(fwd(), ref(), tol=1e-5, what=f"after optimiser #{round_ + 1}")
