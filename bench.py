@@ -9,14 +9,18 @@ A "step" is one optimisation step of the predictor-only flavour of the reference
 training_step_no_gan: frozen-encoder feature grids in HBM -> predictor fwd (S: context +
 target encoder passes, prior/posterior, decoder) -> feature-L1 + KL -> backward -> decoder-only
 grad-norm clip -> AdamW -> cosine-warm-restart lr, with the reference's dropout 0.1 / drop-path 0.1
-active and every GEMM (forward, dgrad AND weight gradient) in the fp32-grade six-term split.
+active and every GEMM (forward, dgrad AND weight gradient) in fp32-grade split arithmetic (default f16x3:
+two fp16 terms per operand, three MFMAs per product, operands scaled by their amax; GEMMs the fp16 kernels
+do not take - fewer than 128 rows, no weight planes - run the three-term bf16 split).
 
 PRIMARY workload (the `value` line) = BASELINE.json configs[2], the largest single-GPU configuration:
-BAIR 64x64 NPVP-D, 64 clips per GPU, To=2, Tp=28 (T=30).  At N > 1 it is weak scaling: every rank gets
+BAIR 64x64 NPVP-D, 64 clips per GPU, To=2, Tp=28 (T=30).  At N > 1 it is WEAK scaling: every rank gets
 its own 64 clips, gradients are all-reduced over RCCL.  SECONDARY workloads (shorter runs, reported under
-`secondary`): north_star's "BAIR B=64 T=20" target line (c2p) and BASELINE configs[1] (c1) at N = 1, and the
-BASELINE configuration named for that GPU count - Cityscapes B=32 on 4 GPUs (c3), KITTI B=64 on 8 GPUs (c4),
-8 clips per GPU each - at N = 4 / 8.
+`secondary`): at N = 1 every other BASELINE configuration - north_star's "BAIR B=64 T=20" target line (c2p),
+configs[1] (c1), configs[0] (c0), the per-GPU shards of configs[3] / configs[4] (c3s / c4s: 8 clips of
+128x128 Cityscapes / KITTI, the N = 1 denominators of the N = 4 / 8 lines) and the FULL step from pixels
+through the frozen autoencoder on a 64x64 (full64 = c1) and a 128x128 (full128 = the c4 shard) workload;
+at N = 4 / 8 the BASELINE configuration named for that GPU count (c3 / c4, 8 clips per GPU).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the GEMM layout - forward or dgrad -
 with the largest share of the timed region, timed live with HIP event pairs around every launch on the
@@ -115,7 +119,7 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def run_workload(key, steps, warmup, args, rank, world, dev, probe):
+def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None):
     """Build the workload's model / optimiser / synthetic batch, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict"""
     import npvp_amd
@@ -140,7 +144,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe):
     past = torch.relu(torch.randn(B, To, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
     fut = torch.relu(torch.randn(B, Tp, 512, 8, 8, generator=g) * 0.1 + 0.05).to(dev)
     iters_per_epoch = 100
-    full = args.flavour == "full"
+    full = (flavour or args.flavour) == "full"
     if full:
         D = cfg["Dataset"]
         enc, dec = npvp_amd.build_frozen_autoencoder(cfg["AE"], D["img_channels"])
@@ -227,22 +231,32 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe):
             kname = ops.GemmProbe.KERNELS[kid]
             ach = pfl / (pms * 1e-3) / 1e12
             traffic = None
-            tj = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{key}.json")
+            tj = os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{key}.json")
             if os.path.exists(tj) and not full:
                 # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command (separate
-                # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r02_hbm_traffic_<key>.*
+                # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r03_hbm_traffic_<key>.*
                 ent = json.load(open(tj)).get("pooled", {}).get(kname)
                 traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
-            roof = {"bound": "mfma", "kernel": f"{kname} (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into "
-                                              "three bf16 terms, pre-split weight planes by LDS-DMA)" if kid == 2 else kname,
+            f16 = kid in (5, 6, 7)
+            mfmas = 1 if kid == 0 else (3 if f16 else 6)
+            desc = {5: " (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into two amax-scaled fp16 terms, "
+                       "scaled fp16 weight planes by LDS-DMA)",
+                    7: " (forward + dgrad launches; the same kernel on 128x128 tiles)",
+                    2: " (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into three bf16 terms, pre-split "
+                       "weight planes by LDS-DMA)"}.get(kid, "")
+            roof = {"bound": "mfma", "kernel": kname + desc,
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "mfma_pipe_busy_frac": round(6 * ach / MFMA_PEAK_TFLOPS, 4),
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "mfma_per_product": mfmas,
+                    "mfma_pipe_busy_frac": round(mfmas * ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
                     "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel": groups,
                     "note": "achieved = ALGORITHMIC fp32-equivalent flops (2MNK) / event-pair time over every forward and dgrad "
-                            "launch of this kernel in the timed region; each product costs 6 v_mfma_f32_32x32x16_bf16 (three-term "
-                            "bf16 split, fp32-grade), so frac <= 1/6 and mfma_pipe_busy_frac = 6 x frac is the share of the dense "
-                            "bf16 MFMA peak the matrix pipe delivers",
+                            f"launch of this kernel in the timed region; each product costs {mfmas} matrix instructions "
+                            + ("(v_mfma_f32_32x32x16_f16 on two amax-scaled fp16 terms per operand: fp32-grade)" if f16 else
+                               "(v_mfma_f32_32x32x16_bf16 on three bf16 terms per operand: fp32-grade)" if mfmas == 6 else "(fp32-input MFMA)")
+                            + f", so frac <= 1/{mfmas} of the dense 16-bit MFMA peak by construction and mfma_pipe_busy_frac = "
+                            f"{mfmas} x frac is the share of that peak the matrix pipe delivers (the sustained f16 MFMA rate of "
+                            "this part on non-trivial operands is ~1.5-1.66 PFLOP/s: tools/f16_probe.hip)",
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
@@ -294,22 +308,34 @@ def main():
 
     secondary = {}
     if not args.no_secondary and args.workload == "c2" and not args.graph and args.flavour == "predictor":
-        keys = {1: ["c2p", "c1"], 4: ["c3"], 8: ["c4"]}.get(world, [])
-        for k in keys:
-            r = run_workload(k, max(3, args.steps // 2), min(3, args.warmup) or 1, args, rank, world, dev, probe=False)
-            secondary[k] = {"workload": r["name"], "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"],
-                            "value": round(r["frames_per_s"], 2), "unit": "frames/s", "ms_per_step": round(r["ms"], 3),
-                            "steps": r["steps"], "warmup": r["warmup"],
-                            "whole_step_tflops_per_gpu": round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 2),
-                            "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)}
+        # (key in the JSON, workload, flavour): every BASELINE configuration the primary line does not cover
+        plan = {1: [("c2p", "c2p", None), ("c1", "c1", None), ("c0", "c0", None), ("c3s", "c3", None), ("c4s", "c4", None),
+                    ("full64", "c1", "full"), ("full128", "c4", "full")],
+                2: [("c4s", "c4", None)], 4: [("c3", "c3", None)], 8: [("c4", "c4", None)]}.get(world, [])
+        for name, k, flav in plan:
+            r = run_workload(k, max(4, args.steps // 2), min(3, args.warmup) or 1, args, rank, world, dev, probe=False, flavour=flav)
+            secondary[name] = {"workload": r["name"] + (" - FULL step from pixels through the frozen autoencoder" if flav == "full" else
+                                                        " - predictor-only step"),
+                               "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"],
+                               "value": round(r["frames_per_s"], 2), "unit": "frames/s", "ms_per_step": round(r["ms"], 3),
+                               "steps": r["steps"], "warmup": r["warmup"],
+                               "whole_step_tflops_per_gpu": round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 2),
+                               "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)}
 
     if rank == 0:
         r = main_res
         wg = "" if ops.WGRAD_PRECISION is None else "; weight-gradient GEMMs two-term (NPVP_WGRAD=bf16x3 opt-in)"
         res = {"metric": "predictor train frames/sec", "value": round(r["frames_per_s"], 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms"], 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.gemm == "f32" else f"f32 (three-term bf16 split on the bf16 MFMA, fp32 accumulate: fp32-grade products{wg})",
+               "higher_is_better": True, "scaling": "weak",
+               "scaling_note": "the primary line is WEAK scaling (64 clips per GPU at every N); the BASELINE multi-GPU configurations "
+                               "(8 clips per GPU) are the c3 / c4 secondaries at N = 4 / 8, with their N = 1 denominators c3s / c4s here",
+               "vs_baseline": None,
+               "dtype": {"f32": "f32 (fp32-input MFMA)",
+                         "bf16x6": f"f32 (three-term bf16 split on the bf16 MFMA, fp32 accumulate: fp32-grade products{wg})",
+                         "f16x3": "f32 (two-term fp16 split on the f16 MFMA, operands scaled by their amax, fp32 accumulate: fp32-grade "
+                                  "products, 1.8e-7..5e-7 rel-L2 against fp64 on the path's GEMM shapes; GEMMs without weight planes / "
+                                  "under 128 rows: three-term bf16 split)"}[args.gemm],
                "data": "synthetic",
                "config": {"workload": f"{r['name']} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
                                                          else "FULL train step from pixels (frozen AE: MIOpen convolutions with folded BatchNorm + csrc/ae.hip epilogues)")

@@ -20,6 +20,12 @@
 // K-step instead of 48 and ~60.
 #include "gemm.h"
 
+// measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_H_ABL=n on the GPU box; results INVALID): 1 = no C stores, 2 = no A global
+// loads inside the K loop, 4 = no B LDS-DMA inside the K loop, 8 = no A split / ds_write inside the K loop
+#ifndef NPVP_H_ABL
+#define NPVP_H_ABL 0
+#endif
+
 namespace npvp {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -84,9 +90,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const int fa_off = h * KGS_A + (wm * TM * 32 + r) * 16;
   const int fb_off = A_BYTES + h * KGS_B + (wn * TN * 32 + r) * 16;
 
-  f32x4 ra0, ra1;
-#define NPVP_H_ALOAD(KT)                                                                 \
-  { const int k_ = min((KT), nk - 1) << 4; ra0 = *reinterpret_cast<const f32x4*>(a_src0 + k_); ra1 = *reinterpret_cast<const f32x4*>(a_src1 + k_); }
+  // A tiles travel global -> registers -> (split) -> LDS planes, TWO tiles ahead in two register sets (ea / eb for the even /
+  // odd step of the unrolled pair).  The loads are inline asm with hand-counted waits: beside an outstanding LDS-DMA hipcc
+  // waits vmcnt(0) at the first use of any loaded register, which put the latency of the loads a step had just issued
+  // in front of every barrier.  VMEM issue order per step: 4 (CPW) LDS-DMA pieces of B tile kt+1, then 2 loads of A tile
+  // kt+3; "vmcnt(2)" at the step's end therefore waits for everything but those 2 loads - B kt+1 (one step of latency
+  // budget) and A kt+2 (a step and a half) have landed, and the registers consumed in the next step are valid.
+  f32x4 ea0, ea1, eb0, eb1;
+#define NPVP_H_ALOAD(R0, R1, KT)                                                                           \
+  { const int k_ = min((KT), nk - 1) << 4;                                                                 \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R0) : "v"(a_src0 + k_) : "memory");              \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R1) : "v"(a_src1 + k_) : "memory"); }
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
   { f16x4 hi_, lo_; split_f16((V) * sa, hi_, lo_);                                       \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
@@ -96,21 +110,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     _Pragma("unroll") for (int i_ = 0; i_ < CPW; ++i_)                                   \
       if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK)                                   \
         __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i_] + ko_), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
+  static_assert(NCHUNK % NW == 0, "the hand-counted waits assume CPW LDS-DMA pieces per wave and step");
 
+  // prologue: tile 0 -> stage 0 (B by DMA, A through the registers), A tiles 1 and 2 -> register sets
   NPVP_H_BLOAD(lds, 0)
-  NPVP_H_ALOAD(0)
-  NPVP_H_ASTORE(lds, ra0, 0)
-  NPVP_H_ASTORE(lds, ra1, (BM / 2) * 16)
-  NPVP_H_ALOAD(1)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  NPVP_H_ALOAD(ea0, ea1, 0)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1) :: "memory");
+  NPVP_H_ASTORE(lds, ea0, 0)
+  NPVP_H_ASTORE(lds, ea1, (BM / 2) * 16)
+  NPVP_H_ALOAD(ea0, ea1, 1)
+  NPVP_H_ALOAD(eb0, eb1, 2)
+  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(ea0), "+v"(ea1) :: "memory");
   __builtin_amdgcn_s_barrier();
 
-#define NPVP_H_STEP(KT, CUR, NXT)                                                                          \
+  // one K-step: MFMAs of tile KT on stage CUR; B tile KT+1 is DMA'd into NXT; A tile KT+1 (register set R, loaded two
+  // steps ago) is split and written to NXT, then R is reloaded with A tile KT+3.  RN = the set the NEXT step consumes: the
+  // step's closing wait is tied to it so that nothing that reads it can be scheduled above the wait.
+#define NPVP_H_STEP(KT, CUR, NXT, R0, R1, RN0, RN1)                                                        \
   {                                                                                                        \
     const char* st_ = lds + (CUR) * STAGE;                                                                 \
     char* nx_ = lds + (NXT) * STAGE;                                                                       \
-    asm volatile("" : "+v"(ra0), "+v"(ra1));                                                               \
-    NPVP_H_BLOAD(nx_, (KT) + 1)                                                                            \
+    if (!(NPVP_H_ABL & 4)) NPVP_H_BLOAD(nx_, (KT) + 1)                                                     \
     f16x8 fb_[2][TN];                                                                                      \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                    \
@@ -119,23 +139,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
       f16x8 fa_[2];                                                                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
         fa_[s_] = *reinterpret_cast<const f16x8*>(st_ + fa_off + s_ * A_PLANE + i_ * 512);                 \
-      if (i_ == 0) NPVP_H_ASTORE(nx_, ra0, 0)                                                              \
-      if (i_ == 1) { NPVP_H_ASTORE(nx_, ra1, (BM / 2) * 16) NPVP_H_ALOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); } \
+      if (i_ == 0 && !(NPVP_H_ABL & 8)) { NPVP_H_ASTORE(nx_, R0, 0) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) } \
+      if (i_ == 1 && !(NPVP_H_ABL & 2)) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                 \
       /* smallest terms first */                                                                           \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
     }                                                                                                      \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    __builtin_amdgcn_sched_barrier(0);       /* every MFMA of the step is issued before the wave parks at the wait */ \
+    if (NPVP_H_ABL & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");  \
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");                 \
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
-    NPVP_H_STEP(kt, 0, 1)
-    NPVP_H_STEP(kt + 1, 1, 0)
+    NPVP_H_STEP(kt, 0, 1, ea0, ea1, eb0, eb1)
+    NPVP_H_STEP(kt + 1, 1, 0, eb0, eb1, ea0, ea1)
   }
-  if (kt < nk) NPVP_H_STEP(kt, 0, 1)
+  if (kt < nk) NPVP_H_STEP(kt, 0, 1, ea0, ea1, eb0, eb1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the clamped loads past the last tile)
 #undef NPVP_H_STEP
 #undef NPVP_H_BLOAD
 #undef NPVP_H_ASTORE
@@ -152,6 +175,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
 
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (NPVP_H_ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    return;
+  }
+#endif
   if constexpr (ROWSTATS) {
     static_assert(!ROWSTATS || (TN % 2 == 0 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
 #pragma unroll
@@ -271,7 +303,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[1], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[0], acc[i_][j_], 0, 0, 0); \
     }                                                                                                        \
-    __syncthreads();                                                                                         \
+    /* the barrier orders LDS only: __syncthreads() would also wait (vmcnt(0)) for the loads of tile KT+2 issued above */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    __builtin_amdgcn_s_barrier();                                                                            \
   }
 
   int kt = 0;
