@@ -1,6 +1,6 @@
 """Frame-folder clip loader feeding the device: the part of ref/utils/dataset.py the Stage-2 loop needs -
-`LitDataModule`'s per-dataset transforms and constants (:25-60), the folder walker of `BAIRDataset` / `CityScapesDataset`
-(:362-443), `ClipDataset` (:517-575), the `Vid*` transforms (:780-900) and the implicit DistributedSampler -
+`LitDataModule`'s per-dataset transforms and constants (:25-60), the folder walkers of `BAIRDataset` (:401-414) and
+`CityScapesDataset` (:420-443) and the 95 / 5 train / validation split (:84-88), `ClipDataset` (:517-575), the `Vid*` transforms (:780-900) and the implicit DistributedSampler -
 re-designed around the GPU instead of around torchvision:
 
   * worker threads decode with PIL and do the GEOMETRIC transforms (centre crop, resize, flips) on uint8 images;
@@ -53,6 +53,38 @@ def frame_folder_clips(frames_dir, clip_length):
     return clips
 
 
+def cityscapes_clips(frames_dir, clip_length):
+    """ref CityScapesDataset.__getClips__ (dataset.py:420-443): inside every sub-folder the (name-sorted) files are grouped by
+    the sequence id in their name (`<city>_<sequence>_<frame>_...`: fields 1 and 2 of the FILE NAME split at '_'; the reference
+    splits the full path string, which gives the same fields as long as no directory above has an underscore in its name),
+    each sequence is cut into runs of consecutive frame numbers, and every run is cut into non-overlapping clips with the
+    remainder dropped half at each end - a clip never straddles two sequences or a gap."""
+    from itertools import groupby
+    root = Path(frames_dir).absolute()
+    clips = []
+    for folder in (root / s_ for s_ in os.listdir(root)):           # the reference does not sort the folder list either
+        if not folder.is_dir():
+            continue
+        by_seq = {}
+        for f in sorted(folder.glob('*')):
+            by_seq.setdefault(f.name.split('_')[1], []).append(f)
+        for files in by_seq.values():
+            for _, run in groupby(enumerate(files), lambda ix: ix[0] - int(ix[1].name.split('_')[2])):
+                run = [f for _, f in run]
+                n, rem = len(run) // clip_length, len(run) % clip_length
+                run = run[rem // 2: rem // 2 + n * clip_length]
+                clips += [run[i * clip_length:(i + 1) * clip_length] for i in range(n)]
+    return clips
+
+
+def train_val_split(dataset_len, train_ratio=0.95, seed=2021):
+    """index lists of the reference's BAIR / SM-MNIST 95 / 5 train / validation split: torch random_split with
+    Generator().manual_seed(2021) (dataset.py:84-88,100-103)"""
+    n_train = int(dataset_len * train_ratio)
+    perm = torch.randperm(dataset_len, generator=torch.Generator().manual_seed(seed)).tolist()
+    return perm[:n_train], perm[n_train:]
+
+
 class ClipDataset:
     """ref ClipDataset (dataset.py:517-575) up to the point where pixels become floats: __getitem__ gives the clip as ONE
     uint8 array (T, H, W, C) after the geometric transforms; ToTensor + Normalize happen on the device (ClipLoader)."""
@@ -93,10 +125,22 @@ class ClipDataset:
         return np.ascontiguousarray(np.stack(frames, 0))
 
 
+# folder walkers by dataset.  KTH (person / action splits, dataset.py:253-360), KITTI (test-folder ids + overlapping windows,
+# :445-515) and SM-MNIST (generated digits, :578-700) are NOT folder-of-frame-folders trees: they have no walker here.
+WALKERS = {"BAIR": frame_folder_clips, "CityScapes": cityscapes_clips}
+
+
 def build_dataset(name, frames_dir, num_past_frames, num_future_frames, train=True, seed=0):
-    """the reference's per-dataset recipe (LitDataModule, dataset.py:33-60) over a folder-of-frame-folders tree"""
+    """the reference's per-dataset recipe (LitDataModule, dataset.py:33-60) for the datasets whose clips come from a tree of
+    frame folders: BAIR (frames_dir = <dir>/train or /test; the reference then splits train 95 / 5: train_val_split) and
+    CityScapes (frames_dir = <dir>/train, /val or /test).  The per-dataset constants of KTH / KITTI / SM-MNIST are in DATASETS
+    for ClipDataset users who bring their own clip lists; their walkers are not built."""
     d = DATASETS[name]
-    clips = frame_folder_clips(frames_dir, num_past_frames + num_future_frames)
+    if name not in WALKERS:
+        raise NotImplementedError(f"{name}: the reference builds its clip list from dataset-specific structure (person / action "
+                                  "splits, test-folder ids, generated digits), not from a tree of frame folders; pass your own "
+                                  "clip lists to ClipDataset with DATASETS[name]'s constants")
+    clips = WALKERS[name](frames_dir, num_past_frames + num_future_frames)
     return ClipDataset(num_past_frames, num_future_frames, clips, d["color"], d["center_crop"], d["resize"],
                        flips=train and d["train_flips"], seed=seed)
 

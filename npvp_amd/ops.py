@@ -464,6 +464,9 @@ class DecoderSplit:
 
     @classmethod
     def wanted(cls, N, T):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False        # under data parallelism the bucket all-reduces are ordered after the compute and gradient streams only
         return cls.enabled and N >= 2 and N % 2 == 0 and (N // 2) * T * 64 >= cls.min_rows and torch.is_grad_enabled()
 
 
@@ -1686,6 +1689,7 @@ class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, residual, act):
         _chk(x, bias, residual)
+        need_x, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[2]     # (read before x may be rebound to a no-grad copy)
         N, C, H, W = x.shape
         cl = (not x.is_contiguous()) and x.is_contiguous(memory_format=torch.channels_last)
         if not cl and not x.is_contiguous():
@@ -1697,7 +1701,7 @@ class _BiasAct(torch.autograd.Function):
         check(lib().npvp_bias_act(_ptr(x), _ptr(bias), _ptr(residual), _ptr(out), outer, inner, C, layout, act, _stream()),
               "npvp_bias_act")
         ctx.act, ctx.cl, ctx.has_res = act, cl, residual is not None
-        if x.requires_grad or (residual is not None and residual.requires_grad):
+        if need_x or need_res:
             if residual is not None:
                 raise NotImplementedError("bias_act: backward with a fused skip-add is not on the Stage-2 path")
             ctx.save_for_backward(out)

@@ -97,7 +97,7 @@ class FlatAdamW:
         self.hyper = torch.tensor([lr, 0.0], dtype=torch.float32, device=dev)      # {lr, step}
         self.clip = torch.zeros(2, dtype=torch.float32, device=dev)                # {norm, coefficient}
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
-        self.param_groups = [{"lr": lr}]
+        self.param_groups = [{"lr": lr, "initial_lr": lr}]      # initial_lr: the base LR a torch scheduler would record at construction
 
     def zero_grad(self, set_to_none=False):
         self.buf.zero_grad()
@@ -152,7 +152,7 @@ class FlatAdamW:
             shape = (lambda t: layouts[id(p)].ref_view(t)) if id(p) in layouts else (lambda t: t.view(p.shape))
             state[i] = {"step": step.clone(), "exp_avg": shape(self.m[off:off + n]).detach().cpu().contiguous().clone(),
                         "exp_avg_sq": shape(self.v[off:off + n]).detach().cpu().contiguous().clone()}
-        group = {"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+        group = {"lr": self.param_groups[0]["lr"], "initial_lr": self.param_groups[0]["initial_lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "params": list(range(len(order)))}
         return {"state": state, "param_groups": [group]}
@@ -178,6 +178,8 @@ class FlatAdamW:
                 step = float(st["step"])
             self.hyper[1:2].fill_(step)
         self.set_lr(g["lr"])
+        if "initial_lr" in g:               # (written by a torch scheduler into the group it was built on)
+            self.param_groups[0]["initial_lr"] = g["initial_lr"]
         self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
 
 
@@ -311,20 +313,34 @@ def vfi_batch_process(batch, to_list, tp_list):
 _CKPT_PREFIX = {"predictor": "predictor.", "enc": "VPTR_Enc.", "dec": "VPTR_Dec."}
 
 
+def _reject_fused_autoencoder(module, role):
+    """to_device_layout / fuse_frozen_autoencoder folds BatchNorm into the convolutions and renumbers the Sequentials: such a
+    module no longer has the reference's VPTR_Enc. / VPTR_Dec. state-dict keys.  Load / save the pair BEFORE fusing it."""
+    from .models.ResNetAutoEncoder import FoldedConvAct
+    if any(isinstance(m, FoldedConvAct) for m in module.modules()):
+        raise RuntimeError(f"{role}: this autoencoder has been fused for the device (to_device_layout): its state-dict keys are no "
+                           "longer the reference's; save / load the checkpoint with the unfused modules, then call to_device_layout")
+
+
 def save_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, epoch=0, global_step=0, scheduler_T0=None,
                               scheduler_eta_min=1e-7):
     sd = {}
     for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
         if m is not None:
+            _reject_fused_autoencoder(m, role)
             sd.update({_CKPT_PREFIX[role] + k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
     ck = {"state_dict": sd, "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "1.6.5"}
     if opt is not None:
         ck["optimizer_states"] = [opt.state_dict(predictor)]
         # the full state_dict of torch's CosineAnnealingWarmRestarts (ref/models/Predictor.py:213-215)
-        lr0 = opt.param_groups[0].get("initial_lr", opt.param_groups[0]["lr"])
+        # The reference's scheduler steps once per EPOCH (configure_optimizers returns it with Lightning's default
+        # interval='epoch', ref Predictor.py:213-215): T_cur / last_epoch count epochs; base_lrs = the LR the optimiser was
+        # BUILT with; _step_count stays 0 (CosineAnnealingWarmRestarts.step overrides the base class's and never advances it -
+        # checked against the live torch scheduler in tests/test_hip_golden.py).
+        lr0 = opt.param_groups[0]["initial_lr"]
         ck["lr_schedulers"] = [{"T_0": scheduler_T0, "T_i": scheduler_T0, "T_mult": 1, "eta_min": scheduler_eta_min,
                                 "T_cur": float(epoch % scheduler_T0), "base_lrs": [lr0], "last_epoch": float(epoch),
-                                "_step_count": int(global_step) + 1, "_last_lr": [opt.param_groups[0]["lr"]],
+                                "_step_count": 0, "_last_lr": [opt.param_groups[0]["lr"]],
                                 "_get_lr_called_within_step": False}] if scheduler_T0 else []
         ck["loops"] = None
     torch.save(ck, path)
@@ -345,6 +361,7 @@ def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, str
     for role, m in (("predictor", predictor), ("enc", enc), ("dec", dec)):
         if m is None:
             continue
+        _reject_fused_autoencoder(m, role)
         pre = _CKPT_PREFIX[role]
         part = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
         if not part and not strict:

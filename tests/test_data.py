@@ -41,6 +41,36 @@ def test_frame_folder_clips_centres_the_remainder(tmp_path):
     assert clips[2][0].parent.name == "vid_001" and clips[3][-1].name == "frame_0019.png"
 
 
+def test_cityscapes_walker_respects_sequences_and_gaps(tmp_path):
+    """ref CityScapesDataset.__getClips__: clips never straddle two sequence ids or a gap in the frame numbers"""
+    root = tmp_path / "cs"
+    city = root / "aachen"
+    city.mkdir(parents=True)
+    names = ([f"aachen_000001_{t:06d}_leftImg8bit.png" for t in range(0, 13)]              # 13 consecutive frames
+             + [f"aachen_000001_{t:06d}_leftImg8bit.png" for t in range(20, 26)]          # same sequence after a gap: 6 frames
+             + [f"aachen_000002_{t:06d}_leftImg8bit.png" for t in range(5, 10)])          # another sequence: 5 frames
+    for n in names:
+        (city / n).write_bytes(b"")
+    clips = D.cityscapes_clips(root, 5)
+    got = [[p.name.split("_")[1] + ":" + str(int(p.name.split("_")[2])) for p in c] for c in clips]
+    # 13 frames -> 2 clips from frame 1 (remainder 3: one dropped in front); 6 frames -> 1 clip from frame 20; 5 frames -> 1 clip
+    assert got == [[f"000001:{t}" for t in range(1, 6)], [f"000001:{t}" for t in range(6, 11)],
+                   [f"000001:{t}" for t in range(20, 25)], [f"000002:{t}" for t in range(5, 10)]]
+    with pytest.raises(NotImplementedError):
+        D.build_dataset("KTH", root, 10, 10)
+    for name in ("KITTI", "SMMNIST"):
+        with pytest.raises(NotImplementedError):
+            D.build_dataset(name, root, 4, 4)
+
+
+def test_train_val_split_is_torch_random_split():
+    from torch.utils.data import random_split
+    n = 257
+    tr, va = random_split(list(range(n)), [int(n * 0.95), n - int(n * 0.95)], generator=torch.Generator().manual_seed(2021))
+    a, b = D.train_val_split(n)
+    assert a == list(tr.indices) and b == list(va.indices)
+
+
 def test_shard_indices_partition_the_epoch():
     n, bs, world = 103, 4, 3
     per_rank = [D.shard_indices(n, bs, r, world, seed=5, epoch=2) for r in range(world)]

@@ -170,6 +170,20 @@ def test_optimizer_state_is_torch_adamw_format(impl, tmp_path):
     assert impl.load_lightning_checkpoint(path, m2, opt=opt2) == (1, 2)
     assert torch.equal(opt2.flat_p, opt.flat_p) and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
     assert float(opt2.hyper[1]) == 2.0 and opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    # the scheduler record is what torch's CosineAnnealingWarmRestarts holds after `epoch` epoch-steps from the CONSTRUCTION LR
+    # (the reference steps it once per epoch): it loads into a real scheduler, which then continues the same cosine
+    rec = torch.load(path, weights_only=True)["lr_schedulers"][0]
+    stock2 = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(stock2, 150, T_mult=1, eta_min=1e-7)
+    sch.step()                                                  # epoch 1, as the record says
+    want = sch.state_dict()
+    assert rec["_step_count"] == want["_step_count"] and rec["base_lrs"] == want["base_lrs"] == [1e-4]
+    assert rec["T_cur"] == want["T_cur"] and rec["last_epoch"] == want["last_epoch"] and rec["T_i"] == want["T_i"]
+    sch2 = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), 150,
+                                                               T_mult=1, eta_min=1e-7)
+    sch2.load_state_dict(rec)
+    sch.step(); sch2.step()
+    assert abs(sch.get_last_lr()[0] - sch2.get_last_lr()[0]) < 1e-12
     a = impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0)
     b = impl.predictor_train_step(m2, opt2, past, fut, 0.01, 1e-6, 1.0)
     assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"]) and torch.equal(opt2.flat_p, opt.flat_p)
@@ -415,3 +429,93 @@ def test_full_size_properties(impl):
         y1, y2 = m(past), m(past)
     assert torch.equal(y1, y2), "eval forward must be bit-deterministic"
     assert bool((y1 >= 0).all()) and y1.shape == (32, 10, 512, 8, 8)
+
+
+@pytest.mark.parametrize("path", ["stock", "fused"])
+@pytest.mark.parametrize("tag", ["64", "128"])
+def test_frozen_decoder_input_gradient_with_shared_relu_masks(impl, tag, path):
+    """The TIGHT form of test_frozen_autoencoder's g_feats check.  d(frames)/d(feats) passes through the decoder's ReLU masks,
+    and a unit within rounding noise of 0 lands on either side depending on the convolution algorithm (millions of units: no
+    input avoids them all), which is why the plain comparison above is held to 5e-3.  Here the HIP decoder's OWN masks are read
+    back and injected into an fp64 CPU twin of the decoder (same weights, ReLU replaced by 'multiply by this mask'): with the
+    kink decisions shared, the input gradient must agree to 1e-4 - transposed convolutions, folded BatchNorm, csrc/ae.hip's
+    act_bwd and all - and the two mask sets may differ in at most 1e-4 of the units."""
+    import torch.nn as nn
+    ci, ngf, nd, nres, S, out_layer = {"64": (1, 64, 3, 2, 64, 'Sigmoid'), "128": (3, 32, 4, 3, 128, 'Tanh')}[tag]
+    enc = impl.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
+    dec = impl.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
+    twin = impl.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
+    O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122); O.key_hashed_fill(twin, 122)
+    enc, dec, twin = enc.eval(), dec.eval(), twin.double().eval()
+    if path == "stock":
+        enc, dec = enc.to(DEV), dec.to(DEV)
+    else:
+        for q in list(enc.parameters()) + list(dec.parameters()):
+            q.requires_grad_(False)
+        enc, dec = impl.to_device_layout(enc, dec, DEV)
+    relu_sites = [m for m in dec.model if isinstance(m, nn.ReLU) or getattr(m, "act", 0) == 1]
+    assert len(relu_sites) == nd
+    masks = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: masks.append((out.detach() > 0).cpu())) for m in relu_sites]
+    x = torch.rand(1, 2, ci, S, S, generator=torch.Generator().manual_seed(123)).to(DEV)
+    with torch.no_grad():
+        feats = enc(x)
+    f = feats.clone().requires_grad_()
+    y = dec(f)
+    cot = O.seeded_randn(y.shape, 124)
+    (y * cot.to(DEV)).sum().backward()
+    for h in hooks:
+        h.remove()
+    assert len(masks) == nd
+
+    class Masked(nn.Module):
+        def __init__(self, mask):
+            super().__init__()
+            self.mask, self.natural = mask, None
+
+        def forward(self, v):
+            self.natural = v.detach() > 0
+            return v * self.mask.to(v.dtype)
+
+    it = iter(masks)
+    twin.model = nn.Sequential(*[Masked(next(it)) if isinstance(m, nn.ReLU) else m for m in twin.model])
+    f64 = feats.detach().double().cpu().requires_grad_()
+    (twin(f64) * cot.double()).sum().backward()
+    e = GC.rel_err(f.grad.cpu(), f64.grad.float())
+    GC.log_err(f"ae_{tag}.g_feats_shared_masks[{MODE},{path}]", "g_feats", e)
+    assert e < 1e-4, f"decoder input gradient with shared ReLU masks: rel-L2 {e:.3e}"
+    flips = sum(int((m.natural != m.mask).sum()) for m in twin.model if isinstance(m, Masked))
+    units = sum(m.mask.numel() for m in twin.model if isinstance(m, Masked))
+    assert flips <= 1e-4 * units, f"{flips} of {units} ReLU units on different sides of the kink"
+
+
+def test_decoder_block_batch8_against_oracle(impl):
+    """One full c2 decoder block (T2 = 28 target steps, T1 = 2 context steps) at N = 8 clips against the CPU oracle, forward and
+    every input gradient: the BATCH dimension of the benchmarked shape value-checked (the full-depth comparisons above stop at
+    N = 1 - 2, the full-size runs check properties only).  14 336 token rows: the fp16 GEMM kernels, the staged T = 28
+    attention backward, the fused MlpDWBN middle."""
+    import oracle
+    N, T2, T1 = 8, 28, 2
+
+    def run(mod_impl, dev):
+        m = mod_impl.VidHRFormerBlockDecNAR(8, 8, 512, 8, 4, 0.0, 0.0, 4, 1024)
+        O.key_hashed_fill(m, 61)
+        m = m.to(dev).train()
+        tgt = (0.3 * O.seeded_randn((N, T2, 8, 8, 512), 62)).to(dev).requires_grad_()
+        qe = (0.5 * O.seeded_randn((N, 8, 8, 512), 63)).to(dev).requires_grad_()
+        mem = O.synth_features((N, T1, 8, 8, 512), 64).to(dev).requires_grad_()
+        mb, _ = GC.pos_tables(T1, 65, False, dev)
+        tb, _ = GC.pos_tables(T2, 66, False, dev)
+        cot = O.seeded_randn((N, T2, 8, 8, 512), 67).to(dev)
+        y = m(tgt, qe, mem, (mb, None), (tb, None), mod_impl.PosFeatFuser(512, 'layer'))
+        g = torch.autograd.grad((y * cot).sum(), [tgt, qe, mem, m.EncDecAttn.in_proj_weight, m.SpatialFFN.fc1.weight, m.norm5.bias])
+        return [t.detach().cpu() for t in (y, *g)]
+
+    key = "dec_block_n8"
+    if key not in _LARGER_ORACLE:
+        _LARGER_ORACLE[key] = run(oracle, "cpu")
+    want, got = _LARGER_ORACLE[key], run(impl, DEV)
+    for a, b, n in zip(got, want, ["y", "g_tgt", "g_qe", "g_mem", "g_encdec_W", "g_fc1_W", "g_norm5_b"]):
+        e = GC.rel_err(a, b)
+        GC.log_err(f"dec_block_n8[{MODE}]", n, e)
+        assert e < TOL, f"{n}: {e:.3e}"
