@@ -38,135 +38,151 @@ __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx,
   p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later
 }
 
-// ---- epilogue of ONE 32x32 accumulator whose top-left element is (row0, col0): the C/D map of the 32x32 MFMA is
-// col = lane&31 (= r), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (= h).
-// order: *alpha +bias -> aux_out (pre-activation copy) -> act -> dropout -> +residual -> (+= C when accumulating)
-// Every option is a wave-uniform flag tested ONCE per tile around a straight 16-element loop (the first version tested
-// them per element: ~170 instructions and 13 branches per output element, a 22 000-line epilogue that ran at 1.4 TB/s and
-// cost 40 % of a K = 512 GEMM).  CHECK = false: the tile lies inside the matrix, no per-element bounds tests.
+// ---- epilogue of ONE 32x32 accumulator whose top-left element is (row0, col0).
+// The C/D map of the 32x32 MFMA is col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane owns one COLUMN,
+// so storing from that layout is 16 dword stores per tile, each 2 x 128 B per wave (and the loads of aux_in / residual /
+// the accumulate target likewise) - a 128 x 256 tile left as 512 store instructions per workgroup, and with the stores
+// removed the f16 kernel ran 19 % faster.  The tile is therefore TRANSPOSED through a per-wave LDS scratch (the operand
+// stages are idle after the K loop): 16 ds_write_b32 + 4 ds_read_b128 turn it into the row-major map
+//     lane l -> rows (l >> 3) + 8 k (k = 0..3), columns 4 (l & 7) .. + 3
+// in which every option of the epilogue works on float4 and a wave-instruction moves 8 rows x 128 B = 1 KB.
+// Order: *alpha +bias -> aux_out (pre-activation copy) -> act -> dropout -> +residual -> (+= C when accumulating).
+// Every option is a wave-uniform flag tested ONCE per tile.  ldc, ldr % 4 == 0 and 16-byte aligned bases (checked on the host).
+constexpr int EPI_LD = 36;                         // floats per scratch row (16-byte aligned rows)
+constexpr int EPI_FLOATS = 32 * EPI_LD;            // per wave
+
+__device__ __forceinline__ void epi_transpose(const f32x16& acc, float* scr, int lane, float4 (&v)[4]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) scr[(((g & 3) + 8 * (g >> 2)) + 4 * h) * EPI_LD + r] = acc[g];
+  // (one wave: its LDS operations execute in order, the reads below see the writes above and the next tile's writes cannot
+  // overtake these reads)
+  const int rr = lane >> 3, cq = lane & 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(scr + (rr + 8 * k) * EPI_LD + 4 * cq);
+}
+
+__device__ __forceinline__ float4 f4_mad(const float4& a, float s, const float4& b) {
+  return make_float4(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z, a.w * s + b.w);
+}
+__device__ __forceinline__ void f4_add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
 template <bool CHECK>
-__device__ __forceinline__ void epilogue_tile_impl(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h,
-                                                   int z, unsigned long long seed, float& cmax) {
-  const int col = col0 + r, rowb = row0 + 4 * h;
-  if (CHECK && col >= p.N) return;
-#define NPVP_RD(g) (((g) & 3) + 8 * ((g) >> 2))
-#define NPVP_INB(g) (!CHECK || rowb + NPVP_RD(g) < p.M)
-  const long long base = (long long)rowb * p.ldc + col;
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, float4 (&v)[4], int row0, int col0, int lane, int z,
+                                              unsigned long long seed, float& cmax) {
+  const int rb = row0 + (lane >> 3), col = col0 + 4 * (lane & 7);
+  if (CHECK && col >= p.N) return;                 // (N % 4 == 0: a quad is inside or outside)
+#define NPVP_ROW(k) (rb + 8 * (k))
+#define NPVP_INB(k) (!CHECK || NPVP_ROW(k) < p.M)
+  float* cp = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll) + col;
   const long long ld = p.ldc;
-  float* cp = p.C + (p.splits > 1 ? (long long)z * p.M * p.ldc : 0ll) + base;
   if (p.splits > 1) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cp[NPVP_RD(g) * ld] = acc[g];
+    for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) st4(cp + NPVP_ROW(k) * ld, v[k]);
     return;
   }
-  const float bv = p.bias ? p.bias[col] : 0.f;
-  float v[16];
+  const float4 bv = p.bias ? ld4(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int g = 0; g < 16; ++g) v[g] = acc[g] * p.alpha + bv;
+  for (int k = 0; k < 4; ++k) v[k] = f4_mad(v[k], p.alpha, bv);
   if (p.aux_out) {
-    float* ap = p.aux_out + base;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) ap[NPVP_RD(g) * ld] = v[g];
+    for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) st4(p.aux_out + NPVP_ROW(k) * ld + col, v[k]);
   }
   if (p.act == 1) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = gelu_f(v[g]);
+    for (int k = 0; k < 4; ++k) v[k] = make_float4(gelu_f(v[k].x), gelu_f(v[k].y), gelu_f(v[k].z), gelu_f(v[k].w));
   } else if (p.act == 2) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = fmaxf(v[g], 0.f);
+    for (int k = 0; k < 4; ++k) v[k] = make_float4(fmaxf(v[k].x, 0.f), fmaxf(v[k].y, 0.f), fmaxf(v[k].z, 0.f), fmaxf(v[k].w, 0.f));
   } else if (p.act == 3 || p.act == 4) {
-    const float* ip = p.aux_in + base;
-    float u[16];
+    float4 u[4];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) u[g] = NPVP_INB(g) ? ip[NPVP_RD(g) * ld] : 0.f;
+    for (int k = 0; k < 4; ++k) u[k] = NPVP_INB(k) ? ld4(p.aux_in + NPVP_ROW(k) * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.act == 3) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v[g] *= gelu_grad_f(u[g]);
+      for (int k = 0; k < 4; ++k) {
+        v[k].x *= gelu_grad_f(u[k].x); v[k].y *= gelu_grad_f(u[k].y); v[k].z *= gelu_grad_f(u[k].z); v[k].w *= gelu_grad_f(u[k].w);
+      }
     } else {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v[g] = u[g] > 0.f ? v[g] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        v[k].x = u[k].x > 0.f ? v[k].x : 0.f; v[k].y = u[k].y > 0.f ? v[k].y : 0.f;
+        v[k].z = u[k].z > 0.f ? v[k].z : 0.f; v[k].w = u[k].w > 0.f ? v[k].w : 0.f;
+      }
     }
   }
   if (p.drop.thresh) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] *= drop_spec_scale(p.drop, seed, rowb + NPVP_RD(g), col, p.N);
+    for (int k = 0; k < 4; ++k) {
+      const long long row = NPVP_ROW(k);
+      v[k].x *= drop_spec_scale(p.drop, seed, row, col + 0, p.N); v[k].y *= drop_spec_scale(p.drop, seed, row, col + 1, p.N);
+      v[k].z *= drop_spec_scale(p.drop, seed, row, col + 2, p.N); v[k].w *= drop_spec_scale(p.drop, seed, row, col + 3, p.N);
+    }
   }
   if (p.residual) {
-    const float* rp = p.residual + (long long)rowb * p.ldr + col;
-    const long long lr = p.ldr;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) v[g] += rp[NPVP_RD(g) * lr];
+    for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) f4_add(v[k], ld4(p.residual + NPVP_ROW(k) * p.ldr + col));
   }
   if (p.accum) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) v[g] += cp[NPVP_RD(g) * ld];
+    for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) f4_add(v[k], ld4(cp + NPVP_ROW(k) * ld));
   }
 #pragma unroll
-  for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cp[NPVP_RD(g) * ld] = v[g];
+  for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) st4(cp + NPVP_ROW(k) * ld, v[k]);
   if (p.c_amax) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) if (NPVP_INB(g)) cmax = fmaxf(cmax, fabsf(v[g]));
+    for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) cmax = amax4(cmax, v[k]);
   }
 #undef NPVP_INB
-#undef NPVP_RD
+#undef NPVP_ROW
 }
 
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int r, int h, int z,
+// scr = THIS WAVE's EPI_FLOATS floats of LDS
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int lane, float* scr, int z,
                                               unsigned long long seed, float& cmax) {
-  // fast path: a tile inside the matrix with a bias-only epilogue (most forward and all plain dgrad GEMMs)
-  const bool simple = p.splits == 1 && !p.aux_out && p.act == 0 && !p.drop.thresh && !p.residual && !p.accum;
-  if (simple && row0 + 32 <= p.M && col0 + 32 <= p.N) {
-    const int col = col0 + r;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-    float* cp = p.C + (long long)(row0 + 4 * h) * p.ldc + col;
-    const long long ld = p.ldc;
-    if (p.c_amax) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) { const float v = acc[g] * p.alpha + bv; cp[((g & 3) + 8 * (g >> 2)) * ld] = v; cmax = fmaxf(cmax, fabsf(v)); }
-      return;
-    }
-#pragma unroll
-    for (int g = 0; g < 16; ++g) cp[((g & 3) + 8 * (g >> 2)) * ld] = acc[g] * p.alpha + bv;
-    return;
-  }
-  epilogue_tile_impl<true>(p, acc, row0, col0, r, h, z, seed, cmax);
+  if (row0 >= p.M || col0 >= p.N) return;          // (wave-uniform: a tile entirely outside the matrix)
+  float4 v[4];
+  epi_transpose(acc, scr, lane, v);
+  if (row0 + 32 <= p.M && col0 + 32 <= p.N) epilogue_rows<false>(p, v, row0, col0, lane, z, seed, cmax);
+  else epilogue_rows<true>(p, v, row0, col0, lane, z, seed, cmax);
 }
 
 // Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
 // plus, per wave, the (mean, M2) of a 64 x 64 block of outputs held as 2 x 2 accumulators.  Token rows come in frames of
 // 64 and the block's 64 rows are exactly one frame (row0 % 64 == 0, M % 64 == 0), so rowstats[frame][column block of 64]
 // = (mean, M2) are the partials of the frame statistics (merged by frame_stats_finalize): the LayerNorm needs no pass
-// over C.  Sums are taken about the lane's first value and combined across the wave in Chan's form; fixed order,
-// deterministic.  M % 64 == 0 and N % 64 == 0 (checked by the launcher): the block is either inside the matrix or outside.
+// over C.  Sums are taken (in the accumulator layout) about the lane's first value and combined across the wave in Chan's
+// form; fixed order, deterministic.  M % 64 == 0 and N % 64 == 0 (checked by the launcher): the block is either inside
+// the matrix or outside.  The stores go through the same transposed path as every other epilogue.
 __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, const f32x16& a00, const f32x16& a01,
-                                                        const f32x16& a10, const f32x16& a11, int row0, int col0, int r, int h,
-                                                        float& cmax) {
+                                                        const f32x16& a10, const f32x16& a11, int row0, int col0, int lane,
+                                                        float* scr, float& cmax) {
   if (row0 >= p.M || col0 >= p.N) return;
+  const int r = lane & 31;
   float shift = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const f32x16& acc = tm == 0 ? (tn == 0 ? a00 : a01) : (tn == 0 ? a10 : a11);
-      const int col = col0 + tn * 32 + r;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float bv = p.bias ? p.bias[col0 + tn * 32 + r] : 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int row = row0 + tm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         const float v = acc[g] * p.alpha + bv;
-        p.C[(long long)row * p.ldc + col] = v;
-        cmax = fmaxf(cmax, fabsf(v));
         if (tm == 0 && tn == 0 && g == 0) shift = v;
         const float d = v - shift;
         s1 += d; s2 += d * d;
       }
+      float4 v[4];
+      epi_transpose(acc, scr, lane, v);
+      epilogue_rows<false>(p, v, row0 + tm * 32, col0 + tn * 32, lane, 0, 0ull, cmax);
     }
   }
   const float n = 64.f, m1 = s1 / n, mean_l = shift + m1, m2_l = s2 - s1 * m1;       // this lane's 64 values
   const float mean_w = wave_sum(mean_l) * (1.f / 64.f);
   const float dl = mean_l - mean_w;
   const float m2_w = wave_sum(m2_l + n * dl * dl);
-  if ((threadIdx.x & 63) == 0) {
+  if ((lane & 63) == 0) {
     const long long frame = row0 >> 6;
     const int cb = col0 >> 6, ncb = p.N >> 6;
     p.rowstats[(frame * ncb + cb) * 2] = mean_w;

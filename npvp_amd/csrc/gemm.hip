@@ -84,17 +84,19 @@ template <> struct Stager<false> {  // source [K][rows], rows contiguous
   }
 };
 
-// the four 32x32 accumulators of a wave's 64 x 64 block (128 x 128 tile, 2 x 2 waves)
+// the four 32x32 accumulators of a wave's 64 x 64 block (128 x 128 tile, 2 x 2 waves); lds = the block's LDS (idle after the K
+// loop's last barrier): per-wave transposition scratch of the epilogue (gemm.h)
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16& acc00, const f32x16& acc01,
                                               const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm, int wn,
-                                              int r, int h, int z) {
+                                              float* lds, int z) {
   const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
-  const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+  const int row0 = m0 + wm * 64, col0 = n0 + wn * 64, lane = threadIdx.x & 63;
+  float* scr = lds + (threadIdx.x >> 6) * EPI_FLOATS;
   float cmax = 0.f;
-  epilogue_tile(p, acc00, row0, col0, r, h, z, seed, cmax);
-  epilogue_tile(p, acc01, row0, col0 + 32, r, h, z, seed, cmax);
-  epilogue_tile(p, acc10, row0 + 32, col0, r, h, z, seed, cmax);
-  epilogue_tile(p, acc11, row0 + 32, col0 + 32, r, h, z, seed, cmax);
+  epilogue_tile(p, acc00, row0, col0, lane, scr, z, seed, cmax);
+  epilogue_tile(p, acc01, row0, col0 + 32, lane, scr, z, seed, cmax);
+  epilogue_tile(p, acc10, row0 + 32, col0, lane, scr, z, seed, cmax);
+  epilogue_tile(p, acc11, row0 + 32, col0 + 32, lane, scr, z, seed, cmax);
   if (p.splits == 1) amax_slot_commit(p.c_amax, cmax, 0u);        // (small shapes only: no peek)
 }
 
@@ -196,9 +198,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(GemmParams p)
         for (int i = 0; i < 8; ++i) t += red[i * 128 + threadIdx.x];
         store_colsum(p, (long long)z * p.M + m0 + threadIdx.x, t);
       }
+      __syncthreads();                   // `red` is about to become the epilogue's scratch
     }
   }
-  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+  static_assert(sizeof(As) >= 4 * EPI_FLOATS * 4, "scratch");
+  gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, &As[0][0], z);
 }
 
 // =====================================================================================================
@@ -417,10 +421,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
       red[t] = cs;
       __syncthreads();
       if (t < 128 && m0 + t < p.M) store_colsum(p, (long long)z * p.M + m0 + t, red[t] + red[t + 128]);
+      __syncthreads();                   // `red` is about to become the epilogue's scratch
     }
   }
-  if constexpr (ROWSTATS) { float cmax = 0.f; epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, r, h, cmax); amax_slot_commit(p.c_amax, cmax, 0u); }
-  else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, r, h, z);
+  static_assert(2 * STAGE >= 4 * EPI_FLOATS * 4, "scratch");
+  float* scr0 = reinterpret_cast<float*>(lds);
+  if constexpr (ROWSTATS) {
+    float cmax = 0.f;
+    epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, lane, scr0 + wave * EPI_FLOATS, cmax);
+    amax_slot_commit(p.c_amax, cmax, 0u);
+  } else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, scr0, z);
 }
 
 // All registered weight views in ONE launch (after the optimiser step): desc[v] = {w, ld, N, K, F, D} as 64-bit words
@@ -558,6 +568,9 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   NPVP_CHECK_ARG(M % 4 == 0 && N % 4 == 0, "gemm: M and N must be multiples of 4");
   NPVP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm: pointers must be 16-byte aligned");
   NPVP_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
+  NPVP_CHECK_ARG(ldc % 4 == 0 && (!residual || (ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0)) && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                 (!aux_in || ((uintptr_t)aux_in % 16) == 0) && (!aux_out || ((uintptr_t)aux_out % 16) == 0),
+                 "gemm: ldc / ldr must be multiples of 4 floats and bias / aux / residual 16-byte aligned (float4 epilogue)");
   NPVP_CHECK_ARG(!(a_kc == 0 && b_kc == 1), "gemm: (a_kc=0,b_kc=1) is not used by the path");
   NPVP_CHECK_ARG((act != 3 && act != 4) || aux_in, "gemm: act 3/4 need aux_in");
   NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p out of range");

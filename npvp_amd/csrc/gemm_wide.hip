@@ -172,19 +172,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
   }
 #endif
   float cmax = 0.f;
+  float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;      // per-wave transposition scratch (gemm.h)
   if constexpr (ROWSTATS) {
     static_assert(!ROWSTATS || (TN % 2 == 0 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
 #pragma unroll
     for (int i = 0; i < TM; i += 2)
 #pragma unroll
       for (int j = 0; j < TN; j += 2)
-        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, r, h, cmax);
+        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax);
   } else {
     const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, 0, seed, cmax);
+      for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax);
   }
   amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
@@ -337,14 +338,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_wide_k
       for (int i = 0; i < 8; ++i) sum += red[i * 128 + t];
       store_colsum(p, (long long)z * p.M + m0 + t, sum);
     }
+    __syncthreads();                     // `red` is about to become the epilogue's scratch
   }
+  float* scr = reinterpret_cast<float*>(lds) + wave * EPI_FLOATS;
   const unsigned long long seed = 0ull;
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, r, h, z, seed, cmax);
+    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, z, seed, cmax);
 }
 
 // split count of the wide weight-gradient kernel: ~512 workgroups (2 per CU), >= 16 K-steps per split

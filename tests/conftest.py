@@ -14,8 +14,9 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """`-m gpu` sessions: start the 2-rank data-parallel rehearsal (tools/dp_check.py) NOW, before this process initialises
-    the GPU (torch.cuda.device_count() does not), and let tests/test_dp_gpu.py collect it.  3 GPU processes in all."""
+    """`-m gpu` sessions: start the 2-rank jobs (tools/dp_jobs.py: the data-parallel rehearsal tools/dp_check.py, then
+    bench.py --gpus 2) NOW, before this process initialises the GPU (torch.cuda.device_count() does not), and let
+    tests/test_dp_gpu.py collect them.  3 GPU processes in all."""
     import subprocess
     import tempfile
     config = session.config
@@ -29,11 +30,10 @@ def pytest_sessionstart(session):
             return
     except Exception:
         return
-    log = tempfile.NamedTemporaryFile(prefix="npvp_dp_check_", suffix=".log", delete=False)
-    env = dict(os.environ, NPVP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]
-    proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    log = tempfile.NamedTemporaryFile(prefix="npvp_dp_jobs_", suffix=".log", delete=False)
+    # tools/dp_jobs.py runs the 2-rank jobs one after the other (dp_check, then bench.py --gpus 2): at most 2 + 1 GPU processes
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dp_jobs.py"), log.name], stdout=log,
+                            stderr=subprocess.STDOUT, cwd=ROOT)
     config._npvp_dp_job = (proc, log.name)
 
 

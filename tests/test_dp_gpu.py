@@ -3,21 +3,44 @@ Predictor step on every rank, GradSink listener -> GradSync hook, bucket all-red
 stream, SyncBatchNorm, train -> eval -> train, random-context batches - against one process on the whole batch
 (tools/dp_check.py).  The two ranks are started by tests/conftest.py at session start, BEFORE this process touches the GPU
 (a process that has initialised the GPU must not spawn GPU programs on this pool); this test only collects the result."""
+import json
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_equal_single_process(request):
+def _jobs(request):
     job = getattr(request.config, "_npvp_dp_job", None)
     if job is None:
-        pytest.skip("the DP rehearsal is only started for `-m gpu` sessions on a box with a GPU")
+        pytest.skip("the 2-rank jobs are only started for `-m gpu` sessions on a box with a GPU")
     proc, log_path = job
     try:
-        rc = proc.wait(timeout=600)
+        rc = proc.wait(timeout=900)
     except Exception:
         proc.kill()
         raise
-    log = open(log_path).read()
-    assert rc == 0 and "[dp_check] OK" in log, f"tools/dp_check.py failed (rc={rc}):\n{log[-3000:]}"
+    read = lambda name: open(f"{log_path}.{name}").read() if os.path.exists(f"{log_path}.{name}") else ""
+    return rc, read
+
+
+def test_two_ranks_equal_single_process(request):
+    rc, read = _jobs(request)
+    log = read("dp_check")
+    assert "[dp_check] OK" in log, f"tools/dp_check.py failed (rc={rc}):\n{log[-3000:]}"
     assert log.count("grad rel-L2") == 2, log[-2000:]
+
+
+def test_bench_two_ranks(request):
+    """bench.py's own N > 1 branch (the one the driver's scaling runs take) with 2 ranks on this card over gloo: the BASELINE
+    multi-GPU shard workload c4 (8 clips per rank), rank 0's JSON line."""
+    rc, read = _jobs(request)
+    log = read("bench2")
+    lines = [l for l in log.splitlines() if l.startswith("{")]
+    assert lines, f"bench.py --gpus 2 printed no JSON line (rc={rc}):\n{log[-3000:]}"
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 16 and "c4" not in r["config"]["parallelism"] and r["config"]["parallelism"] == "dp2"
+    assert r["roofline"] is not None and r["roofline"]["achieved"] > 0
+    assert abs(r["value"] - 2 * 8 * 20 / (r["ms_per_step"] * 1e-3)) < 1e-2 * r["value"]

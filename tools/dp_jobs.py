@@ -1,0 +1,22 @@
+"""The multi-process GPU jobs of `pytest -m gpu`, run one after the other by ONE child of the test session (started by
+tests/conftest.py before the test process touches the GPU; this wrapper itself never does):
+  1. tools/dp_check.py        - 2 ranks on one card (gloo on device tensors): the real data-parallel step == one process
+  2. bench.py --gpus 2        - the N > 1 branch of the benchmark itself (rank-strided model build, GradSync, SyncBatchNorm,
+                                MAX-over-ranks timing, the JSON line) on the BASELINE multi-GPU shard workload (c4: 8 clips)
+Each job's output goes to <log>.<name>; the wrapper's exit code is the first failure's."""
+import os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+log = sys.argv[1]
+env = dict(os.environ, NPVP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+jobs = [("dp_check", run + ["--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]),
+        ("bench2", run + ["--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "3",
+                          "--warmup", "1", "--no-secondary"])]
+rc = 0
+for name, cmd in jobs:
+    with open(f"{log}.{name}", "w") as f:
+        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    if r.returncode != 0 and rc == 0:
+        rc = r.returncode
+sys.exit(rc)
