@@ -136,6 +136,14 @@ int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const fl
                      const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
                      long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
 
+/* param_free_norm_type = 'instance' of the same module (ref/models/submodules.py:427-431: InstanceNorm2d(affine=False), statistics
+ * per (frame, channel) over the P = H*W <= 64 pixels): x [N*T][P][C] channels-last, add [N][P][C] or NULL, beta / gamma [T][P][C],
+ * mean / rstd [N*T][C].  No shipped configuration uses it; it is here so that the module's whole constructor surface runs. */
+int npvp_posfuse_instance_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y, float* mean,
+                              float* rstd, int N, int T, int P, int C, float eps, float* y_amax, npvp_stream_t stream);
+int npvp_posfuse_instance_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
+                              const float* rstd, float* du, float* dyxh, int N, int T, int P, int C, npvp_stream_t stream);
+
 /* ---- MlpDWBN inner stages (ref/models/VidHRFormer.py:374-392) on the channels-last hidden tensor
  * h [frames][per_frame = H*W*Ch]:  out = res + droppath_n( drop( GELU( LayerNorm((Ch,H,W))(h) ) ) )
  * with the per-element affine w,b given channels-last [H*W][Ch]; mean/rstd from npvp_frame_stats. */

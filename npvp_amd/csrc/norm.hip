@@ -329,6 +329,77 @@ __global__ void posfuse_bwd_apply_kernel(const float* __restrict__ dy, const flo
   }
 }
 
+// ------------------------------------------------------------------ PosFeatFuser, param_free_norm_type = 'instance'
+// InstanceNorm2d(affine=False) over the P = H*W pixels of every (frame, channel) (ref/models/submodules.py:427-431: the
+// branch no shipped config takes), then xhat (1 + gamma) + beta as the 'layer' form.  Channels-last: thread = one channel of
+// one frame, its P <= 64 pixels in registers (consecutive threads = consecutive channels: every load is coalesced); one
+// pass forward, one pass backward.  mean / rstd are [frames][C].
+constexpr int PFI_MAXP = 64;
+__global__ __launch_bounds__(256) void posfuse_inst_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                               const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                               float* __restrict__ y, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int T, int P, int C, float eps,
+                                                               float* __restrict__ amax) {
+  __shared__ float ared[4];
+  const unsigned int peek = amax_peek_block(amax);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long f = blockIdx.y;
+  float am = 0.f;
+  if (c < C) {
+    const int n = (int)(f / T), t = (int)(f - (long long)n * T);
+    const float* xp = x + f * P * C + c;
+    const float* ap = add ? add + (long long)n * P * C + c : nullptr;
+    float u[PFI_MAXP], s = 0.f;
+#pragma unroll
+    for (int p = 0; p < PFI_MAXP; ++p) if (p < P) { u[p] = xp[(long long)p * C] + (ap ? ap[(long long)p * C] : 0.f); s += u[p]; }
+    const float mu = s / P;
+    float q = 0.f;
+#pragma unroll
+    for (int p = 0; p < PFI_MAXP; ++p) if (p < P) { const float d = u[p] - mu; q += d * d; }
+    const float rs = rsqrtf(q / P + eps);
+    mean[f * C + c] = mu; rstd[f * C + c] = rs;
+    const float* bp = beta + (long long)t * P * C + c;
+    const float* gp = gamma ? gamma + (long long)t * P * C + c : nullptr;
+#pragma unroll
+    for (int p = 0; p < PFI_MAXP; ++p) if (p < P) {
+      float o = (u[p] - mu) * rs;
+      if (gp) o *= 1.f + gp[(long long)p * C];
+      o += bp[(long long)p * C];
+      y[f * P * C + (long long)p * C + c] = o;
+      am = fmaxf(am, fabsf(o));
+    }
+  }
+  amax_slot_commit_block(amax, am, ared, peek);
+}
+
+// du = rstd (g - mean_p g - uhat mean_p (g uhat)), g = dy (1 + gamma); dyxh (nullable) = dy * uhat
+__global__ __launch_bounds__(256) void posfuse_inst_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ add, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ du, float* __restrict__ dyxh, int T, int P,
+                                                               int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long f = blockIdx.y;
+  if (c >= C) return;
+  const int n = (int)(f / T), t = (int)(f - (long long)n * T);
+  const long long base = f * P * C + c;
+  const float* ap = add ? add + (long long)n * P * C + c : nullptr;
+  const float* gp = gamma ? gamma + (long long)t * P * C + c : nullptr;
+  const float mu = mean[f * C + c], rs = rstd[f * C + c];
+  float g[PFI_MAXP], uh[PFI_MAXP], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < PFI_MAXP; ++p) if (p < P) {
+    const float d = dy[base + (long long)p * C];
+    uh[p] = (x[base + (long long)p * C] + (ap ? ap[(long long)p * C] : 0.f) - mu) * rs;
+    if (dyxh) dyxh[base + (long long)p * C] = d * uh[p];
+    g[p] = gp ? d * (1.f + gp[(long long)p * C]) : d;
+    s1 += g[p]; s2 += g[p] * uh[p];
+  }
+  s1 /= P; s2 /= P;
+#pragma unroll
+  for (int p = 0; p < PFI_MAXP; ++p) if (p < P) du[base + (long long)p * C] = rs * (g[p] - s1 - uh[p] * s2);
+}
+
 // ------------------------------------------------------------------ frame-LN + affine + GELU (+dropout, residual, drop-path)
 // out = res + dp[n] * drop( gelu( (h-mean)*rstd*w[e] + b[e] ) )
 struct FlnParams {
@@ -593,6 +664,27 @@ extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* ad
   const long long total4 = (long long)frames * per_frame / 4;
   hipLaunchKernelGGL(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
                      rstd, (const float*)s1, (const float*)s2, du, dyxh, T, per_frame, total4);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// 'instance' form of the positional fuse: x [N*T][P][C], add [N][P][C] or NULL, beta / gamma [T][P][C]; mean / rstd [N*T][C]
+extern "C" int npvp_posfuse_instance_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y,
+                                         float* mean, float* rstd, int N, int T, int P, int C, float eps, float* y_amax,
+                                         hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && T > 0 && P > 0 && P <= PFI_MAXP && C > 0, "posfuse_instance: bad shape (P <= 64)");
+  hipLaunchKernelGGL(posfuse_inst_fwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, x, add, beta, gamma, y, mean,
+                     rstd, T, P, C, eps, y_amax);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_posfuse_instance_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
+                                         const float* rstd, float* du, float* dyxh, int N, int T, int P, int C,
+                                         hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && T > 0 && P > 0 && P <= PFI_MAXP && C > 0, "posfuse_instance_bwd: bad shape (P <= 64)");
+  hipLaunchKernelGGL(posfuse_inst_bwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, dy, x, add, gamma, mean, rstd,
+                     du, dyxh, T, P, C);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

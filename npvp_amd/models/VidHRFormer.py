@@ -225,9 +225,11 @@ class DropPath(nn.Module):
 
 
 def _stock_fuser(pos_fuser):
-    """the sub-layer nodes call the positional-fuse kernels directly: only for the stock PosFeatFuser('layer')"""
+    """the sub-layer nodes call the positional-fuse kernels directly: only for the stock PosFeatFuser('layer') (an 'instance'
+    fuser or a user's own module goes through the per-kernel autograd path below)"""
     from .submodules import PosFeatFuser
-    return type(pos_fuser) is PosFeatFuser and os.environ.get("NPVP_SUBLAYER_NODES", "1") == "1"
+    return (type(pos_fuser) is PosFeatFuser and pos_fuser.norm_type == 'layer'
+            and os.environ.get("NPVP_SUBLAYER_NODES", "1") == "1")
 
 
 def _get_clones(module, N):

@@ -69,19 +69,20 @@ class NRMLP(nn.Module):
 
 
 class PosFeatFuser(nn.Module):
-    """ref/models/submodules.py:412-454, param_free_norm_type 'layer' (every shipped config)."""
+    """ref/models/submodules.py:412-454: param_free_norm_type 'layer' (GroupNorm(1, C): every shipped config; the sub-layer nodes
+    of the blocks call its kernels directly) or 'instance' (InstanceNorm2d: statistics per frame and channel)."""
 
     def __init__(self, x_channels, param_free_norm_type='layer'):
         super().__init__()
-        if param_free_norm_type != 'layer':
-            raise NotImplementedError(
-                f"param_free_norm_type={param_free_norm_type!r}: only 'layer' (GroupNorm(1,C)) has a HIP kernel; "
-                "all reference configs use 'layer'")
+        if param_free_norm_type not in ('layer', 'instance'):
+            raise ValueError('%s is not a supported param-free norm type' % param_free_norm_type)        # ref :432-433
         self.norm_type = param_free_norm_type
 
     def forward(self, x, pos_beta, pos_gamma, add=None):
         """x (N,T,H,W,C); pos_* (T*H*W, C) (pos_gamma may be None = zeros); add (N,H,W,C) optional."""
         N, T = x.shape[0], x.shape[1]
+        if self.norm_type == 'instance':
+            return ops.posfuse_instance(x, add, pos_beta, pos_gamma, N, T).view(x.shape)
         return ops.posfuse(x, add, pos_beta, pos_gamma, N, T).view(x.shape)
 
 

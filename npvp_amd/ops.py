@@ -918,6 +918,49 @@ def posfuse(x, add, beta, gamma, N, T):
     return _PosFuse.apply(x, add, beta, gamma, N, T)
 
 
+class _PosFuseInstance(torch.autograd.Function):
+    """PosFeatFuser with param_free_norm_type='instance' (ref submodules.py:427-431): statistics per (frame, channel) over the
+    H*W pixels.  x (N,T,H,W,C) channels-last; beta / gamma [T*H*W, C]; add (N,H,W,C) or None."""
+
+    @staticmethod
+    def forward(ctx, x, add, beta, gamma, N, T):
+        _chk(x, add, beta, gamma)
+        x = _c(x)
+        C = x.shape[-1]
+        P = x.numel() // (N * T * C)
+        beta = _c(beta)
+        add_c = None if add is None else _c(add)
+        gamma_c = None if gamma is None else _c(gamma)
+        y = torch.empty_like(x)
+        st = torch.empty(2, N * T, C, dtype=torch.float32, device=x.device)
+        slot = _new_slot(x.device)
+        check(lib().npvp_posfuse_instance_fwd(_ptr(x), _ptr(add_c), _ptr(beta), _ptr(gamma_c), _ptr(y), _ptr(st[0]), _ptr(st[1]), N, T, P,
+                                              C, 1e-5, _ptr(slot), _stream()), "npvp_posfuse_instance_fwd")
+        tag_amax(y, slot)
+        ctx.save_for_backward(x, add_c, gamma_c, st)
+        ctx.cfg = (N, T, P, C, beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, add, gamma, st = ctx.saved_tensors
+        N, T, P, C, beta_shape = ctx.cfg
+        dy = _c(dy)
+        du = torch.empty_like(x)
+        dyxh = torch.empty_like(x) if (gamma is not None and ctx.needs_input_grad[3]) else None
+        check(lib().npvp_posfuse_instance_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(st[0]), _ptr(st[1]), _ptr(du), _ptr(dyxh),
+                                              N, T, P, C, _stream()), "npvp_posfuse_instance_bwd")
+        PF = P * C
+        dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and ctx.needs_input_grad[1]) else None
+        dbeta = reduce_mid(dy.view(1, N, T * PF)).view(beta_shape) if ctx.needs_input_grad[2] else None
+        dgamma = reduce_mid(dyxh.view(1, N, T * PF)).view(gamma.shape) if dyxh is not None else None
+        return du, dadd, dbeta, dgamma, None, None
+
+
+def posfuse_instance(x, add, beta, gamma, N, T):
+    return _PosFuseInstance.apply(x, add, beta, gamma, N, T)
+
+
 class _Linear(torch.autograd.Function):
     """y = residual + drop(x w^T + b): nn.Linear / 1x1 conv / MHA projections with the residual add
     and the dropout / drop-path that follows them in the reference fused into the GEMM epilogue."""

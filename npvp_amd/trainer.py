@@ -392,8 +392,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream(self.past.device).wait_stream(side)
         torch.cuda.synchronize(self.past.device)
         self.graph = torch.cuda.CUDAGraph()
+        # amax slots (f16x3 GEMMs) must be zero when their tensor is produced: the captured step cuts its slots from chunks
+        # created INSIDE the capture, so their zero fill is a node of the graph and every replay starts from clean slots
+        ops.AmaxSlot._cur = None
         with torch.cuda.graph(self.graph):
             self.out = predictor_train_step(*args, sync=False)
+        ops.AmaxSlot._cur = None            # (the graph's private-pool chunk is not for eager code)
 
     def __call__(self, past_feats=None, future_feats=None, lr=None):
         if lr is not None:

@@ -35,8 +35,35 @@ def impl(request):
     TOL = 1e-4
 
 
-def test_posfuse(impl):
-    GC.compare(GC.case_posfuse(impl, DEV, "layer"), GC.load("posfuse_layer"), TOL, tag=f"posfuse[{MODE}]")
+@pytest.mark.parametrize("norm", ["layer", "instance"])
+def test_posfuse(impl, norm):
+    GC.compare(GC.case_posfuse(impl, DEV, norm), GC.load(f"posfuse_{norm}"), TOL, tag=f"posfuse_{norm}[{MODE}]")
+
+
+def test_decoder_block_with_instance_fuser_against_oracle(impl):
+    """PosFeatFuser('instance') inside a decoder block (the blocks then run their per-kernel autograd path instead of the
+    sub-layer nodes): forward and input gradients against the oracle."""
+    import oracle
+    N, T2, T1 = 2, 3, 2
+
+    def run(mod_impl, dev):
+        m = mod_impl.VidHRFormerBlockDecNAR(8, 8, 512, 8, 4, 0.0, 0.0, 4, 1024)
+        O.key_hashed_fill(m, 61)
+        m = m.to(dev).train()
+        tgt = (0.3 * O.seeded_randn((N, T2, 8, 8, 512), 62)).to(dev).requires_grad_()
+        qe = (0.5 * O.seeded_randn((N, 8, 8, 512), 63)).to(dev).requires_grad_()
+        mem = O.synth_features((N, T1, 8, 8, 512), 64).to(dev).requires_grad_()
+        mb, mg = GC.pos_tables(T1, 65, True, dev)
+        tb, tg = GC.pos_tables(T2, 66, True, dev)
+        cot = O.seeded_randn((N, T2, 8, 8, 512), 67).to(dev)
+        y = m(tgt, qe, mem, (mb, mg), (tb, tg), mod_impl.PosFeatFuser(512, 'instance'))
+        g = torch.autograd.grad((y * cot).sum(), [tgt, qe, mem, m.norm5.bias])
+        return [t.detach().cpu() for t in (y, *g)]
+
+    want, got = run(oracle, "cpu"), run(impl, DEV)
+    for a, b, n in zip(got, want, ["y", "g_tgt", "g_qe", "g_mem", "g_norm5_b"]):
+        e = GC.rel_err(a, b)
+        assert e < TOL, f"{n}: {e:.3e}"
 
 
 @pytest.mark.parametrize("fuse", ["Add", "SPADE"])
