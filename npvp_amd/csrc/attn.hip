@@ -730,6 +730,127 @@ __global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
   amax_slot_commit(p.dv_amax, am_v, pk_v);
 }
 
+// ---- the same backward with ONE score orientation.  attn_bwd_staged_kernel evaluates S = Q K^T and dP = dO V^T twice - once
+// with queries on lanes (softmax statistics, dQ), once with keys on lanes (dK, dV) - because the row-reducing products
+// P^T dO and dS^T Q want P / dS with the QUERY index in registers.  Here they are evaluated once, in the query-on-lanes
+// orientation, and the two 16 x 16 blocks a (query block, key block) pair produces - P (dropout mask applied) and dS - are
+// transposed through a 2 x 16 x 20-float LDS scratch (1 ds_write_b128 + 4 ds_read_b32 per lane and matrix).  448 -> 320
+// MFMAs per wave, and the softmax exponentials and the dropout hash - half of the staged kernel's VALU work - are evaluated
+// once per element instead of twice.  dV / dK accumulate over the query blocks in registers and leave at the end.
+constexpr int LDX = 20;      // row stride of the transposition scratch (16-B aligned rows)
+
+template <int NQ, int NK>
+__global__ __launch_bounds__(64, 2) void attn_bwd_staged1_kernel(AttnParams p) {      // (2 waves / SIMD: <= 256 registers, VGPR + AGPR)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x, n = lane & 15, c = lane >> 4;
+  const long long wid = blockIdx.x;
+  const int head = (int)(wid % p.heads);
+  const long long g = wid / p.heads;
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  float* Qs = smem;
+  float* Gs = Qs + L * LDT;
+  float* Ks = Gs + L * LDT;
+  float* Xp = Ks + S * LDT;          // [16][LDX] P (masked) of the current block pair, query-major
+  float* Xd = Xp + 16 * LDX;         // [16][LDX] dS
+  AttnTileR vr[NK];
+  {
+    float4 sq[4 * NQ], sg[4 * NQ], sk[4 * NK];
+    attn_stage_load<4 * NK>(sk, p.k, p.ld_k, p, g, S, Tk, head, lane);
+    attn_stage_load<4 * NQ>(sq, p.q, p.ld_q, p, g, L, Tq, head, lane);
+    attn_stage_load<4 * NQ>(sg, p.go, p.ld_o, p, g, L, Tq, head, lane);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) attn_load_r(vr[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
+    __builtin_amdgcn_sched_barrier(0);      // every global load of this wave is in flight before the first wait
+    attn_stage_store<4 * NK>(Ks, sk, S, lane);
+    attn_stage_store<4 * NQ>(Qs, sq, L, lane);
+    attn_stage_store<4 * NQ>(Gs, sg, L, lane);
+  }
+  __syncthreads();                          // one wave per workgroup: orders the LDS writes before the reads below
+  float am_q = 0.f, am_k = 0.f, am_v = 0.f;
+  const unsigned int pk_q = amax_peek_wave(p.dq_amax), pk_k = amax_peek_wave(p.dk_amax), pk_v = amax_peek_wave(p.dv_amax);
+  f32x4_t dv[NK][4], dk[NK][4];
+#pragma unroll
+  for (int kb = 0; kb < NK; ++kb) { attn_zero(dv[kb]); attn_zero(dk[kb]); }
+#pragma unroll
+  for (int qb = 0; qb < NQ; ++qb) {
+    AttnTileR qr, gr;
+    attn_lds_r(qr, Qs, L, n, c, qb);
+    attn_lds_r(gr, Gs, L, n, c, qb);
+    const int q = 16 * qb + n, qn = min(q, L - 1);
+    float sc[NK][4], dp[NK][4], mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      AttnTileR kr;
+      attn_lds_r(kr, Ks, S, n, c, kb);
+      const f32x4_t sa = attn_mm_d(kr, qr), da = attn_mm_d(vr[kb], gr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float s = sa[i] * p.scale;
+        if (j >= S || (p.mask_mode == 1 && j == S - 1 && q < L - 1)) s = -INFINITY;
+        sc[kb][i] = s; dp[kb][i] = da[i]; mx = fmaxf(mx, s);
+      }
+    }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[kb][i] = (sc[kb][i] == -INFINITY) ? 0.f : __expf(sc[kb][i] - mx); sum += sc[kb][i]; }
+    sum = quad_sum(sum);
+    const float inv = 1.f / sum;
+    float rs = 0.f, pm[NK][4];
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * kb + 4 * c + i;
+        float m = 1.f;
+        if (p.drop_thresh && j < S)
+          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
+        sc[kb][i] *= inv;
+        pm[kb][i] = sc[kb][i] * m;              // P with the dropout mask: what multiplies dO in dV
+        dp[kb][i] *= m;
+        rs += dp[kb][i] * sc[kb][i];
+      }
+    rs = quad_sum(rs);
+    const bool live = q < L;                    // rows past the end (clamped loads) must not reach dK / dV
+    f32x4_t dq[4];
+    attn_zero(dq);
+    AttnTileG gg, qg;
+    attn_lds_g(gg, Gs, L, n, c, qb);
+    attn_lds_g(qg, Qs, L, n, c, qb);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
+      float ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ds[i] = sc[kb][i] * (dp[kb][i] - rs) * p.scale;
+      AttnTileG kg;
+      attn_lds_g(kg, Ks, S, n, c, kb);
+      attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] += sum_j dS[q][j] K[j][d]
+      // transpose the pair's P and dS blocks: lane (n, c) holds M[query n][key 4c+i], dK / dV want M[query 4c+i][key n]
+      st4(Xp + n * LDX + 4 * c, live ? make_float4(pm[kb][0], pm[kb][1], pm[kb][2], pm[kb][3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+      st4(Xd + n * LDX + 4 * c, live ? make_float4(ds[0], ds[1], ds[2], ds[3]) : make_float4(0.f, 0.f, 0.f, 0.f));
+      float pT[4], dT[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pT[i] = Xp[(4 * c + i) * LDX + n]; dT[i] = Xd[(4 * c + i) * LDX + n]; }
+      attn_mm_rows(dv[kb], pT, gg);                              // dV[j][d] += sum_q Pd[q][j] dO[q][d]
+      attn_mm_rows(dk[kb], dT, qg);                              // dK[j][d] += sum_q dS[q][j] Q[q][d]
+    }
+    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb, am_q);
+  }
+#pragma unroll
+  for (int kb = 0; kb < NK; ++kb) {
+    attn_store_d(dv[kb], p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb, am_v);
+    attn_store_d(dk[kb], p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb, am_k);
+  }
+  amax_slot_commit(p.dq_amax, am_q, pk_q);
+  amax_slot_commit(p.dk_amax, am_k, pk_k);
+  amax_slot_commit(p.dv_amax, am_v, pk_v);
+}
+
 static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
                       int Tk, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, bool bwd) {
   if (head_dim != HD) { npvp_set_error("attn: head_dim must be 64"); return NPVP_ERR_ARG; }
@@ -813,7 +934,9 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   const int L = p.L > p.S ? p.L : p.S;
   static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;
   static const bool staged = getenv("NPVP_ATTN_BWD_UNSTAGED") == nullptr;   // A/B switch for the measurement in DESIGN.md
+  static const bool two_orient = getenv("NPVP_ATTN_BWD_TWO_ORIENT") != nullptr;   // A/B: the staged kernel with both score orientations
   const size_t staged_lds = (size_t)(2 * p.L + p.S) * LDT * sizeof(float);
+  const size_t staged1_lds = staged_lds + 2 * 16 * LDX * sizeof(float);
   NPVP_CHECK_ARG(p.total < (1ll << 31), "attn_bwd: too many (group, head) pairs for one launch");
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
@@ -822,8 +945,13 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
     else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
     else if (!staged && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
     else if (!staged) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
-    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
-    else hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
+    // measured at the c2 size (tools/attn_bench.py, one / two orientations): T = 28: 718 / 734 us, 28 x 2: 254 / 295 us, but
+    // T = 18: 678 / 580 us (a second query block with 2 live rows pays the full transposition and the dV / dK products):
+    // the one-orientation kernel takes one key block, or query sequences that fill most of the second block
+    else if ((two_orient || (nk == 2 && p.L < 25)) && nk == 1) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
+    else if (two_orient || (nk == 2 && p.L < 25)) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
+    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
+    else hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
   } else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
   NPVP_CHECK_LAUNCH();
