@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 profile set, run on the GPU box from the repo root:  bash tools/profile_r03.sh
+# Writes summaries under gpurun_out/prof_r03/ (copied to profiles/r03_* afterwards).  Counter passes are separate from the
+# kernel-trace pass and from each other (FETCH_SIZE / WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md), and carry no other
+# tracing domain.
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/prof_r03"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 2 --no-secondary --no-cpu-baseline --no-probe"
+
+echo "[1] un-profiled bench (the record the kernel stats are read beside)"
+python3 $ROOT/bench.py --steps 10 --warmup 3 --no-secondary --no-cpu-baseline > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+tail -2 "$OUT/bench_c2.err"
+
+echo "[2] kernel trace"
+rocprofv3 --kernel-trace -d "$OUT/kt" -o c2 -- $BENCH > "$OUT/bench_c2_profiled.json" 2> "$OUT/kt.err"
+python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2.csv" > /dev/null
+python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2_by_grid.csv" --by-grid > /dev/null
+rm -rf "$OUT/kt"
+
+echo "[3] FETCH_SIZE pass"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pf" -o c2 -- $BENCH > /dev/null 2> "$OUT/pf.err"
+echo "[4] WRITE_SIZE pass"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pw" -o c2 -- $BENCH > /dev/null 2> "$OUT/pw.err"
+python3 $ROOT/tools/rocpd_traffic.py $(ls "$OUT"/pf/*.db | head -1) $(ls "$OUT"/pw/*.db | head -1) "$OUT/hbm_traffic_c2.md" "$OUT/hbm_traffic_c2.json" > /dev/null
+rm -rf "$OUT/pf" "$OUT/pw"
+
+echo "[5] SQ counters of the fp16 GEMM kernels (two passes)"
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+  -d "$OUT/g1" -o gemm -- python3 $ROOT/tools/gemm_pmc.py > /dev/null 2> "$OUT/g1.err"
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES \
+  -d "$OUT/g2" -o gemm -- python3 $ROOT/tools/gemm_pmc.py > /dev/null 2> "$OUT/g2.err"
+python3 $ROOT/tools/rocpd_pmc.py $(ls "$OUT"/g1/*.db | head -1) $(ls "$OUT"/g2/*.db | head -1) --filter npvp::gemm --out "$OUT/pmc_gemm_table.md" > /dev/null
+rm -rf "$OUT/g1" "$OUT/g2"
+ls -la "$OUT"
