@@ -19,6 +19,7 @@
 // per CU) with two planes per operand: 24.8 KB per stage instead of 36.4, 24 MFMAs and ~20 VALU of splitting per wave and
 // K-step instead of 48 and ~60.
 #include "gemm.h"
+#include <cstdlib>
 
 // measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_H_ABL=n on the GPU box; results INVALID): 1 = no C stores, 2 = no A global
 // loads inside the K loop, 4 = no B LDS-DMA inside the K loop, 8 = no A split / ds_write inside the K loop
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 int f16_wgrad_splits(int M, int N, int K) {
   if ((K & 15) || M < 64 || N < 128 || K < 4096) return 0;
   const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
-  int s = (512 + tiles - 1) / tiles;
+  static const int want = getenv("NPVP_WGRAD_WGS") ? atoi(getenv("NPVP_WGRAD_WGS")) : 512;     // A/B switch (workgroups per launch)
+  int s = (want + tiles - 1) / tiles;
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;

@@ -57,11 +57,12 @@ def test_decoder_block_with_instance_fuser_against_oracle(impl):
         tb, tg = GC.pos_tables(T2, 66, True, dev)
         cot = O.seeded_randn((N, T2, 8, 8, 512), 67).to(dev)
         y = m(tgt, qe, mem, (mb, mg), (tb, tg), mod_impl.PosFeatFuser(512, 'instance'))
-        g = torch.autograd.grad((y * cot).sum(), [tgt, qe, mem, m.norm5.bias])
+        # (norm5.weight, not .bias: an instance norm removes any per-channel constant, so d/d norm5.bias is pure rounding noise)
+        g = torch.autograd.grad((y * cot).sum(), [tgt, qe, mem, m.norm5.weight, m.norm1.bias])
         return [t.detach().cpu() for t in (y, *g)]
 
     want, got = run(oracle, "cpu"), run(impl, DEV)
-    for a, b, n in zip(got, want, ["y", "g_tgt", "g_qe", "g_mem", "g_norm5_b"]):
+    for a, b, n in zip(got, want, ["y", "g_tgt", "g_qe", "g_mem", "g_norm5_w", "g_norm1_b"]):
         e = GC.rel_err(a, b)
         assert e < TOL, f"{n}: {e:.3e}"
 
@@ -115,6 +116,8 @@ def test_frozen_autoencoder(impl, tag, path):
     """frozen AE vs the reference's vectors.  stock: the modules as built on PyTorch-ROCm (MIOpen); fused: to_device_layout =
     channels_last encoder, BatchNorm folded into the convolutions, bias / ReLU / skip-add / tanh in csrc/ae.hip's epilogue pass,
     decoder input gradient through npvp_act_bwd"""
+    if MODE != DEFAULT_MODE:
+        pytest.skip("the frozen autoencoder has no GEMM of the predictor's kind: one arithmetic mode is enough")
     res = GC.case_ae(impl, DEV, tag, device_layout=impl.to_device_layout if path == "fused" else None)
     gold = GC.load(f"ae_{tag}")
     # forward: MIOpen convolutions vs the CPU reference.  The decoder's input gradient passes through its ReLU masks:
@@ -468,6 +471,8 @@ def test_frozen_decoder_input_gradient_with_shared_relu_masks(impl, tag, path):
     kink decisions shared, the input gradient must agree to 1e-4 - transposed convolutions, folded BatchNorm, csrc/ae.hip's
     act_bwd and all - and the two mask sets may differ in at most 1e-4 of the units."""
     import torch.nn as nn
+    if MODE != DEFAULT_MODE:
+        pytest.skip("the frozen autoencoder has no GEMM of the predictor's kind: one arithmetic mode is enough")
     ci, ngf, nd, nres, S, out_layer = {"64": (1, 64, 3, 2, 64, 'Sigmoid'), "128": (3, 32, 4, 3, 128, 'Tanh')}[tag]
     enc = impl.ResnetEncoder(ci, ngf=ngf, n_downsampling=nd, num_res_blocks=nres, learn_3d=False)
     dec = impl.ResnetDecoder(ci, ngf=ngf, n_downsampling=nd, out_layer=out_layer)
