@@ -393,6 +393,9 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
+  static const int force_g = getenv("NPVP_COLGROUPS") ? atoi(getenv("NPVP_COLGROUPS")) : 0;        // A/B switch
+  if (force_g > 0 && (force_g == 1 || (p.tiles_n % force_g == 0 && p.tiles_m % (8 / force_g) == 0 && (p.tiles_m * p.tiles_n) % 8 == 0)))
+    p.colgroups = force_g;
   dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (v == 1) {
     if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
