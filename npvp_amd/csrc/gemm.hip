@@ -465,11 +465,24 @@ __global__ void split_weights_batched_kernel(const SplitDesc* __restrict__ desc)
   }
 }
 
-// sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out)
+// sum split-K partial slabs: out[m][n] = alpha * sum_z ws[z][m][n]   (ldc-strided out); the same launch also finishes the
+// column-sum partials of the bias gradient (cs_part [splits][M] -> cs_out [M], no alpha), which used to be a launch of its own
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
-                                     long long ldc, int splits, float alpha, int accum) {
-  const long long total4 = (long long)M * N / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+                                     long long ldc, int splits, float alpha, int accum, const float* __restrict__ cs_part,
+                                     float* __restrict__ cs_out) {
+  const long long total4 = (long long)M * N / 4, cs4 = cs_out ? M / 4 : 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4 + cs4; i += (long long)gridDim.x * blockDim.x) {
+    if (i >= total4) {
+      const long long e = (i - total4) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int zz = 0; zz < splits; ++zz) {
+        const float4 v = ld4(cs_part + (long long)zz * M + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (accum) { const float4 o = ld4(cs_out + e); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+      st4(cs_out + e, s);
+      continue;
+    }
     const long long e = i * 4;
     const int m = (int)(e / N), n = (int)(e - (long long)m * N);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -626,10 +639,11 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
         if (sh > 1) {
           const long long total4 = (long long)M * N / 4;
           int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+          const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;       // (a float4-aligned bias gradient rides along)
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
-                             sh, alpha, p.accum);
+                             sh, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr);
           NPVP_CHECK_LAUNCH();
-          if (colsum_a && launch_sum_rows(p.colsum, colsum_a, sh, M, M, stream, p.accum)) {
+          if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, sh, M, M, stream, p.accum)) {
             npvp_set_error("gemm: column-sum reduce launch failed");
             return NPVP_ERR_LAUNCH;
           }
@@ -683,10 +697,11 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (splits > 1) {
     const long long total4 = (long long)M * N / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
-                       splits, alpha, p.accum);
+                       splits, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr);
     NPVP_CHECK_LAUNCH();
-    if (colsum_a && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream, p.accum)) {
+    if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream, p.accum)) {
       npvp_set_error("gemm: column-sum reduce launch failed");
       return NPVP_ERR_LAUNCH;
     }

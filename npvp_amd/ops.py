@@ -319,8 +319,11 @@ class WeightPlanes:
         if any(ent.version != ent.w._version for ent in cls._entries()):
             cls.refresh_all()
 
+    epoch = 0               # bumped whenever the parameters changed under us (caches derived from parameters key on it)
+
     @classmethod
     def refresh_all(cls):
+        cls.epoch += 1
         if not cls.enabled:
             return
         if cls._dirty or cls._tables is None:
@@ -1327,10 +1330,17 @@ class _MlpDwbn(torch.autograd.Function):
         stats = torch.empty(6, frames, dtype=f32, device=dev)               # mean1, rstd1, mean2, rstd2, mean3, rstd3
         check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _ptr(stats[0]), _ptr(stats[1]), frames, 1e-5, st),
               "npvp_frame_stats_finalize")
-        # tap-major depthwise weights [9][hid] + bias row
-        wtb = torch.empty(10, hid, dtype=f32, device=dev)
-        check(L.npvp_transpose(_ptr(dww), _ptr(wtb), 1, hid, 9, st), "npvp_transpose")
-        wtb[9].copy_(dwb)
+        # tap-major depthwise weights [9][hid] + bias row: rebuilt when the parameters changed (optimiser step / in-place update),
+        # not per call (2 launches per MlpDWBN forward)
+        key = (WeightPlanes.epoch, dww._version, dwb._version, dww.data_ptr(), dwb.data_ptr())
+        hit = dww.__dict__.get("_npvp_wtb")
+        if hit is not None and hit[0] == key:
+            wtb = hit[1]
+        else:
+            wtb = torch.empty(10, hid, dtype=f32, device=dev)
+            check(L.npvp_transpose(_ptr(dww), _ptr(wtb), 1, hid, 9, st), "npvp_transpose")
+            wtb[9].copy_(dwb)
+            dww.__dict__["_npvp_wtb"] = (key, wtb)
         # fused middle
         h2 = torch.empty(R, hid, dtype=f32, device=dev)
         ws, wsn = _ws(frames * (hid // 512) * 8, dev)
