@@ -98,6 +98,16 @@ __host__ __device__ __forceinline__ float amax_scale(float amax) {
   return s;
 }
 
+// 1 / s for a power of two s with exponent field 1..253 (what amax_scale returns): no division sequence
+__host__ __device__ __forceinline__ float pow2_recip(float s) {
+  unsigned int u;
+  __builtin_memcpy(&u, &s, 4);
+  u = 0x7f000000u - u;
+  float r;
+  __builtin_memcpy(&r, &u, 4);
+  return r;
+}
+
 // running bound of four stored values
 __device__ __forceinline__ float amax4(float m, const float4& v) {
   return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));

@@ -73,20 +73,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int quad = t & 3, rl = t >> 2;
-  const float* a_src0 = p.A + (long long)min(m0 + rl, p.M - 1) * p.lda + 4 * quad;
-  const float* a_src1 = p.A + (long long)min(m0 + rl + BM / 2, p.M - 1) * p.lda + 4 * quad;
+  // global addresses = wave-uniform 64-bit base (SGPRs, advanced per K-step by scalar adds) + a per-lane 32-bit byte offset that
+  // never changes: no 64-bit vector adds inside the K loop (they were 6 of its 38 VALU per step)
+  const char* a_base = reinterpret_cast<const char*>(p.A + (long long)m0 * p.lda);
+  const unsigned int a_off0 = (unsigned int)(((long long)(min(m0 + rl, p.M - 1) - m0) * p.lda + 4 * quad) * 4);
+  const unsigned int a_off1 = (unsigned int)(((long long)(min(m0 + rl + BM / 2, p.M - 1) - m0) * p.lda + 4 * quad) * 4);
   const int a_dst = (quad >> 1) * KGS_A + (quad & 1) * 8 + rl * 16;
-  const uint4* b_src[CPW];
+  const char* b_base = reinterpret_cast<const char*>(p.b_pre);
+  unsigned int b_off[CPW];
   int b_dst[CPW];
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     const int c = wave + NW * i;
     const int slab = c / CPS, part = c - slab * CPS, s = slab >> 1, kg = slab & 1;
     const int col = min(n0 + part * 64 + lane, p.N - 1);
-    b_src[i] = reinterpret_cast<const uint4*>(p.b_pre) + (long long)s * (p.b_pre_plane >> 3) + (long long)kg * p.N + col;
+    b_off[i] = (unsigned int)(((long long)s * (p.b_pre_plane >> 3) + (long long)kg * p.N + col) * 16);
     b_dst[i] = A_BYTES + s * B_PLANE + kg * KGS_B + part * 1024;
   }
-  const long long b_step = 2ll * p.N;
+  const long long b_step = 32ll * p.N;                // bytes per K-step
 
   const int fa_off = h * KGS_A + (wm * TM * 32 + r) * 16;
   const int fb_off = A_BYTES + h * KGS_B + (wn * TN * 32 + r) * 16;
@@ -99,18 +103,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   // budget) and A kt+2 (a step and a half) have landed, and the registers consumed in the next step are valid.
   f32x4 ea0, ea1, eb0, eb1;
 #define NPVP_H_ALOAD(R0, R1, KT)                                                                           \
-  { const int k_ = min((KT), nk - 1) << 4;                                                                 \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R0) : "v"(a_src0 + k_) : "memory");              \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R1) : "v"(a_src1 + k_) : "memory"); }
+  { const char* ab_ = a_base + ((long long)min((KT), nk - 1) << 6);                                        \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R0) : "v"(a_off0), "s"(ab_) : "memory");          \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R1) : "v"(a_off1), "s"(ab_) : "memory"); }
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
   { f16x4 hi_, lo_; split_f16((V) * sa, hi_, lo_);                                       \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
     *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
 #define NPVP_H_BLOAD(ST, KT)                                                             \
-  { const long long ko_ = (long long)min((KT), nk - 1) * b_step;                         \
+  { const char* bb_ = b_base + (long long)min((KT), nk - 1) * b_step;                    \
     _Pragma("unroll") for (int i_ = 0; i_ < CPW; ++i_)                                   \
       if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK)                                   \
-        __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i_] + ko_), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
+        __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + b_off[i_]), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
   static_assert(NCHUNK % NW == 0, "the hand-counted waits assume CPW LDS-DMA pieces per wave and step");
 
   // prologue: tile 0 -> stage 0 (B by DMA, A through the registers), A tiles 1 and 2 -> register sets
@@ -165,14 +169,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
 #undef NPVP_H_ASTORE
 #undef NPVP_H_ALOAD
 
-  // back to the operands' own scale (exact: powers of two; two factors so that neither product of scales can underflow)
-  const float ia = 1.f / sa, ib = 1.f / amax_scale(amax_slot_read(p.b_amax));
+  // Back to the operands' own scale: C = acc * (1/sa) * (1/sb) * alpha + bias.  The two scales are powers of two, so their product
+  // times alpha is exact and ONE fused multiply-add per element (the epilogue's own alpha * acc + bias) rounds exactly like
+  // scaling first - as long as that combined factor is a normal number.  Otherwise (bounds near the ends of fp32's range) the
+  // accumulators are scaled in two exact steps, so that neither product of scales can under- or overflow.  Folding saves 32 VALU
+  // per 32 x 32 tile (the scalings were a third of the epilogue's instructions).
+  const float ia = pow2_recip(sa), ib = pow2_recip(amax_scale(amax_slot_read(p.b_amax)));
+  GemmParams q = p;
+  {
+    const float f = ia * ib, af = p.alpha * f, mag = fabsf(af);
+    const bool fold = f >= 1.17549435e-38f && f <= 3.0e38f && ((mag >= 1.17549435e-38f && mag <= 3.0e38f) || p.alpha == 0.f);
+    if (fold) q.alpha = af;
+    else {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) acc[i][j][g] = acc[i][j][g] * ia * ib;
+          for (int g = 0; g < 16; ++g) acc[i][j][g] = acc[i][j][g] * ia * ib;
+    }
+  }
 
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
@@ -193,13 +209,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     for (int i = 0; i < TM; i += 2)
 #pragma unroll
       for (int j = 0; j < TN; j += 2)
-        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax);
+        epilogue_rowstats_block(q, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax);
   } else {
-    const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
+    const unsigned long long seed = (q.seed && q.drop.thresh) ? *q.seed : 0ull;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax);
+      for (int j = 0; j < TN; ++j) epilogue_tile(q, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax);
   }
   amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   }
   float* scr = reinterpret_cast<float*>(lds) + wave * EPI_FLOATS;
   static_assert(2 * STAGE >= NW * EPI_FLOATS * 4, "scratch");
-  const float ia = 1.f / sa, ib = 1.f / sb;
+  const float ia = pow2_recip(sa), ib = pow2_recip(sb);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -14,7 +14,8 @@ _p = ctypes.c_void_p
 
 
 def _ptr(t):
-    return _p(0) if t is None else _p(t.data_ptr())
+    """device address as a plain int (None -> NULL): the ctypes prototypes declare c_void_p, which takes either"""
+    return None if t is None else t.data_ptr()
 
 
 class AmaxSlot:
@@ -76,14 +77,20 @@ def tag_amax(t, slot):
     return t
 
 
+def _row(t, i):
+    """device address of row i of a contiguous fp32 matrix (t[i] without building the view: ~1 000 of them per step)"""
+    return t.data_ptr() + 4 * i * t.stride(0)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device      # (the C call, without the lazy-init checks)
 
 
 def _stream():
     """the calling thread's current HIP stream as a raw handle (one C call: this runs once per kernel launch)"""
     if _raw_stream is not None:
-        return _p(_raw_stream(torch.cuda.current_device()))
-    return _p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_cur_dev())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _chk(*ts):
@@ -232,9 +239,10 @@ class WeightPlanes:
     _owners = []            # weak references to tensors that carry a `_npvp_planes` store
     _tables = None          # [(fmt, device table, amax table or None, [entries])] - rebuilt when `_dirty`
     _dirty = True
+    _gen = object()         # identity token of the current generation of entries
 
     class Entry:
-        __slots__ = ("fmt", "version", "planes", "w", "amax", "amax_t")
+        __slots__ = ("fmt", "version", "planes", "w", "amax", "amax_t", "F", "D")
 
     @classmethod
     def _owner_died(cls, _ref):
@@ -250,6 +258,7 @@ class WeightPlanes:
         """drop the planes cached on `owner` (FlatBuffers re-points parameter storage: the old planes mirror dead memory)"""
         if owner.__dict__.pop("_npvp_planes", None) is not None:
             cls._dirty = True
+            cls._gen = object()         # voids every remembered entry (`_npvp_ent`) at once
 
     @staticmethod
     def _split(ent):
@@ -267,6 +276,13 @@ class WeightPlanes:
         """want = 'F' (forward, B = w as [N][K]) or 'D' (dgrad, B = w as [K][N]); returns (planes buffer, amax slot or None)
         or None when this weight has no planes."""
         fmt = GEMM_PRECISION
+        # fast path (a Parameter that went through the slow path before: the entry and its address are remembered on the tensor
+        # object; ~350 lookups per step)
+        hit = w.__dict__.get("_npvp_ent")
+        if hit is not None:
+            ent = hit[0]
+            if ent.fmt == fmt and hit[1] == w.data_ptr() and ent.version == w._version and hit[2] is cls._gen and cls.enabled:
+                return (ent.F if want == "F" else ent.D), ent.amax
         if not cls.enabled or fmt not in (4, 6) or w.dim() != 2 or w.shape[0] % 8 or w.shape[1] % 8 or w.stride(1) != 1:
             return None
         owner = w._base if w._base is not None else w
@@ -293,12 +309,15 @@ class WeightPlanes:
             else:
                 ent.planes = torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
                 ent.amax = ent.amax_t = None
+            ent.F, ent.D = ent.planes[0], ent.planes[1]
             cls._split(ent)
             store[key] = ent
             cls._dirty = True
         elif ent.version != w._version:
             cls._split(ent)
-        return ent.planes[0 if want == "F" else 1], ent.amax
+        if w._base is None and tuple(w.shape) == tuple(ent.w.shape):
+            w.__dict__["_npvp_ent"] = (ent, w.data_ptr(), cls._gen)
+        return (ent.F if want == "F" else ent.D), ent.amax
 
     @classmethod
     def _entries(cls):
@@ -498,20 +517,41 @@ class WgradStream:
             cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return cls._side[key]
 
+    _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
+    BATCH = max(1, int(os.environ.get("NPVP_WGRAD_BATCH", "3")))
+
     @classmethod
-    def run(cls, fn, *keep_alive):
-        """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors
-        are protected from allocator reuse until the side stream has consumed them."""
-        dev = keep_alive[0].device
-        main, side = torch.cuda.current_stream(dev), cls.stream(dev)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            fn()
-        for t in keep_alive:
-            t.record_stream(side)
+    def run(cls, fn, *keep_alive, wrote=None, urgent=False):
+        """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors are protected
+        from allocator reuse until the side stream has consumed them; `wrote` = gradient slots to report to the GradSink
+        listener once fn is enqueued.  Calls are QUEUED and handed to the side stream BATCH at a time (and when the backward
+        pass ends): one event record / wait and one stream switch per batch instead of per call - 300 of them were 8 ms of an
+        8-clip step's 42 ms of host time (c3 shard 48.5 -> 43 ms).  `urgent` hands the queue over at once: large GEMMs, whose
+        early start is worth more than the host time (c2: 257 vs 260 ms).  The inputs of fn are never written again on the main stream (they are already read
+        concurrently with later main-stream kernels), so starting it a few launches later changes no result."""
+        cls._queue.append((fn, keep_alive, wrote))
         if cls._pending is None:
-            cls._pending = (dev, side)
+            dev = keep_alive[0].device
+            cls._pending = (dev, cls.stream(dev))
             torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+        if urgent or len(cls._queue) >= cls.BATCH:
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        if not cls._queue:
+            return
+        q, cls._queue = cls._queue, []
+        dev, side = cls._pending
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for fn, _, _ in q:
+                fn()
+        for _, keep, slots in q:
+            for t in keep:
+                t.record_stream(side)
+            if slots is not None:
+                GradSink.wrote(*slots)          # (on the caller's stream: the listener orders its collective after both streams)
 
     @classmethod
     def pending_stream(cls):
@@ -524,6 +564,7 @@ class WgradStream:
         """the caller's current stream waits for the gradient stream (the autograd engine runs its final callbacks
         under the streams that were current when backward() was called)"""
         if cls._pending is not None:
+            cls.flush()
             dev, side = cls._pending
             torch.cuda.current_stream(dev).wait_stream(side)
             cls._pending = None
@@ -568,6 +609,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
     # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
     if GEMM_EXCLUSIVE and planes is not None and WgradStream._pending is not None:
+        WgradStream.flush()
         # measurement switch: a critical-path GEMM starts only when the gradient stream has drained
         torch.cuda.current_stream(A.device).wait_stream(WgradStream._pending[1])
     probe = GemmProbe.armed
@@ -759,9 +801,11 @@ def _sink_mode(sk):
 
 def _sunk_ln_reduce(sk, ws, rows, C):
     if WgradStream.enabled:
-        WgradStream.run(lambda: check(lib().npvp_layernorm_bwd_reduce(_ptr(ws), _ptr(sk[0][0]), _ptr(sk[1][0]), rows, C, 1,
-                                                                      _stream()), "npvp_layernorm_bwd_reduce"), ws)
-    GradSink.wrote(*sk)
+        # (deferred: every value is bound NOW, the closure runs a few launches later)
+        WgradStream.run(lambda ws=ws, gw=sk[0][0], gb=sk[1][0], rows=rows, C=C: check(
+            lib().npvp_layernorm_bwd_reduce(_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1, _stream()), "npvp_layernorm_bwd_reduce"), ws, wrote=sk)
+    else:
+        GradSink.wrote(*sk)
 
 
 def layernorm(x, w, b, eps=1e-5, relu=False):
@@ -937,7 +981,7 @@ class _PosFuseInstance(torch.autograd.Function):
         y = torch.empty_like(x)
         st = torch.empty(2, N * T, C, dtype=torch.float32, device=x.device)
         slot = _new_slot(x.device)
-        check(lib().npvp_posfuse_instance_fwd(_ptr(x), _ptr(add_c), _ptr(beta), _ptr(gamma_c), _ptr(y), _ptr(st[0]), _ptr(st[1]), N, T, P,
+        check(lib().npvp_posfuse_instance_fwd(_ptr(x), _ptr(add_c), _ptr(beta), _ptr(gamma_c), _ptr(y), _row(st, 0), _row(st, 1), N, T, P,
                                               C, 1e-5, _ptr(slot), _stream()), "npvp_posfuse_instance_fwd")
         tag_amax(y, slot)
         ctx.save_for_backward(x, add_c, gamma_c, st)
@@ -951,7 +995,7 @@ class _PosFuseInstance(torch.autograd.Function):
         dy = _c(dy)
         du = torch.empty_like(x)
         dyxh = torch.empty_like(x) if (gamma is not None and ctx.needs_input_grad[3]) else None
-        check(lib().npvp_posfuse_instance_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(st[0]), _ptr(st[1]), _ptr(du), _ptr(dyxh),
+        check(lib().npvp_posfuse_instance_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _row(st, 0), _row(st, 1), _ptr(du), _ptr(dyxh),
                                               N, T, P, C, _stream()), "npvp_posfuse_instance_bwd")
         PF = P * C
         dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and ctx.needs_input_grad[1]) else None
@@ -1030,12 +1074,13 @@ def _wgrad_slots(dy, x, dy_amax=None, x_amax=None):
 def _sunk_wgrad(dy, x, with_b, sk, dy_amax=None, x_amax=None):
     """accumulate dW (and db) of one linear into its gradient slots - on the wgrad stream when enabled"""
     dy_amax, x_amax = _wgrad_slots(dy, x, dy_amax, x_amax)
-    fn = lambda: linear_wgrad(dy, x, with_b, into=sk[0][0], into_b=sk[1][0] if with_b else None, dy_amax=dy_amax, x_amax=x_amax)
+    fn = lambda dy=dy, x=x, gw=sk[0][0], gb=(sk[1][0] if with_b else None), a1=dy_amax, a2=x_amax: \
+        linear_wgrad(dy, x, with_b, into=gw, into_b=gb, dy_amax=a1, x_amax=a2)
     if WgradStream.enabled:
-        WgradStream.run(fn, dy, x)
+        WgradStream.run(fn, dy, x, wrote=sk, urgent=2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] >= 3e10)
     else:
         fn()
-    GradSink.wrote(*sk)
+        GradSink.wrote(*sk)
 
 
 def _wb_sink(w, b):
@@ -1244,9 +1289,11 @@ class _FrameLnAct(torch.autograd.Function):
         tag_amax(dh, slot)
         if sk:
             if WgradStream.enabled:
-                WgradStream.run(lambda: check(L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1,
-                                                                            _stream()), "npvp_frameln_act_bwd_reduce"), ws)
-            GradSink.wrote(*sk)
+                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
+                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
+                    ws, wrote=sk)
+            else:
+                GradSink.wrote(*sk)
             dw = db = None
         return dh, dw, db, (dout if has_res else None), None, None, None, None, None, None
 
@@ -1272,12 +1319,12 @@ class _DwConv(torch.autograd.Function):
             mean = torch.empty(frames, dtype=torch.float32, device=a.device)
             rstd = torch.empty_like(mean)
             ws, wsn = _ws(frames * (Ch // 1024) * 8, a.device)
-            check(lib().npvp_dwconv3x3_stats(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), _ptr(mean), _ptr(rstd), frames, H, W,
+            check(lib().npvp_dwconv3x3_stats(_ptr(a), _ptr(wtb), _row(wtb, 9), _ptr(out), _ptr(mean), _ptr(rstd), frames, H, W,
                                              Ch, 1e-5, _ptr(ws), wsn, _stream()), "npvp_dwconv3x3_stats")
             ctx.mark_non_differentiable(mean, rstd)
             ctx.set_materialize_grads(False)
             return out, mean, rstd
-        check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _ptr(wtb[9]), _ptr(out), frames, H, W, Ch, 0, _stream()),
+        check(lib().npvp_dwconv3x3(_ptr(a), _ptr(wtb), _row(wtb, 9), _ptr(out), frames, H, W, Ch, 0, _stream()),
               "npvp_dwconv3x3")
         return out
 
@@ -1328,7 +1375,7 @@ class _MlpDwbn(torch.autograd.Function):
         gemm(1, 1, R, hid, C, x, x.stride(0), w1, w1.stride(0), h1, bias=b1, b_pre=_planes(w1, "F", R),
              rowstats=part)
         stats = torch.empty(6, frames, dtype=f32, device=dev)               # mean1, rstd1, mean2, rstd2, mean3, rstd3
-        check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _ptr(stats[0]), _ptr(stats[1]), frames, 1e-5, st),
+        check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _row(stats, 0), _row(stats, 1), frames, 1e-5, st),
               "npvp_frame_stats_finalize")
         # tap-major depthwise weights [9][hid] + bias row: rebuilt when the parameters changed (optimiser step / in-place update),
         # not per call (2 launches per MlpDWBN forward)
@@ -1344,15 +1391,15 @@ class _MlpDwbn(torch.autograd.Function):
         # fused middle
         h2 = torch.empty(R, hid, dtype=f32, device=dev)
         ws, wsn = _ws(frames * (hid // 512) * 8, dev)
-        check(L.npvp_mlpdw_mid_fwd(_ptr(h1), _ptr(stats[0]), _ptr(stats[1]), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(wtb[9]),
-                                   _ptr(h2), _ptr(stats[2]), _ptr(stats[3]), frames, 8, 8, hid, 1e-5, _ptr(ws), wsn, st),
+        check(L.npvp_mlpdw_mid_fwd(_ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _row(wtb, 9),
+                                   _ptr(h2), _row(stats, 2), _row(stats, 3), frames, 8, 8, hid, 1e-5, _ptr(ws), wsn, st),
               "npvp_mlpdw_mid_fwd")
         d2, d3, dp = Drop(p_drop), Drop(p_drop), Drop(p_dp, 1)
         DropRecorder.note(d2, "elem", R * hid)
         seed = rng.seed_tensor(dev) if (d2.on or dp.on) else None
         a2 = torch.empty(R, hid, dtype=f32, device=dev)
         a2_slot = _new_slot(dev)
-        check(L.npvp_frameln_act_fwd(_ptr(h2), _ptr(stats[2]), _ptr(stats[3]), _ptr(n2w), _ptr(n2b), _p(0), _ptr(a2), frames, PFh,
+        check(L.npvp_frameln_act_fwd(_ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _p(0), _ptr(a2), frames, PFh,
                                      d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), _ptr(a2_slot), st), "npvp_frameln_act_fwd")
         tag_amax(a2, a2_slot)
         # fc2 (+ statistics), norm3 + GELU + dropout + residual + drop-path
@@ -1360,12 +1407,12 @@ class _MlpDwbn(torch.autograd.Function):
         part3 = torch.empty(frames * (Co // 64) * 2, dtype=f32, device=dev)
         gemm(1, 1, R, Co, hid, a2, hid, w2, w2.stride(0), h3, bias=b2, b_pre=_planes(w2, "F", R),
              rowstats=part3)
-        check(L.npvp_frame_stats_finalize(_ptr(part3), Co // 64, 4096.0, _ptr(stats[4]), _ptr(stats[5]), frames, 1e-5, st),
+        check(L.npvp_frame_stats_finalize(_ptr(part3), Co // 64, 4096.0, _row(stats, 4), _row(stats, 5), frames, 1e-5, st),
               "npvp_frame_stats_finalize")
         DropRecorder.note(d3, "elem", R * Co)
         DropRecorder.note(dp, "group", frames // max(1, T))
         out = torch.empty(R, Co, dtype=f32, device=dev)
-        check(L.npvp_frameln_act_fwd(_ptr(h3), _ptr(stats[4]), _ptr(stats[5]), _ptr(n3w), _ptr(n3b), _ptr(res), _ptr(out), frames,
+        check(L.npvp_frameln_act_fwd(_ptr(h3), _row(stats, 4), _row(stats, 5), _ptr(n3w), _ptr(n3b), _ptr(res), _ptr(out), frames,
                                      PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed), _p(0), st), "npvp_frameln_act_fwd")
         ctx.save_for_backward(x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b)
         ctx.cfg = (frames, T, d2, d3, dp, res is not None, b1 is not None, b2 is not None)
@@ -1394,9 +1441,11 @@ class _MlpDwbn(torch.autograd.Function):
                   "npvp_frameln_act_bwd_apply")
         if sk:
             if WgradStream.enabled:
-                WgradStream.run(lambda: check(L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()),
-                                              "npvp_frameln_act_bwd_reduce"), ws)
-            GradSink.wrote(*sk)
+                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
+                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
+                    ws, wrote=sk)
+            else:
+                GradSink.wrote(*sk)
             return dh, None, None
         return dh, dw, db
 
@@ -1436,8 +1485,9 @@ class _MlpDwbn(torch.autograd.Function):
         # v_fmac_f32 and is reproducible without this wait (soak runs in DESIGN.md); the wait costs less than run-to-run
         # noise, so it stays on by default (NPVP_MID_BWD_FENCE=0 removes it).
         if MID_BWD_FENCE and WgradStream._pending is not None:
+            WgradStream.flush()
             torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
-        check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _ptr(stats[0]), _ptr(stats[1]), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
+        check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
                                    _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
         del dh2
         gdww = torch.empty(hid, 1, 3, 3, dtype=torch.float32, device=dev)
@@ -1471,7 +1521,7 @@ def _raw_ln_fwd(x2, w, b, eps):
     y = torch.empty_like(x2)
     st = torch.empty(2, rows, dtype=torch.float32, device=x2.device)
     slot = _new_slot(x2.device)
-    check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(st[0]), _ptr(st[1]), rows, C, eps, 0, _ptr(slot),
+    check(lib().npvp_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _row(st, 0), _row(st, 1), rows, C, eps, 0, _ptr(slot),
                                    _stream()), "npvp_layernorm_fwd")
     return tag_amax(y, slot), st
 
@@ -1484,7 +1534,7 @@ def _raw_ln_bwd(dy2, x2, w, b, st, dres, sk):
     dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
     ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
     slot = _new_slot(x2.device)
-    check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _ptr(st[0]), _ptr(st[1]), _ptr(dx), _ptr(dw), _ptr(db), rows, C,
+    check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _row(st, 0), _row(st, 1), _ptr(dx), _ptr(dw), _ptr(db), rows, C,
                                0, _ptr(dres), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
     tag_amax(dx, slot)
     if sk:
@@ -1498,7 +1548,7 @@ def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
     y = torch.empty_like(x)
     st = torch.empty(2, N * T, dtype=torch.float32, device=x.device)
     slot = _new_slot(x.device)
-    check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add), _ptr(beta), _ptr(gamma), _ptr(y), _ptr(st[0]), _ptr(st[1]), N, T, PF, 1e-5,
+    check(lib().npvp_posfuse_fwd(_ptr(x), _ptr(add), _ptr(beta), _ptr(gamma), _ptr(y), _row(st, 0), _row(st, 1), N, T, PF, 1e-5,
                                  _ptr(slot), _stream()), "npvp_posfuse_fwd")
     return tag_amax(y, slot), st
 
@@ -1509,7 +1559,7 @@ def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
     du = torch.empty_like(x)
     dyxh = torch.empty_like(x) if gamma is not None else None
     ws, wsn = _ws(8 * N * T, x.device)
-    check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(st[0]), _ptr(st[1]), _ptr(du), _ptr(dyxh), N, T, PF,
+    check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _row(st, 0), _row(st, 1), _ptr(du), _ptr(dyxh), N, T, PF,
                                  _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
     dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and want_add) else None
     dbeta = reduce_mid(dy.view(1, N, T * PF)).view(beta_shape)
