@@ -127,14 +127,19 @@ int npvp_layernorm_nchw_fwd(const float* x, const float* w, const float* b, floa
 /* ---- PosFeatFuser 'layer' (ref/models/submodules.py:432-454: GroupNorm(1,C,affine=False) over one
  * frame's C*H*W elements, then xhat*(1+gamma)+beta).  x [N*T][per_frame], add [N][per_frame] or NULL
  * (the `+ query_evt` of ref/models/VidHRFormer.py:211,236), beta/gamma [T][per_frame] (gamma NULL for
- * fuse_method 'Add').  mean/rstd [N*T] are outputs.  bwd: du = d(x+add); dyxh (nullable) = dy*uhat. */
+ * fuse_method 'Add').  mean/rstd [N*T] are outputs. */
 int npvp_frame_stats(const float* x, const float* add, float* mean, float* rstd, int frames, int T, int per_frame,
                      float eps, npvp_stream_t stream);
 int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const float* gamma, float* y, float* mean,
                      float* rstd, int N, int T, int per_frame, float eps, float* y_amax, npvp_stream_t stream);
+/* bwd: du = d(x+add) [N*T][per_frame]; dbeta / dgamma [T][per_frame] (nullable) = the sums over the batch of dy and dy*uhat (the
+ * reference's autograd sums them where beta / gamma broadcast over N).  npvp_posfuse_bwd_fused(N, T, per_frame) == 1: they come out
+ * of the apply pass itself (the batch loop runs inside the thread; dyxh is not touched and may be NULL); == 0 (few (t, e) columns,
+ * many samples): dyxh [N*T][per_frame] is scratch for dy*uhat and two reductions follow. */
+int npvp_posfuse_bwd_fused(int N, int T, int per_frame);
 int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
-                     const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
-                     long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
+                     const float* rstd, float* du, float* dyxh, float* dbeta, float* dgamma, int N, int T, int per_frame,
+                     void* workspace, long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
 
 /* param_free_norm_type = 'instance' of the same module (ref/models/submodules.py:427-431: InstanceNorm2d(affine=False), statistics
  * per (frame, channel) over the P = H*W <= 64 pixels): x [N*T][P][C] channels-last, add [N][P][C] or NULL, beta / gamma [T][P][C],
@@ -217,6 +222,10 @@ int npvp_attn_bwd(const float* q, long long ld_q, const float* k, long long ld_k
 int npvp_drop_apply(const float* x, float* out, long long rows, int ncols, float p, int mode, int g1, int g2,
                     const unsigned long long* seed, unsigned int salt, float* out_amax, npvp_stream_t stream);
 int npvp_transpose(const float* in, float* out, int batch, int R, int C, npvp_stream_t stream); /* [B][R][C]->[B][C][R] */
+/* Gradient slots of nn.Conv2d(C, C, 3, groups=C) (ref VidHRFormer.py:351-358: weight [C][1][3][3], bias [C]) from the tap-major
+ * table [10][C] (9 weight rows + the bias row) that npvp_mlpdw_mid_bwd / npvp_dwconv3x3_wgrad produce: gw[c][tap] += dwtb[tap][c],
+ * gb[c] += dwtb[9][c].  Accumulates in place (the flat gradient buffer of the optimiser). */
+int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, npvp_stream_t stream);
 int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 

@@ -177,12 +177,35 @@ extern "C" int npvp_transpose(const float* in, float* out, int batch, int R, int
   return NPVP_OK;
 }
 
-extern "C" int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
+// gradient of the depthwise 3x3 parameters out of the tap-major table the fused MlpDWBN backward produces: gw [C][9] += dwtb
+// [9][C] transposed, gb [C] += dwtb[9][:]  (one launch instead of a transpose and autograd's two accumulate adds)
+__global__ void dwtb_accumulate_kernel(const float* __restrict__ dwtb, float* __restrict__ gw, float* __restrict__ gb, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 9 * C) {
+    const int c = i / 9, tap = i - 9 * c;
+    gw[i] += dwtb[tap * C + c];
+  } else if (i < 10 * C) {
+    gb[i - 9 * C] += dwtb[i];
+  }
+}
+
+extern "C" int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, hipStream_t stream) {
+  NPVP_CHECK_ARG(C > 0 && dwtb && gw && gb, "dwtb_accumulate: bad arguments");
+  hipLaunchKernelGGL(dwtb_accumulate_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, dwtb, gw, gb, C);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
   NPVP_CHECK_ARG(A > 0 && B > 0 && Cc > 0 && Cc % 4 == 0, "reduce_mid: bad shape");
   hipLaunchKernelGGL(reduce_mid_kernel, dim3(ew_blocks((long long)A * Cc / 4, 256)), dim3(256), 0, stream, in, out, A, B, Cc,
                      scale);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
+}
+
+extern "C" int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
+  return npvp_reduce_mid_launch(in, out, A, B, Cc, scale, stream);
 }
 
 extern "C" int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {

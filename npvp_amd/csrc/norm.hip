@@ -329,6 +329,41 @@ __global__ void posfuse_bwd_apply_kernel(const float* __restrict__ dy, const flo
   }
 }
 
+// The same apply pass with the batch loop INSIDE the thread: a thread owns one float4 of (t, e) and walks the N samples, so the
+// parameter gradients d beta[t,e] = sum_n dy and d gamma[t,e] = sum_n dy * uhat are plain register sums in a fixed order - no
+// dy*uhat tensor, no second read of dy, no reduction launches (per positional fuse: 3 passes over an [R, 512] tensor and 2
+// launches less).  A block sits inside one t (per_frame / 4 is a multiple of the block size): the frame scalars are uniform.
+__global__ __launch_bounds__(256) void posfuse_bwd_apply_nsum_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                     const float* __restrict__ add, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* __restrict__ s1, const float* __restrict__ s2,
+                                                                     float* __restrict__ du, float* __restrict__ dbeta,
+                                                                     float* __restrict__ dgamma, int N, int T, int per_frame) {
+  const int pf4 = per_frame / 4;
+  const int t = blockIdx.x / (pf4 / 256), e = ((blockIdx.x % (pf4 / 256)) * 256 + threadIdx.x) * 4;
+  float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (gamma) { const float4 g0 = ld4(gamma + (long long)t * per_frame + e); gm.x += g0.x; gm.y += g0.y; gm.z += g0.z; gm.w += g0.w; }
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+#pragma unroll 4
+  for (int n = 0; n < N; ++n) {
+    const long long f = (long long)n * T + t;
+    float4 v = ld4(x + f * per_frame + e);
+    if (add) { const float4 a = ld4(add + (long long)n * per_frame + e); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    const float mu = mean[f], rs = rstd[f], a1 = s1[f], a2 = s2[f];
+    float4 uh;
+    uh.x = (v.x - mu) * rs; uh.y = (v.y - mu) * rs; uh.z = (v.z - mu) * rs; uh.w = (v.w - mu) * rs;
+    const float4 d = ld4(dy + f * per_frame + e);
+    float4 o;
+    o.x = rs * (d.x * gm.x - a1 - uh.x * a2); o.y = rs * (d.y * gm.y - a1 - uh.y * a2);
+    o.z = rs * (d.z * gm.z - a1 - uh.z * a2); o.w = rs * (d.w * gm.w - a1 - uh.w * a2);
+    st4(du + f * per_frame + e, o);
+    sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    sg.x += d.x * uh.x; sg.y += d.y * uh.y; sg.z += d.z * uh.z; sg.w += d.w * uh.w;
+  }
+  if (dbeta) st4(dbeta + (long long)t * per_frame + e, sb);
+  if (dgamma) st4(dgamma + (long long)t * per_frame + e, sg);
+}
+
 // ------------------------------------------------------------------ PosFeatFuser, param_free_norm_type = 'instance'
 // InstanceNorm2d(affine=False) over the P = H*W pixels of every (frame, channel) (ref/models/submodules.py:427-431: the
 // branch no shipped config takes), then xhat (1 + gamma) + beta as the 'layer' form.  Channels-last: thread = one channel of
@@ -650,21 +685,43 @@ extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* b
   return NPVP_OK;
 }
 
-// du [N*T, per_frame]; dyxh (nullable) receives dy*uhat for the d(gamma) reduction; ws = 2*N*T floats
+// 1 when npvp_posfuse_bwd computes d beta / d gamma inside its apply pass (the batch loop in the thread): enough (t, e) work to
+// fill the device, or so few samples that the launches saved matter more
+extern "C" int npvp_posfuse_bwd_fused(int N, int T, int per_frame) {
+  static const int off = getenv("NPVP_POSFUSE_FUSED") && atoi(getenv("NPVP_POSFUSE_FUSED")) == 0;      // A/B switch
+  if (off || per_frame % 1024 != 0) return 0;
+  const long long blocks = (long long)T * (per_frame / 1024);
+  return (blocks >= 128 || N <= 16) ? 1 : 0;
+}
+
+int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream);   // elementwise.hip
+
+// du [N*T, per_frame]; dbeta / dgamma [T, per_frame] (nullable) = sum over the batch of dy / dy*uhat; dyxh (nullable) = scratch
+// for dy*uhat, needed only when npvp_posfuse_bwd_fused(N, T, per_frame) == 0 and dgamma is wanted; ws = 2*N*T floats
 extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
-                                const float* rstd, float* du, float* dyxh, int N, int T, int per_frame, void* workspace,
-                                long long ws_bytes, hipStream_t stream) {
+                                const float* rstd, float* du, float* dyxh, float* dbeta, float* dgamma, int N, int T,
+                                int per_frame, void* workspace, long long ws_bytes, hipStream_t stream) {
   const int frames = N * T;
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse_bwd: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * 2 * 4, "posfuse_bwd: workspace too small");
+  NPVP_CHECK_ARG(!dgamma || gamma, "posfuse_bwd: dgamma without gamma");
   float* s1 = (float*)workspace; float* s2 = s1 + frames;
   hipLaunchKernelGGL(posfuse_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, dy, x, add, gamma, mean, rstd, s1, s2, T,
                      per_frame);
   NPVP_CHECK_LAUNCH();
+  if (npvp_posfuse_bwd_fused(N, T, per_frame)) {
+    hipLaunchKernelGGL(posfuse_bwd_apply_nsum_kernel, dim3(T * (per_frame / 1024)), dim3(256), 0, stream, dy, x, add, gamma, mean,
+                       rstd, (const float*)s1, (const float*)s2, du, dbeta, dgamma, N, T, per_frame);
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
+  }
+  NPVP_CHECK_ARG(!dgamma || dyxh, "posfuse_bwd: this shape needs the dy*uhat scratch (dyxh) for dgamma");
   const long long total4 = (long long)frames * per_frame / 4;
   hipLaunchKernelGGL(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
-                     rstd, (const float*)s1, (const float*)s2, du, dyxh, T, per_frame, total4);
+                     rstd, (const float*)s1, (const float*)s2, du, dgamma ? dyxh : nullptr, T, per_frame, total4);
   NPVP_CHECK_LAUNCH();
+  if (dbeta) { const int rc = npvp_reduce_mid_launch(dy, dbeta, 1, N, (long long)T * per_frame, 1.f, stream); if (rc) return rc; }
+  if (dgamma) { const int rc = npvp_reduce_mid_launch(dyxh, dgamma, 1, N, (long long)T * per_frame, 1.f, stream); if (rc) return rc; }
   return NPVP_OK;
 }
 

@@ -588,7 +588,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if b_pre is not None:
         planes, b_amax = b_pre
     if prec == 6:
-        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, 6, int(planes is not None))
+        kid = _gemm_kernel_id(a_kc, b_kc, M, N, K, 6, planes is not None)
         if kid == 5 or kid == 7:                # fp16 forward / dgrad kernel
             if a_amax is None:
                 a_amax = amax_of(A)
@@ -599,7 +599,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
                 b_amax = amax_of(B)
         else:                                   # runs as bf16x6 without planes
             planes = None
-    wsb = L.npvp_gemm_workspace_bytes(M, N, K)
+    wsb = _gemm_ws_bytes(M, N, K)
     ws, wsn = (None, 0)
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
@@ -627,6 +627,25 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, prec, int(planes is not None))
         GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), ((a_kc, b_kc), kid)))
     return out
+
+
+_KID_CACHE, _WSB_CACHE = {}, {}
+
+
+def _gemm_kernel_id(a_kc, b_kc, M, N, K, prec, has_planes):
+    """npvp_gemm_kernel_id, remembered per shape (a pure function of its arguments; one C call less per GEMM)"""
+    key = (a_kc, b_kc, M, N, K, prec, has_planes)
+    v = _KID_CACHE.get(key)
+    if v is None:
+        v = _KID_CACHE[key] = lib().npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, prec, int(has_planes))
+    return v
+
+
+def _gemm_ws_bytes(M, N, K):
+    v = _WSB_CACHE.get((M, N, K))
+    if v is None:
+        v = _WSB_CACHE[(M, N, K)] = lib().npvp_gemm_workspace_bytes(M, N, K)
+    return v
 
 
 def _planes(w, want, R):
@@ -946,19 +965,25 @@ class _PosFuse(torch.autograd.Function):
         x, add, gamma, mean, rstd = ctx.saved_tensors
         N, T, PF = ctx.N, ctx.T, ctx.PF
         dy = _c(dy)
-        du = torch.empty_like(x)
-        dyxh = torch.empty_like(x) if (gamma is not None and ctx.needs_input_grad[3]) else None
-        ws, wsn = _ws(8 * N * T, x.device)
-        check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(du),
-                                     _ptr(dyxh), N, T, PF, _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
-        dadd = dbeta = dgamma = None
-        if add is not None and ctx.needs_input_grad[1]:
-            dadd = reduce_mid(du.view(N, T, PF)).view(add.shape)
-        if ctx.needs_input_grad[2]:
-            dbeta = reduce_mid(dy.view(1, N, T * PF)).view(ctx.beta_shape)
-        if dyxh is not None:
-            dgamma = reduce_mid(dyxh.view(1, N, T * PF)).view(gamma.shape)
+        du, dbeta, dgamma = _posfuse_bwd_call(dy, x, add, gamma, mean, rstd, N, T, PF, ctx.beta_shape, ctx.needs_input_grad[2],
+                                              gamma is not None and ctx.needs_input_grad[3])
+        dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and ctx.needs_input_grad[1]) else None
         return du, dadd, dbeta, dgamma, None, None
+
+
+def _posfuse_bwd_call(dy, x, add, gamma, mean, rstd, N, T, PF, beta_shape, want_beta, want_gamma):
+    """-> du, dbeta, dgamma: one entry point; the sums over the batch come out of the apply pass when the shape allows
+    (npvp_posfuse_bwd_fused), else through a dy*uhat scratch and two reductions inside the library"""
+    L = lib()
+    du = torch.empty_like(x)
+    dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device) if want_beta else None
+    dgamma = torch.empty(gamma.shape, dtype=torch.float32, device=x.device) if want_gamma else None
+    dyxh = torch.empty_like(x) if (want_gamma and not L.npvp_posfuse_bwd_fused(N, T, PF)) else None
+    ws, wsn = _ws(8 * N * T, x.device)
+    mp, rp = (mean, rstd) if isinstance(mean, int) else (_ptr(mean), _ptr(rstd))        # (tensors or device addresses)
+    check(L.npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), mp, rp, _ptr(du), _ptr(dyxh), _ptr(dbeta),
+                             _ptr(dgamma), N, T, PF, _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
+    return du, dbeta, dgamma
 
 
 def posfuse(x, add, beta, gamma, N, T):
@@ -1066,7 +1091,7 @@ def _wgrad_slots(dy, x, dy_amax=None, x_amax=None):
     """the amax slots of a weight-gradient GEMM's operands when the fp16 kernel will take it, filled on the CURRENT stream
     (the GEMM itself may run on the gradient stream, which is ordered after this one; a slot first filled over there would
     be read here without any ordering)"""
-    if GEMM_PRECISION == 6 and lib().npvp_gemm_kernel_id(0, 0, dy.shape[1], x.shape[1], dy.shape[0], 6, 0) == 6:
+    if GEMM_PRECISION == 6 and _gemm_kernel_id(0, 0, dy.shape[1], x.shape[1], dy.shape[0], 6, False) == 6:
         return amax_of(dy, dy_amax), amax_of(x, x_amax)
     return None, None
 
@@ -1417,6 +1442,8 @@ class _MlpDwbn(torch.autograd.Function):
         ctx.save_for_backward(x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b)
         ctx.cfg = (frames, T, d2, d3, dp, res is not None, b1 is not None, b2 is not None)
         ctx.sinks = (_wb_sink(w1, b1), _wb_sink(w2, b2), _ln_sink(n1w, n1b), _ln_sink(n2w, n2b), _ln_sink(n3w, n3b))
+        sd = _wb_sink(dww, dwb) if (dww.is_contiguous() and dwb is not None) else None
+        ctx.sink_dw = sd if (sd and sd[1] is not None) else None
         return out
 
     @staticmethod
@@ -1490,9 +1517,22 @@ class _MlpDwbn(torch.autograd.Function):
         check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
                                    _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
         del dh2
-        gdww = torch.empty(hid, 1, 3, 3, dtype=torch.float32, device=dev)
-        check(L.npvp_transpose(_ptr(dwtb), _ptr(gdww), 1, 9, hid, _stream()), "npvp_transpose")
-        gdwb = dwtb[9]
+        sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
+        if sk_dw:
+            # straight into the gradient slots (on the gradient stream, like every in-place gradient write): one launch instead
+            # of a transpose on this stream and autograd's two accumulate adds
+            fn = lambda t=dwtb, gw=sk_dw[0][0], gb=sk_dw[1][0], C=hid: check(
+                L.npvp_dwtb_accumulate(_ptr(t), _ptr(gw), _ptr(gb), C, _stream()), "npvp_dwtb_accumulate")
+            if WgradStream.enabled:
+                WgradStream.run(fn, dwtb, wrote=sk_dw)
+            else:
+                fn()
+                GradSink.wrote(*sk_dw)
+            gdww = gdwb = None
+        else:
+            gdww = torch.empty(hid, 1, 3, 3, dtype=torch.float32, device=dev)
+            check(L.npvp_transpose(_ptr(dwtb), _ptr(gdww), 1, 9, hid, _stream()), "npvp_transpose")
+            gdwb = dwtb[9]
         dh1, gn1w, gn1b = F_._fln_bwd(L, da1, h1, stats[0], stats[1], n1w, n1b, frames, 64 * hid, NO_DROP, NO_DROP, 1, s_n1,
                                       psum=psum, nparts=hid // 256)
         del da1
@@ -1556,14 +1596,8 @@ def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
 def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
     """-> du [like x], dadd, dbeta, dgamma"""
     PF = x.numel() // (N * T)
-    du = torch.empty_like(x)
-    dyxh = torch.empty_like(x) if gamma is not None else None
-    ws, wsn = _ws(8 * N * T, x.device)
-    check(lib().npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), _row(st, 0), _row(st, 1), _ptr(du), _ptr(dyxh), N, T, PF,
-                                 _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
+    du, dbeta, dgamma = _posfuse_bwd_call(dy, x, add, gamma, _row(st, 0), _row(st, 1), N, T, PF, beta_shape, True, gamma is not None)
     dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and want_add) else None
-    dbeta = reduce_mid(dy.view(1, N, T * PF)).view(beta_shape)
-    dgamma = reduce_mid(dyxh.view(1, N, T * PF)).view(gamma.shape) if dyxh is not None else None
     return du, dadd, dbeta, dgamma
 
 

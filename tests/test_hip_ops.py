@@ -175,9 +175,13 @@ def test_layernorm(K, rows, relu):
         close(a, b_, what=n)
 
 
-@pytest.mark.parametrize("with_add,with_gamma", [(False, False), (True, False), (True, True)])
-def test_posfuse(K, with_add, with_gamma):
-    N, T, P, C = 3, 4, 64, 512
+@pytest.mark.parametrize("with_add,with_gamma,N,T", [(False, False, 3, 4), (True, False, 3, 4), (True, True, 3, 4), (True, True, 18, 2)])
+def test_posfuse(K, with_add, with_gamma, N, T):
+    """N = 3: the batch sums d beta / d gamma come out of the apply pass (batch loop in the thread); N = 18, T = 2 (more than 16
+    samples, few (t, e) columns - the shape of c2's encoder): the dy * uhat scratch and the two reductions inside the library"""
+    P, C = 64, 512
+    import npvp_amd
+    assert npvp_amd.ops.lib().npvp_posfuse_bwd_fused(N, T, P * C) == (1 if N == 3 else 0)
     x = (0.5 + O.seeded_randn((N * T, P, C), 41)).requires_grad_()
     add = O.seeded_randn((N, P, C), 42).requires_grad_() if with_add else None
     beta = O.seeded_randn((T * P, C), 43).requires_grad_()

@@ -64,11 +64,14 @@ def main():
     from torch.utils._python_dispatch import TorchDispatchMode
     sites = collections.Counter()
     names = collections.Counter()
+    shapes = collections.Counter()
 
     class Log(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             n = str(func)
             names[n] += 1
+            if "add" in n and args and hasattr(args[0], "shape"):
+                shapes[(n, tuple(args[0].shape), tuple(args[1].shape) if len(args) > 1 and hasattr(args[1], "shape") else None)] += 1
             if any(k in n for k in ("copy_", "add", "fill_", "zero_", "mul", "clone", "sum", "div", "sub", "cat", "zeros", "ones",
                                     "select", "_to_copy", "neg", "mean", "sqrt", "exp", "where", "stack", "index")):
                 fr = [f for f in traceback.extract_stack(limit=14) if "npvp_amd" in f.filename]
@@ -82,6 +85,9 @@ def main():
     torch.cuda.synchronize()
     for n, c in names.most_common(40):
         print(f"{c / steps:8.1f}/step  {n}")
+    print()
+    for k, c in shapes.most_common(40):
+        print(f"{c / steps:8.1f}/step  {k}")
     print()
     for (n, site), c in sites.most_common(90):
         print(f"{c / steps:8.1f}/step  {n:34s} {site}")
