@@ -228,6 +228,7 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
     frozen decoder and the target frames are given.  `opt` must be a FlatAdamW.  With sync=False nothing is
     read back (bench / graph capture) and device scalars are returned."""
     dev = past_feats.device
+    ops.WgradStream.join()            # (a backward pass that raised leaves queued weight-gradient work and an open join behind)
     ops.rng.begin_step(dev)
     opt.max_grad_norm = max_grad_norm
     opt.zero_grad()
