@@ -187,6 +187,24 @@ int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, co
                        const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H, int W,
                        int Ch, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
 int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate, npvp_stream_t stream);
+/* The same with norm2's backward inside (ref VidHRFormer.py:385-387: act2(norm2(.)) + Dropout): da2 = gradient w.r.t.
+ * a2 = drop(gelu(norm2(h2))); the kernel evaluates dh2 = rstd2 (g - s1 - hhat2 s2), g = da2 * mask * gelu'(y2) * w2n, element by
+ * element while it fills its window, so dh2 is never written or read (two passes over the [R, Ch] tensor less).  psum2
+ * [frames][nparts2 <= 256][2] = partial (sum g, sum g*hhat2) from npvp_frameln_act_bwd_pgrad, which also produces norm2's
+ * parameter gradients.  drop_p / salt / seed: the forward's elementwise dropout (0 = none). */
+int npvp_mlpdw_mid_bwd_n2(const float* da2, const float* h2, const float* mean2, const float* rstd2, const float* w2n,
+                          const float* b2n, const float* psum2, int nparts2, float drop_p, unsigned int salt,
+                          const unsigned long long* seed, const float* h1, const float* mean1, const float* rstd1,
+                          const float* w1n, const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames,
+                          int H, int W, int Ch, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* frame-LN backward WITHOUT the input gradient: psum [frames][per_frame / 1024][2] = partial (sum g, sum g*hhat) for a consumer
+ * that evaluates dh itself (npvp_mlpdw_mid_bwd_n2); dw / db, accumulate and workspace exactly as npvp_frameln_act_bwd
+ * (npvp_frameln_act_bwd_reduce applies).  per_frame % 1024 == 0. */
+int npvp_frameln_act_bwd_pgrad(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                               const float* b, float* psum, float* dw, float* db, int frames, int per_frame, float drop_p,
+                               unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
+                               const unsigned long long* seed, int accumulate, void* workspace, long long ws_bytes,
+                               npvp_stream_t stream);
 /* frame-LN backward with the statistics supplied by the producer of dout (one pass instead of two; no dropout):
  * psum [frames][nparts][2]; workspace as npvp_frameln_act_bwd. */
 int npvp_frameln_act_bwd_apply(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,

@@ -47,6 +47,10 @@ SIGNATURES = {
     "npvp_mlpdw_mid_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_mlpdw_mid_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_bwd_reduce": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
+    "npvp_mlpdw_mid_bwd_n2": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_u, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_frameln_act_bwd_pgrad": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
+                                           c_p, c_int, c_p, c_ll, c_p]),
     "npvp_frameln_act_bwd_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_im2col3x3": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_wgrad_workspace_bytes": (c_ll, [c_int, c_int]),

@@ -206,15 +206,26 @@ __global__ __launch_bounds__(256, 4) void mlpdw_mid_fwd_kernel(const float* __re
 #ifndef NPVP_MID_BWD_WAVES
 #define NPVP_MID_BWD_WAVES 2
 #endif
-template <int VEC>
+// FUSE2: `dh2` is da2, the gradient w.r.t. a2 = drop(gelu(norm2(h2))), and the kernel evaluates norm2's input gradient
+//   dh2 = rstd2 (g - s1 - hhat2 s2),  g = da2 * mask * gelu'(y2) * w2n,  (s1, s2) = frame means of (g, g*hhat2)
+// element by element as it loads the window (the frame sums arrive as n2.psum2 partials from frameln_act_bwd_pgrad_kernel): dh2
+// is never written or read - two passes over the [R, hidden] tensor less per MlpDWBN backward.
+struct MidN2 {
+  const float* h2; const float* mean2; const float* rstd2; const float* w2n; const float* b2n;
+  const float* psum2; int nparts2;
+  const unsigned long long* seed; unsigned int drop_thresh; float drop_inv_keep; unsigned int salt;
+};
+
+template <int VEC, bool FUSE2>
 __global__ __launch_bounds__(256, NPVP_MID_BWD_WAVES) void mlpdw_mid_bwd_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
                                                             const float* __restrict__ mean1, const float* __restrict__ rstd1,
                                                             const float* __restrict__ w1n, const float* __restrict__ b1n,
                                                             const float* __restrict__ wt, float* __restrict__ da1,
                                                             float* __restrict__ part, float* __restrict__ psum, int Ch,
-                                                            int frames, int frames_per_chunk) {
+                                                            int frames, int frames_per_chunk, MidN2 n2) {
   constexpr int HH = 8, WW = 8;
   __shared__ float red[4];
+  const unsigned long long seed2 = (FUSE2 && n2.seed && n2.drop_thresh) ? *n2.seed : 0ull;
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   const int nblk = gridDim.x;
   Vec<VEC> wv[9], aw[9], ab;
@@ -232,14 +243,48 @@ __global__ __launch_bounds__(256, NPVP_MID_BWD_WAVES) void mlpdw_mid_bwd_kernel(
     const float* hf = h1 + f * (HH * WW) * Ch;           // wave-uniform bases + 32-bit offsets (see the forward kernel)
     const float* gf = dh2 + f * (HH * WW) * Ch;
     float* of = da1 + f * (HH * WW) * Ch;
+    float mu2 = 0.f, rs2 = 0.f, c1 = 0.f, c2 = 0.f;
+    const float* h2f = nullptr;
+    if constexpr (FUSE2) {
+      mu2 = n2.mean2[f]; rs2 = n2.rstd2[f];
+      h2f = n2.h2 + f * (HH * WW) * Ch;
+      const int j = threadIdx.x;                          // frame sums of norm2's backward: nparts2 <= 256 partials, fixed order
+      const float p1 = j < n2.nparts2 ? n2.psum2[(f * n2.nparts2 + j) * 2] : 0.f;
+      const float p2 = j < n2.nparts2 ? n2.psum2[(f * n2.nparts2 + j) * 2 + 1] : 0.f;
+      const float inv = 1.f / (float)(HH * WW * Ch);
+      c1 = block_sum<4>(p1, red) * inv;
+      c2 = block_sum<4>(p2, red) * inv;
+    }
     // windows: a = a1 rows (h-1, h, h+1); g = dh2 rows; for the centre row also gelu'(y1) * w1n and hhat
     Vec<VEC> a0[WW], a1r[WW], a2[WW], g0[WW], g1[WW], g2[WW], gp1[WW], xh1[WW], gp2[WW], xh2[WW];
     auto load_row = [&](Vec<VEC>* arow, Vec<VEC>* grow, Vec<VEC>* gprow, Vec<VEC>* xhrow, int hh) {
+      if constexpr (FUSE2) {
+        // norm2's input gradient for the row, four pixels at a time (the scheduling fences keep the loads of a group from
+        // being hoisted over the whole row: the window already holds 10 rows of 8 values)
+#pragma unroll
+        for (int w0 = 0; w0 < WW; w0 += 4) {
+#pragma unroll
+          for (int w = w0; w < w0 + 4; ++w) {
+            const int off = (hh * WW + w) * Ch + c;
+            const Vec<VEC> d2 = ldv<VEC>(gf + off), x2 = ldv<VEC>(h2f + off), w2 = ldv<VEC>(n2.w2n + off), b2 = ldv<VEC>(n2.b2n + off);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float xh2 = (x2.v[e] - mu2) * rs2;
+              float m = 1.f;
+              if (n2.drop_thresh)
+                m = drop_scale(seed2, n2.salt, (unsigned long long)(f * (HH * WW) * Ch + off + e), n2.drop_thresh, n2.drop_inv_keep);
+              const float dyln = d2.v[e] * m * gelu_grad_f(xh2 * w2.v[e] + b2.v[e]);
+              grow[w].v[e] = rs2 * (dyln * w2.v[e] - c1 - xh2 * c2);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int w = 0; w < WW; ++w) {
         const int pix = hh * WW + w, off = pix * Ch + c;
         const Vec<VEC> x = ldv<VEC>(hf + off), ww = ldv<VEC>(w1n + off), bb = ldv<VEC>(b1n + off);
-        grow[w] = ldv<VEC>(gf + off);
+        if constexpr (!FUSE2) grow[w] = ldv<VEC>(gf + off);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float xh = (x.v[e] - mu) * rs, y = xh * ww.v[e] + bb.v[e];
@@ -537,20 +582,50 @@ extern "C" long long npvp_mlpdw_mid_bwd_workspace_bytes(int frames, int Ch) {
 // Fused MlpDWBN middle, backward: da1 (gradient w.r.t. a1 = gelu(norm1(h1)), [frames, 64, Ch]), dwt_db [10][Ch] (depthwise
 // weight taps + bias gradient, written or accumulated), and psum [frames][Ch/256][2] = the statistics norm1's backward needs
 // (pass to npvp_frameln_act_bwd_apply with nparts = Ch / 256).
-extern "C" int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, const float* rstd1, const float* w1n,
-                                  const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H,
-                                  int W, int Ch, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
+static int mid_bwd_launch(const float* dh2, const float* h1, const float* mean1, const float* rstd1, const float* w1n,
+                          const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H, int W,
+                          int Ch, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream, const MidN2* n2) {
   NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 512 == 0, "mlpdw_mid_bwd: needs an 8x8 grid and Ch % 512 == 0");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_mlpdw_mid_bwd_workspace_bytes(frames, Ch), "mlpdw_mid_bwd: workspace too small");
   const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
   // one channel per thread: the windows of a1, dh2, gelu'(y1) w1n and hhat (10 rows of 8) fit 242 VGPRs without spilling
-  hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n, b1n, wt,
-                     da1, (float*)workspace, psum, Ch, frames, fpc);
+  if (n2)
+    hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1, true>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
+                       b1n, wt, da1, (float*)workspace, psum, Ch, frames, fpc, *n2);
+  else
+    hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1, false>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
+                       b1n, wt, da1, (float*)workspace, psum, Ch, frames, fpc, MidN2{});
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;        // the caller reduces the partials (npvp_mlpdw_mid_bwd_reduce)
   const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream, accumulate);
   if (rc) { npvp_set_error("mlpdw_mid_bwd: reduce launch failed"); return rc; }
   return NPVP_OK;
+}
+
+extern "C" int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, const float* rstd1, const float* w1n,
+                                  const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H,
+                                  int W, int Ch, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
+  return mid_bwd_launch(dh2, h1, mean1, rstd1, w1n, b1n, wt, da1, dwt_db, psum, frames, H, W, Ch, accumulate, workspace, ws_bytes,
+                        stream, nullptr);
+}
+
+// The same with norm2's input gradient evaluated inside (see MidN2): da2 = gradient w.r.t. a2 = drop(gelu(norm2(h2))) with
+// elementwise dropout (drop_p, salt; 0 = none), psum2 [frames][nparts2 <= 256][2] = the partial (sum g, sum g*hhat2) that
+// npvp_frameln_act_bwd_pgrad produced for norm2.
+extern "C" int npvp_mlpdw_mid_bwd_n2(const float* da2, const float* h2, const float* mean2, const float* rstd2, const float* w2n,
+                                     const float* b2n, const float* psum2, int nparts2, float drop_p, unsigned int salt,
+                                     const unsigned long long* seed, const float* h1, const float* mean1, const float* rstd1,
+                                     const float* w1n, const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum,
+                                     int frames, int H, int W, int Ch, int accumulate, void* workspace, long long ws_bytes,
+                                     hipStream_t stream) {
+  NPVP_CHECK_ARG(h2 && mean2 && rstd2 && w2n && b2n && psum2 && nparts2 > 0 && nparts2 <= 256, "mlpdw_mid_bwd_n2: bad norm2 arguments");
+  NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "mlpdw_mid_bwd_n2: bad dropout arguments");
+  MidN2 n2;
+  n2.h2 = h2; n2.mean2 = mean2; n2.rstd2 = rstd2; n2.w2n = w2n; n2.b2n = b2n; n2.psum2 = psum2; n2.nparts2 = nparts2;
+  n2.seed = seed; n2.drop_thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  n2.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; n2.salt = salt;
+  return mid_bwd_launch(da2, h1, mean1, rstd1, w1n, b1n, wt, da1, dwt_db, psum, frames, H, W, Ch, accumulate, workspace, ws_bytes,
+                        stream, &n2);
 }
 
 extern "C" int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate,

@@ -549,6 +549,43 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
   st4(o + p.per_frame + e, ab);
 }
 
+// Statistics AND parameter gradients of the frame LayerNorm's backward in one pass, WITHOUT the input gradient: for a consumer
+// that evaluates dh = rstd (g - s1 - hhat s2) itself where it needs it (the fused MlpDWBN middle's backward does, for norm2: dh2
+// is never written).  Same thread map as frameln_act_bwd_fused_kernel (thread = 4 elements of the frame, loop over the frames
+// of a chunk: dw / db in registers); the block's share of the frame sums leaves as psum[f][blockIdx.x] = (sum g, sum g*hhat),
+// summed in fixed order by the consumer.  per_frame must be a multiple of 1024 (every thread of every block is live).
+__global__ __launch_bounds__(256) void frameln_act_bwd_pgrad_kernel(FlnParams p, const float* __restrict__ dout,
+                                                                    float* __restrict__ psum, float* __restrict__ part, int frames,
+                                                                    int frames_per_chunk) {
+  __shared__ float red[4];
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int nblk = gridDim.x;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  const float4 ww = ld4(p.w + e), bb = ld4(p.b + e);
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int f0 = blockIdx.y * frames_per_chunk;
+  const int f1 = min(frames, f0 + frames_per_chunk);
+  for (long long f = f0; f < f1; ++f) {
+    const long long g0 = f * p.per_frame + e;
+    const float mu = p.mean[f], rs = p.rstd[f];
+    const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
+    const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
+    const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
+    const float dy_ = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
+    const float dz_ = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
+    const float dw_ = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
+    aw.x += dx_ * hx; aw.y += dy_ * hy; aw.z += dz_ * hz; aw.w += dw_ * hw;
+    ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
+    const float gx = dx_ * ww.x, gy = dy_ * ww.y, gz = dz_ * ww.z, gw = dw_ * ww.w;
+    const float s1 = block_sum<4>((gx + gy) + (gz + gw), red);
+    const float s2 = block_sum<4>((gx * hx + gy * hy) + (gz * hz + gw * hw), red);
+    if (threadIdx.x == 0) { psum[(f * nblk + blockIdx.x) * 2] = s1; psum[(f * nblk + blockIdx.x) * 2 + 1] = s2; }
+  }
+  float* o = part + (long long)blockIdx.y * 2 * p.per_frame;
+  st4(o + e, aw);
+  st4(o + p.per_frame + e, ab);
+}
+
 int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, hipStream_t stream, int accum, float* out_b,
                     int split) {
   // few partial rows (frame-LN params: 32 x 262144) -> 4 row lanes of 64 columns; many partial rows over few columns
@@ -820,6 +857,32 @@ extern "C" int npvp_frameln_act_bwd_apply(const float* dout, const float* h, con
   if (accumulate == 2) return NPVP_OK;
   if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
     npvp_set_error("frameln_act_bwd_apply: reduce launch failed");
+    return NPVP_ERR_LAUNCH;
+  }
+  return NPVP_OK;
+}
+
+// Statistics and parameter gradients only (see frameln_act_bwd_pgrad_kernel): psum [frames][per_frame / 1024][2] receives the
+// partial (sum g, sum g*hhat); dw / db as npvp_frameln_act_bwd (same workspace layout: npvp_frameln_act_bwd_reduce applies).
+extern "C" int npvp_frameln_act_bwd_pgrad(const float* dout, const float* h, const float* mean, const float* rstd, const float* w,
+                                          const float* b, float* psum, float* dw, float* db, int frames, int per_frame,
+                                          float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
+                                          const unsigned long long* seed, int accumulate, void* workspace, long long ws_bytes,
+                                          hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && per_frame % 1024 == 0 && psum, "frameln_act_bwd_pgrad: per_frame must be a multiple of 1024");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_frameln_act_bwd_workspace_bytes(frames, per_frame),
+                 "frameln_act_bwd_pgrad: workspace too small");
+  FlnParams p;
+  fill_fln(p, h, mean, rstd, w, b, nullptr, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
+  float* part = (float*)workspace + (long long)frames * 2 * FLN_PARTS;
+  const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
+  const int nchunks = (frames + fpc - 1) / fpc;
+  hipLaunchKernelGGL(frameln_act_bwd_pgrad_kernel, dim3(per_frame / 1024, nchunks), dim3(256), 0, stream, p, dout, psum, part,
+                     frames, fpc);
+  NPVP_CHECK_LAUNCH();
+  if (accumulate == 2) return NPVP_OK;
+  if (launch_sum_rows((const float*)part, dw, nchunks, 2 * per_frame, 2 * per_frame, stream, accumulate, db, per_frame)) {
+    npvp_set_error("frameln_act_bwd_pgrad: reduce launch failed");
     return NPVP_ERR_LAUNCH;
   }
   return NPVP_OK;

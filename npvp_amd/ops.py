@@ -1477,6 +1477,28 @@ class _MlpDwbn(torch.autograd.Function):
         return dh, dw, db
 
     @staticmethod
+    def _fln_pgrad(L, dout, h, mean, rstd, w, b, frames, PF, d, sk):
+        """frame-LN backward without the input gradient (npvp_frameln_act_bwd_pgrad): -> psum [frames][PF/1024][2], dw, db
+        (None, None when they went into the sink); mean / rstd are device addresses"""
+        dev = h.device
+        psum = torch.empty(frames * (PF // 1024) * 2, dtype=torch.float32, device=dev)
+        dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
+        ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), dev)
+        seed = rng.seed_tensor(dev) if d.on else None
+        check(L.npvp_frameln_act_bwd_pgrad(_ptr(dout), _ptr(h), mean, rstd, _ptr(w), _ptr(b), _ptr(psum), _ptr(dw), _ptr(db),
+                                           frames, PF, d.p, d.salt, 0.0, 0, 1, _ptr(seed), _sink_mode(sk), _ptr(ws), wsn, _stream()),
+              "npvp_frameln_act_bwd_pgrad")
+        if sk:
+            if WgradStream.enabled:
+                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
+                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
+                    ws, wrote=sk)
+            else:
+                GradSink.wrote(*sk)
+            return psum, None, None
+        return psum, dw, db
+
+    @staticmethod
     def _lin_bwd(dy, x, w, sk, has_b):
         """dgrad on this stream, weight (+bias) gradient into the sink on the gradient stream or returned"""
         dx = linear_dgrad(dy, w)
@@ -1499,9 +1521,15 @@ class _MlpDwbn(torch.autograd.Function):
         F_ = _MlpDwbn
         dh3, gn3w, gn3b = F_._fln_bwd(L, dout, h3, stats[4], stats[5], n3w, n3b, frames, 64 * Co, d3, dp, T, s_n3)
         da2, gw2, gb2 = F_._lin_bwd(dh3, a2, w2, s_fc2, has_b2)
-        dh2, gn2w, gn2b = F_._fln_bwd(L, da2, h2, stats[2], stats[3], n2w, n2b, frames, 64 * hid, d2, NO_DROP, 1, s_n2,
-                                      want_amax=False)
-        del da2
+        fuse_n2 = MID_BWD_N2 and hid // 16 <= 256
+        if fuse_n2:
+            # norm2's backward WITHOUT its input gradient: frame sums (partials) + parameter gradients in one pass over da2 / h2;
+            # dh2 is evaluated inside the fused middle's backward below and never written (2 passes over [R, hidden] less)
+            psum2, gn2w, gn2b = F_._fln_pgrad(L, da2, h2, _row(stats, 2), _row(stats, 3), n2w, n2b, frames, 64 * hid, d2, s_n2)
+        else:
+            dh2, gn2w, gn2b = F_._fln_bwd(L, da2, h2, stats[2], stats[3], n2w, n2b, frames, 64 * hid, d2, NO_DROP, 1, s_n2,
+                                          want_amax=False)
+            del da2
         # fused middle backward: da1, depthwise weight / bias gradient (a1 recomputed from h1), norm1's backward statistics
         da1 = torch.empty_like(h1)
         dwtb = torch.empty(10, hid, dtype=torch.float32, device=dev)
@@ -1514,9 +1542,17 @@ class _MlpDwbn(torch.autograd.Function):
         if MID_BWD_FENCE and WgradStream._pending is not None:
             WgradStream.flush()
             torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
-        check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
-                                   _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
-        del dh2
+        if fuse_n2:
+            seed = rng.seed_tensor(dev) if d2.on else None
+            check(L.npvp_mlpdw_mid_bwd_n2(_ptr(da2), _ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _ptr(psum2),
+                                          hid // 16, d2.p, d2.salt, _ptr(seed), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w),
+                                          _ptr(n1b), _ptr(wtb), _ptr(da1), _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn,
+                                          _stream()), "npvp_mlpdw_mid_bwd_n2")
+            del da2, psum2
+        else:
+            check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
+                                       _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
+            del dh2
         sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
         if sk_dw:
             # straight into the gradient slots (on the gradient stream, like every in-place gradient write): one launch instead
@@ -1539,6 +1575,9 @@ class _MlpDwbn(torch.autograd.Function):
         dx, gw1, gb1 = F_._lin_bwd(dh1, x, w1, s_fc1, has_b1)
         return (dx, dout if has_res else None, gw1, gb1, gn1w, gn1b, gdww, gdwb, gn2w, gn2b, gw2, gb2, gn3w, gn3b,
                 None, None, None, None)
+
+
+MID_BWD_N2 = os.environ.get("NPVP_MID_BWD_N2", "1") == "1"        # A/B switch: norm2's input gradient inside the fused middle's backward
 
 
 def mlpdwbn_fused_supported(R, C, hid, Co, H, W):
