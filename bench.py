@@ -184,11 +184,12 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
         ops.GemmProbe.arm()
     fence()
     t0 = time.perf_counter()
-    host_max, host_min = 0.0, 1e9
+    host_max, host_min, host_all = 0.0, 1e9, []
     for i in range(steps):
         ti = time.perf_counter()
         out = step(warmup + i)
-        host_max, host_min = max(host_max, time.perf_counter() - ti), min(host_min, time.perf_counter() - ti)
+        host_all.append(time.perf_counter() - ti)
+        host_max, host_min = max(host_max, host_all[-1]), min(host_min, host_all[-1])
     # Python + launch time of one step.  The FASTEST step is the host's own cost (the first one after the fence finds an idle
     # GPU); the others also contain the time the launch queue makes the host wait for the GPU once it is a few thousand
     # launches ahead, i.e. they converge to the GPU's step time and say nothing about the host.
@@ -207,7 +208,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     frames = world * B * (To + Tp)
     flops_step = 3 * 2 * forward_macs_per_clip(To, Tp, P["stochastic"]) * B          # per GPU, fwd+bwd
     log(f"[{key}] {steps} timed steps: {ms:.2f} ms/step (host enqueue {1000.0 * t_host / steps:.2f} ms/step, slowest {1000.0 * host_max:.2f}), "
-        f"{frames / (ms * 1e-3):.0f} frames/s")
+        f"{frames / (ms * 1e-3):.0f} frames/s; host ms per step: " + " ".join(f"{1000.0 * h:.0f}" for h in host_all))
 
     roof = None
     if probe:
@@ -269,7 +270,8 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
         gsync.remove()
     del model, opt, gsync, past, fut, out, step
     gc.collect()
-    torch.cuda.empty_cache()
+    # (no torch.cuda.empty_cache() here: handing ~100 GB back to the driver made a LATER workload's first new allocation block the
+    # host for 3 - 4 s inside its timed steps, about one default run in five; the cached blocks are reused instead)
     return res
 
 

@@ -335,6 +335,46 @@ def test_dropout_statistics_and_replay(K):
     assert torch.equal(gx != 0, yy != 0)
 
 
+def test_mlpdwbn_backward_with_norm2_inside_the_fused_middle(K):
+    """MlpDWBN backward, dropout ON: norm2's input gradient evaluated inside the fused middle's backward (frame sums + parameter
+    gradients from npvp_frameln_act_bwd_pgrad, the dropout mask replayed element by element in npvp_mlpdw_mid_bwd_n2; dh2 never
+    written) against the separate norm2 backward + npvp_mlpdw_mid_bwd, same inputs and the same mask stream."""
+    if not K.mlpdwbn_fused_supported(6 * 64, 512, 2048, 512, 8, 8):
+        pytest.skip("the fused MlpDWBN path needs a split GEMM mode")
+    frames, T, C, hid, P = 6, 3, 512, 2048, 64
+    R = frames * P
+    mk = lambda shape, seed, sc=1.0, off=0.0: g((off + sc * O.seeded_randn(shape, seed)).requires_grad_())
+    x, res = mk((R, C), 901), mk((R, C), 902)
+    w1, b1 = mk((hid, C), 903, C ** -0.5), mk((hid,), 904, 0.1)
+    n1w, n1b = mk((P * hid,), 905, 0.1, 1.0), mk((P * hid,), 906, 0.1)
+    dww, dwb = mk((hid, 1, 3, 3), 907, 0.3), mk((hid,), 908, 0.1)
+    n2w, n2b = mk((P * hid,), 909, 0.1, 1.0), mk((P * hid,), 910, 0.1)
+    w2, b2 = mk((C, hid), 911, hid ** -0.5), mk((C,), 912, 0.1)
+    n3w, n3b = mk((P * C,), 913, 0.1, 1.0), mk((P * C,), 914, 0.1)
+    cot = O.seeded_randn((R, C), 915).to(DEV)
+    leaves = [x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b]
+    dev = torch.device(DEV)
+
+    def run(inside):
+        keep = K.MID_BWD_N2
+        K.MID_BWD_N2 = inside
+        try:
+            K.rng.manual_seed(77, dev)
+            K.rng.begin_step(dev)
+            y = K.mlpdwbn(*leaves, frames, T, 0.3, 0.2)
+            return [y.detach()] + [t.detach() for t in torch.autograd.grad(y, leaves, cot)]
+        finally:
+            K.MID_BWD_N2 = keep
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    names = ["y", "dx", "dres", "dw1", "db1", "dn1w", "dn1b", "ddww", "ddwb", "dn2w", "dn2b", "dw2", "db2", "dn3w", "dn3b"]
+    for u, v, n in zip(a, b, names):
+        e = float((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-300))
+        assert e < 2e-6, f"{n}: {e:.3e}"
+    assert float((a[1] == 0).float().mean()) < 0.5 and float(a[9].abs().sum()) > 0
+
+
 def test_attention_dropout_bwd_matches_finite_structure(K):
     """With attention dropout on, backward must replay forward's mask: check dV against a forward-mode identity
     (o is linear in v, so <cot, o(v)> = <dv, v>)."""

@@ -34,4 +34,8 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST
   -d "$OUT/g2" -o gemm -- python3 $ROOT/tools/gemm_pmc.py > /dev/null 2> "$OUT/g2.err"
 python3 $ROOT/tools/rocpd_pmc.py $(ls "$OUT"/g1/*.db | head -1) $(ls "$OUT"/g2/*.db | head -1) --filter npvp::gemm --out "$OUT/pmc_gemm_table.md" > /dev/null
 rm -rf "$OUT/g1" "$OUT/g2"
+echo "[6] kernel trace of the 8-clip shard (c4)"
+rocprofv3 --kernel-trace -d "$OUT/kt4" -o c4 -- python3 $ROOT/bench.py --steps 7 --warmup 3 --workload c4 --no-secondary --no-cpu-baseline --no-probe > "$OUT/bench_c4_profiled.json" 2> "$OUT/kt4.err"
+python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt4/*.db | head -1) "$OUT/kernel_stats_c4shard.csv" > /dev/null
+rm -rf "$OUT/kt4"
 ls -la "$OUT"
