@@ -176,10 +176,17 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up WITHOUT a synchronisation per step: the host must run ahead of the GPU here as it does in the timed region.  Blocks that
+    # the gradient stream still uses are not reusable until its events complete, so a host that is a step or two ahead needs a
+    # larger pool than a synchronised one - and with a sync after every warm-up step that pool was first grown INSIDE the timed
+    # steps: each new multi-GB hipMalloc blocked the host for 1.5 - 3 s on a box whose memory an earlier process had just released
+    # (back-to-back runs: the driver's N = 1, 2, 4, 8 sequence).  The pool also gets slack (allocated and returned to the cache).
     for i in range(warmup):
         step(i)
-        torch.cuda.synchronize()
-        log(f"[{key}] warm-up step {i} done")
+        log(f"[{key}] warm-up step {i} enqueued")
+    torch.cuda.synchronize()
+    slack = torch.empty(max(1, int(0.2 * torch.cuda.memory_reserved(dev))), dtype=torch.uint8, device=dev)
+    del slack
     if probe:
         ops.GemmProbe.arm()
     fence()
