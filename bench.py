@@ -188,7 +188,9 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     slack = torch.empty(max(1, int(0.2 * torch.cuda.memory_reserved(dev))), dtype=torch.uint8, device=dev)
     del slack
     if probe:
-        ops.GemmProbe.arm()
+        # forward / dgrad kernels of either arithmetic (ids 2, 4, 5, 7: the candidates for the dominant kernel); --probe-all also
+        # brackets the weight-gradient and small-shape launches (their event pairs cost the step ~1 %)
+        ops.GemmProbe.arm(None if args.probe_all else {2, 4, 5, 7})
     fence()
     t0 = time.perf_counter()
     host_max, host_min, host_all = 0.0, 1e9, []
@@ -258,6 +260,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
                     "mfma_pipe_busy_frac": round(mfmas * ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
                     "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel": groups,
+                    "probe": "every GEMM launch" if args.probe_all else "forward / dgrad launches of the wide kernels (--probe-all: all)",
                     "note": "achieved = ALGORITHMIC fp32-equivalent flops (2MNK) / event-pair time over every forward and dgrad "
                             f"launch of this kernel in the timed region; each product costs {mfmas} matrix instructions "
                             + ("(v_mfma_f32_32x32x16_f16 on two amax-scaled fp16 terms per operand: fp32-grade)" if f16 else
@@ -300,6 +303,7 @@ def main():
                     help="replay the step from one captured HIP graph (N=1, predictor flavour; no per-kernel probe: roofline null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--probe-all", action="store_true", help="bracket every GEMM launch with events, not only forward / dgrad")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
     args = ap.parse_args()
 

@@ -387,9 +387,13 @@ class GemmProbe:
                3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>", 5: "npvp::gemm_f16_kernel<2, 4, 2, 2>",
                6: "npvp::gemm_wgrad_f16_kernel", 7: "npvp::gemm_f16_kernel<2, 2, 2, 2>"}
 
+    only = None           # set of kernel ids to bracket (None = every GEMM launch)
+
     @classmethod
-    def arm(cls):
-        cls.armed, cls.records = True, []
+    def arm(cls, only=None):
+        """only = kernel ids to time: every event pair is a pair of marker packets that fences the launches around it, so the
+        benchmark brackets the critical-path (forward / dgrad) kernels by default and the gradient stream's on request"""
+        cls.armed, cls.records, cls.only = True, [], (None if only is None else set(only))
 
     @classmethod
     def disarm(cls):
@@ -614,6 +618,9 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         torch.cuda.current_stream(A.device).wait_stream(WgradStream._pending[1])
     probe = GemmProbe.armed
     if probe:
+        kid = _gemm_kernel_id(a_kc, b_kc, M, N, K, prec, planes is not None)
+        probe = GemmProbe.only is None or kid in GemmProbe.only
+    if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
@@ -624,7 +631,6 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
           "npvp_gemm_f32")
     if probe:
         e1.record()
-        kid = L.npvp_gemm_kernel_id(a_kc, b_kc, M, N, K, prec, int(planes is not None))
         GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), ((a_kc, b_kc), kid)))
     return out
 
