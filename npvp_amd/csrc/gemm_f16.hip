@@ -35,11 +35,20 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// x (already scaled) -> (hi, lo)
+// x (already scaled) -> (hi, lo).  Written on PAIRS so that the compiler emits, per two elements, one v_cvt_pk_f16_f32 (hi), two
+// v_cvt_f32_f16 (back), one v_pk_add_f32 (x - hi) and one v_cvt_pk_f16_f32 (lo): 5 VALU per pair - the scalar form came out as 8-9
+// (it converted one pair to fp16 twice, once packed for the store and once element by element for the subtraction).  Every VALU
+// instruction of the K loop costs its 4 cycles on top of the MFMAs' (profiles/r03_gemm_f16_latency.txt): the split is 28 of the
+// loop's 36 per step.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_f16(const f32x4 v, f16x4& hi, f16x4& lo) {
-  hi[0] = (_Float16)v[0]; hi[1] = (_Float16)v[1]; hi[2] = (_Float16)v[2]; hi[3] = (_Float16)v[3];
-  lo[0] = (_Float16)(v[0] - (float)hi[0]); lo[1] = (_Float16)(v[1] - (float)hi[1]);
-  lo[2] = (_Float16)(v[2] - (float)hi[2]); lo[3] = (_Float16)(v[3] - (float)hi[3]);
+  const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+  const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+  const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
+  const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
+  hi[0] = ha[0]; hi[1] = ha[1]; hi[2] = hb[0]; hi[3] = hb[1];
+  lo[0] = la[0]; lo[1] = la[1]; lo[2] = lb[0]; lo[3] = lb[1];
 }
 
 template <int TM, int TN, int WM, int WN, bool ROWSTATS>
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     b_dst[i] = A_BYTES + s * B_PLANE + kg * KGS_B + part * 1024;
   }
   const long long b_step = 32ll * p.N;                // bytes per K-step
+  const unsigned int lds_u32 = (unsigned int)(size_t)((lptr_t)lds);
 
   const int fa_off = h * KGS_A + (wm * TM * 32 + r) * 16;
   const int fb_off = A_BYTES + h * KGS_B + (wn * TN * 32 + r) * 16;
@@ -110,11 +120,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   { f16x4 hi_, lo_; split_f16((V) * sa, hi_, lo_);                                       \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
     *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
+  // LDS-DMA with a scalar base + 32-bit lane offset, M0 = the piece's LDS address (the builtin takes a 64-bit per-lane pointer
+  // and pays a 64-bit vector add per piece)
 #define NPVP_H_BLOAD(ST, KT)                                                             \
   { const char* bb_ = b_base + (long long)min((KT), nk - 1) * b_step;                    \
     _Pragma("unroll") for (int i_ = 0; i_ < CPW; ++i_)                                   \
-      if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK)                                   \
-        __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + b_off[i_]), (lptr_t)((ST) + b_dst[i_]), 16, 0, 0); }
+      if (NCHUNK % NW == 0 || wave + NW * i_ < NCHUNK) {                                 \
+        const unsigned int m0_ = lds_u32 + (unsigned int)((ST) - lds) + (unsigned int)b_dst[i_];          \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                     \
+                     :: "s"(m0_), "v"(b_off[i_]), "s"(bb_) : "memory", "m0"); } }
   static_assert(NCHUNK % NW == 0, "the hand-counted waits assume CPW LDS-DMA pieces per wave and step");
 
   // prologue: tile 0 -> stage 0 (B by DMA, A through the registers), A tiles 1 and 2 -> register sets
@@ -271,9 +285,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int ka = t >> 5, cqa = t & 31, kb = t >> 6, cqb = t & 63;
-  const float* a_src = A + (long long)ka * p.lda + min(m0 + 4 * cqa, p.M - 4);
-  const float* b_src = B + (long long)kb * p.ldb + min(n0 + 4 * cqb, p.N - 4);
-  const long long a_row8 = 8 * p.lda, b_row4 = 4 * p.ldb, a_step = 16 * p.lda, b_step = 16 * p.ldb;
+  // global addresses = wave-uniform base (advanced per K-step and per row group by scalar adds) + one 32-bit lane offset per
+  // operand: the loads take the scalar-base form and the loop has no 64-bit vector adds
+  const char* a_base = reinterpret_cast<const char*>(A);
+  const char* b_base = reinterpret_cast<const char*>(B);
+  const unsigned int a_voff = (unsigned int)(((long long)ka * p.lda + min(m0 + 4 * cqa, p.M - 4)) * 4);
+  const unsigned int b_voff = (unsigned int)(((long long)kb * p.ldb + min(n0 + 4 * cqb, p.N - 4)) * 4);
+  const long long a_row8 = 32 * p.lda, b_row4 = 16 * p.ldb, a_step = 64 * p.lda, b_step = 64 * p.ldb;      // bytes
   const int a_dst = ka * ROWA + ((8 * cqa) ^ ((ka & 3) << 6));
   const int b_dst = A_BYTES + kb * ROWB + ((8 * cqb) ^ ((kb & 3) << 6));
   const int q = (lane >> 2) & 3, pp = lane & 3, cg = 16 * ((lane >> 4) & 1) + 4 * pp;
@@ -288,9 +306,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   f32x4 ra[2], rb[4];
 #define NPVP_G_LOAD(KT)                                                                                     \
   { const int kt_ = min((KT), nk - 1);                                                                      \
-    const float* pa_ = a_src + (long long)kt_ * a_step; const float* pb_ = b_src + (long long)kt_ * b_step; \
-    ra[0] = *reinterpret_cast<const f32x4*>(pa_); ra[1] = *reinterpret_cast<const f32x4*>(pa_ + a_row8);    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) rb[i_] = *reinterpret_cast<const f32x4*>(pb_ + i_ * b_row4); }
+    const char* pa_ = a_base + (long long)kt_ * a_step; const char* pb_ = b_base + (long long)kt_ * b_step;  \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[0]) : "v"(a_voff), "s"(pa_) : "memory");        \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[1]) : "v"(a_voff), "s"(pa_ + a_row8) : "memory"); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                        \
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[i_]) : "v"(b_voff), "s"(pb_ + i_ * b_row4) : "memory"); }
+  // the loads are inline asm (scalar base + lane offset): waits by hand - issue order A0 A1 B0 B1 B2 B3
+#define NPVP_G_WAIT(N, ...) asm volatile("s_waitcnt vmcnt(" #N ")" : __VA_ARGS__ :: "memory");
 #define NPVP_G_STORE(DST, V, SC, PLANE)                                                                     \
   { f16x4 hi_, lo_; split_f16((V) * (SC), hi_, lo_);                                                        \
     *reinterpret_cast<f16x4*>(DST) = hi_; *reinterpret_cast<f16x4*>((DST) + (PLANE)) = lo_; }
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 #define NPVP_G_STORE_B(ST, I) NPVP_G_STORE((ST) + b_dst + (I) * 4 * ROWB, rb[I], sb, B_PLANE)
 
   NPVP_G_LOAD(0)
+  NPVP_G_WAIT(0, "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]))
   if (want_cs) cs += ra[0] + ra[1];
   NPVP_G_STORE_A(lds)
   NPVP_G_STORE_B(lds, 0) NPVP_G_STORE_B(lds, 1) NPVP_G_STORE_B(lds, 2) NPVP_G_STORE_B(lds, 3)
@@ -308,7 +331,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   {                                                                                                          \
     const char* st_ = lds + (CUR) * STAGE;                                                                   \
     char* nx_ = lds + (NXT) * STAGE;                                                                         \
-    if (want_cs && (KT) + 1 < nk) cs += ra[0] + ra[1];                                                       \
+    NPVP_G_WAIT(3, "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]))                                                    \
+    if (want_cs && (KT) + 1 < nk) { asm volatile("" ::: "memory"); cs += ra[0] + ra[1]; }  /* (a real branch: only the first tile column sums) */ \
     f16x8 fa_[TM][2];                                                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) fa_[i_][s_] = lds_read_tr_pair_h(st_ + fa[i_] + s_ * A_PLANE, 4 * ROWA); \
@@ -316,8 +340,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
       f16x8 fb_[2];                                                                                          \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) fb_[s_] = lds_read_tr_pair_h(st_ + fb[j_] + s_ * B_PLANE, 4 * ROWB); \
       if (j_ == 0) { NPVP_G_STORE_A(nx_) NPVP_G_STORE_B(nx_, 0) }                                            \
-      if (j_ == 1) { NPVP_G_STORE_B(nx_, 1) NPVP_G_STORE_B(nx_, 2) }                                         \
-      if (j_ == 2) { NPVP_G_STORE_B(nx_, 3) NPVP_G_LOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); }       \
+      if (j_ == 1) { NPVP_G_WAIT(1, "+v"(rb[1]), "+v"(rb[2])) NPVP_G_STORE_B(nx_, 1) NPVP_G_STORE_B(nx_, 2) } \
+      if (j_ == 2) { NPVP_G_WAIT(0, "+v"(rb[3])) NPVP_G_STORE_B(nx_, 3) NPVP_G_LOAD((KT) + 2) __builtin_amdgcn_sched_barrier(0); } \
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][1], fb_[0], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[1], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[i_][0], fb_[0], acc[i_][j_], 0, 0, 0); \
@@ -334,7 +358,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
     NPVP_G_STEP(kt + 1, 1, 0)
   }
   if (kt < nk) NPVP_G_STEP(kt, 0, 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the clamped loads past the last tile still target ra / rb)
 #undef NPVP_G_STEP
+#undef NPVP_G_WAIT
 #undef NPVP_G_STORE_B
 #undef NPVP_G_STORE_A
 #undef NPVP_G_STORE
