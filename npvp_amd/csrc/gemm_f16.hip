@@ -73,13 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const float sa = amax_scale(amax_slot_read(p.a_amax));
   const unsigned int cpeek = amax_peek_block(p.c_amax);
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+  f32x16 acc[TM][TN];                                 // (written by the first K-step: never zeroed)
 
   const int quad = t & 3, rl = t >> 2;
   // global addresses = wave-uniform 64-bit base (SGPRs, advanced per K-step by scalar adds) + a per-lane 32-bit byte offset that
@@ -145,7 +139,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   // one K-step: MFMAs of tile KT on stage CUR; B tile KT+1 is DMA'd into NXT; A tile KT+1 (register set R, loaded two
   // steps ago) is split and written to NXT, then R is reloaded with A tile KT+3.  RN = the set the NEXT step consumes: the
   // step's closing wait is tied to it so that nothing that reads it can be scheduled above the wait.
-#define NPVP_H_STEP(KT, CUR, NXT, R0, R1, RN0, RN1)                                                        \
+#define NPVP_H_STEP(KT, CUR, NXT, R0, R1, RN0, RN1) NPVP_H_STEP_(KT, CUR, NXT, R0, R1, RN0, RN1, false)
+  // FIRST: the step's first MFMA per accumulator takes the constant 0 as its C operand (the accumulators are never zeroed: 128
+  // v_mov less per wave and tile)
+#define NPVP_H_STEP_(KT, CUR, NXT, R0, R1, RN0, RN1, FIRST)                                                \
   {                                                                                                        \
     const char* st_ = lds + (CUR) * STAGE;                                                                 \
     char* nx_ = lds + (NXT) * STAGE;                                                                       \
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
       if (i_ == 0 && !(NPVP_H_ABL & 8)) { NPVP_H_ASTORE(nx_, R0, 0) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) } \
       if (i_ == 1 && !(NPVP_H_ABL & 2)) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                 \
       /* smallest terms first */                                                                           \
-      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], (FIRST) ? zero16 : acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
     }                                                                                                      \
@@ -171,14 +168,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
-  int kt = 0;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  NPVP_H_STEP_(0, 0, 1, ea0, ea1, eb0, eb1, true)
+  int kt = 1;
   for (; kt + 1 < nk; kt += 2) {
-    NPVP_H_STEP(kt, 0, 1, ea0, ea1, eb0, eb1)
-    NPVP_H_STEP(kt + 1, 1, 0, eb0, eb1, ea0, ea1)
+    NPVP_H_STEP(kt, 1, 0, eb0, eb1, ea0, ea1)
+    NPVP_H_STEP(kt + 1, 0, 1, ea0, ea1, eb0, eb1)
   }
-  if (kt < nk) NPVP_H_STEP(kt, 0, 1, ea0, ea1, eb0, eb1)
+  if (kt < nk) NPVP_H_STEP(kt, 1, 0, eb0, eb1, ea0, ea1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the clamped loads past the last tile)
 #undef NPVP_H_STEP
+#undef NPVP_H_STEP_
 #undef NPVP_H_BLOAD
 #undef NPVP_H_ASTORE
 #undef NPVP_H_ALOAD
