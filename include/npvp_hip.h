@@ -73,7 +73,14 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
                   const void* b_pre, int accumulate, float* rowstats, const float* a_amax, const float* b_amax,
-                  float* c_amax, void* workspace, long long ws_bytes, npvp_stream_t stream);
+                  float* c_amax, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt, void* workspace,
+                  long long ws_bytes, npvp_stream_t stream);
+/* adrop_p > 0 (precision 6, launches that npvp_gemm_kernel_id maps to the fp16 kernels 5 / 6 / 7 only; anything else is an
+ * argument error): a ROW-GROUP mask on the rows of operand A - row r is multiplied by the DropPath decision of group
+ * (r / adrop_g1) % adrop_g2 (0 or 1 / (1 - p); same (seed, salt) stream as the forward site).  This is the backward of a DropPath
+ * site (ref/models/VidHRFormer.py:513-525) without a masked copy of dy: for a dgrad (A = dy [M][K]) the mask is folded into
+ * the scale of the rows a thread stages, for a weight gradient (A = dy [K][M], adrop_g1 % 16 == 0) into the scale of the K-step,
+ * and the bias gradient colsum_a sums the masked rows. */
 /* rowstats (nullable; default precision, a_kc = b_kc = 1, bias-only epilogue, M % 64 == 0, N % 128 == 0): receives
  * [M/64][N/64][2] partial (mean, M2) statistics of the output per frame of 64 rows and block of 64 columns;
  * npvp_frame_stats_finalize turns them into the frame LayerNorm's (mean, rstd): no statistics pass over C. */

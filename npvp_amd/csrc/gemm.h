@@ -22,6 +22,8 @@ struct GemmParams {
   int M, N, K;             // K = this launch's reduction length per split
   int act;                 // 0 none 1 gelu 2 relu 3 *gelu'(aux_in) 4 *relu'(aux_in)
   DropSpec drop;
+  DropSpec adrop;          // fp16 kernels only: a ROW-GROUP mask (mode 1) on the rows of operand A (dgrad: A = dy [M][K]; weight
+                           // gradient: A = dy [K][M]) - the backward of a DropPath site without a masked copy of dy; thresh 0 = off
   int tiles_m, tiles_n;
   int splits;              // >1: raw partial tiles go to C + z*M*ldc (workspace)
   float alpha;

@@ -567,6 +567,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
                              int precision, float* colsum_a, const void* b_pre, int accumulate, float* rowstats,
                              const float* a_amax, const float* b_amax, float* c_amax,
+                             float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
                              void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   NPVP_CHECK_ARG(precision == 0 || precision == 4 || precision == 5 || precision == 6,
@@ -595,6 +596,11 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.aux_out = aux_out; p.aux_in = aux_in;
   p.seed = seed; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K; p.act = act;
   p.drop = make_drop_spec(drop_p, salt, drop_mode, drop_g1, drop_g2);
+  // row-group mask on operand A (see GemmParams::adrop): only the fp16 kernels implement it, and only with whole K-steps per group
+  NPVP_CHECK_ARG(adrop_p >= 0.f && adrop_p < 0.5f, "gemm: adrop_p must be in [0, 0.5) (the masked operand must stay inside its amax scale)");
+  NPVP_CHECK_ARG(adrop_p == 0.f || (seed && want_h && adrop_g1 > 0 && adrop_g2 > 0 && (a_kc || adrop_g1 % 16 == 0)),
+                 "gemm: adrop needs precision 6, a device seed and (for a weight gradient) groups of a multiple of 16 rows");
+  p.adrop = make_drop_spec(adrop_p, adrop_salt, 1, adrop_g1, adrop_g2);
   p.alpha = alpha;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int splits = pick_splits(M, N, K);
@@ -652,6 +658,8 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
       }
     }
   }
+
+  NPVP_CHECK_ARG(adrop_p == 0.f, "gemm: adrop was requested but this shape does not run on the fp16 kernels (npvp_gemm_kernel_id tells)");
 
   // large forward / dgrad shapes: 256 x 256 tiles (gemm_wide.hip); it declines what it is not built for
   if (b_pre && launch_gemm_wide(p, stream)) {

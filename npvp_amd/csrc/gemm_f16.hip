@@ -82,6 +82,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const unsigned int a_off0 = (unsigned int)(((long long)(min(m0 + rl, p.M - 1) - m0) * p.lda + 4 * quad) * 4);
   const unsigned int a_off1 = (unsigned int)(((long long)(min(m0 + rl + BM / 2, p.M - 1) - m0) * p.lda + 4 * quad) * 4);
   const int a_dst = (quad >> 1) * KGS_A + (quad & 1) * 8 + rl * 16;
+  // a row-group mask on A (the backward of a DropPath site): this thread stages the same two rows in every K-step, so the
+  // mask is folded into their scales once
+  float sa0 = sa, sa1 = sa;
+  if (p.adrop.thresh) {
+    const unsigned long long aseed = *p.seed;
+    sa0 *= drop_spec_scale(p.adrop, aseed, min(m0 + rl, p.M - 1), 0, 1);
+    sa1 *= drop_spec_scale(p.adrop, aseed, min(m0 + rl + BM / 2, p.M - 1), 0, 1);
+  }
   const char* b_base = reinterpret_cast<const char*>(p.b_pre);
   unsigned int b_off[CPW];
   int b_dst[CPW];
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R0) : "v"(a_off0), "s"(ab_) : "memory");          \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R1) : "v"(a_off1), "s"(ab_) : "memory"); }
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
-  { f16x4 hi_, lo_; split_f16((V) * sa, hi_, lo_);                                       \
+  { f16x4 hi_, lo_; split_f16((V) * ((ROWOFF) ? sa1 : sa0), hi_, lo_);                   \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
     *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
   // LDS-DMA with a scalar base + 32-bit lane offset, M0 = the piece's LDS address (the builtin takes a 64-bit per-lane pointer
@@ -316,12 +324,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 #define NPVP_G_STORE(DST, V, SC, PLANE)                                                                     \
   { f16x4 hi_, lo_; split_f16((V) * (SC), hi_, lo_);                                                        \
     *reinterpret_cast<f16x4*>(DST) = hi_; *reinterpret_cast<f16x4*>((DST) + (PLANE)) = lo_; }
-#define NPVP_G_STORE_A(ST) { NPVP_G_STORE((ST) + a_dst, ra[0], sa, A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], sa, A_PLANE) }
+  // a row-group mask on A = dy [K][M]: the 16 rows of a K-step belong to ONE group (g1 % 16 == 0, checked by the launcher), so the
+  // step's mask is one wave-uniform factor folded into the scale (and into the bias-gradient sums); am_ = mask of the tile in ra
+  const unsigned long long aseed = p.adrop.thresh ? *p.seed : 0ull;
+  const long long arow0 = (long long)z * p.K;
+  float am_ = 1.f;
+#define NPVP_G_AMASK(KT) { if (p.adrop.thresh) am_ = drop_spec_scale(p.adrop, aseed, arow0 + 16ll * min((KT), nk - 1), 0, 1); }
+#define NPVP_G_STORE_A(ST) { const float sam_ = sa * am_; NPVP_G_STORE((ST) + a_dst, ra[0], sam_, A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], sam_, A_PLANE) }
 #define NPVP_G_STORE_B(ST, I) NPVP_G_STORE((ST) + b_dst + (I) * 4 * ROWB, rb[I], sb, B_PLANE)
 
   NPVP_G_LOAD(0)
+  NPVP_G_AMASK(0)
   NPVP_G_WAIT(0, "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]))
-  if (want_cs) cs += ra[0] + ra[1];
+  if (want_cs) cs += (ra[0] + ra[1]) * am_;
   NPVP_G_STORE_A(lds)
   NPVP_G_STORE_B(lds, 0) NPVP_G_STORE_B(lds, 1) NPVP_G_STORE_B(lds, 2) NPVP_G_STORE_B(lds, 3)
   NPVP_G_LOAD(1)
@@ -332,7 +347,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
     const char* st_ = lds + (CUR) * STAGE;                                                                   \
     char* nx_ = lds + (NXT) * STAGE;                                                                         \
     NPVP_G_WAIT(3, "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]))                                                    \
-    if (want_cs && (KT) + 1 < nk) { asm volatile("" ::: "memory"); cs += ra[0] + ra[1]; }  /* (a real branch: only the first tile column sums) */ \
+    NPVP_G_AMASK((KT) + 1)                            /* (ra holds tile KT+1) */                             \
+    if (want_cs && (KT) + 1 < nk) { asm volatile("" ::: "memory"); cs += (ra[0] + ra[1]) * am_; }  /* (a real branch: only the first tile column sums) */ \
     f16x8 fa_[TM][2];                                                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) fa_[i_][s_] = lds_read_tr_pair_h(st_ + fa[i_] + s_ * A_PLANE, 4 * ROWA); \
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 #undef NPVP_G_WAIT
 #undef NPVP_G_STORE_B
 #undef NPVP_G_STORE_A
+#undef NPVP_G_AMASK
 #undef NPVP_G_STORE
 #undef NPVP_G_LOAD
 
@@ -429,6 +446,7 @@ int gemm_f16_variant(int M, int N, int K) {
 
 bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
   if (!p.b_pre || !p.a_amax || !p.b_amax || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return false;
+  if (p.adrop.thresh && (p.adrop.mode != 1 || !p.seed)) return false;
   const int v = gemm_f16_variant(p.M, p.N, p.K);
   if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return false;
   const int bn = v == 1 ? 256 : 128;

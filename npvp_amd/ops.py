@@ -580,11 +580,12 @@ GEMM_EXCLUSIVE = os.environ.get("NPVP_GEMM_EXCL", "0") == "1"
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None,
-         replay=False, a_amax=None, b_amax=None, c_amax=None):
+         replay=False, a_amax=None, b_amax=None, c_amax=None, a_drop=NO_DROP):
     """replay=True: `drop` replays a forward site's mask in backward (not a new site for ops.DropRecorder).
     b_pre = WeightPlanes.get(...) = (planes, weight amax slot) or None; a_amax / b_amax: the operands' amax slots (f16x3; a
     missing slot of A - or of B for a weight gradient - is filled by the stand-alone reduction); c_amax: slot that receives
-    the bound of the values stored to `out`."""
+    the bound of the values stored to `out`.  a_drop: a row-group (DropPath) mask on the rows of A - fp16 kernels only, see
+    `masked_grad`."""
     _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
     L = lib()
     prec = GEMM_PRECISION if precision is None else precision
@@ -607,7 +608,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     ws, wsn = (None, 0)
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
-    seed = rng.seed_tensor(A.device) if drop.on else None
+    seed = rng.seed_tensor(A.device) if (drop.on or a_drop.on) else None
     if DropRecorder.sites is not None and not replay:
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
@@ -627,7 +628,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
                           drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, prec, _ptr(colsum_a),
                           _ptr(planes), int(accumulate), _ptr(rowstats), _ptr(a_amax), _ptr(b_amax), _ptr(c_amax),
-                          _ptr(ws), wsn, _stream()),
+                          a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
         e1.record()
@@ -678,16 +679,35 @@ def linear_frame_stats_supported(R, N):
     return GEMM_PRECISION in (4, 6) and R % 64 == 0 and N % 128 == 0
 
 
-def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None):
-    """dx[R,K] = epilogue(dy[R,N] w[N,K])"""
+def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None, a_drop=NO_DROP):
+    """dx[R,K] = epilogue((a_drop mask on the rows of dy) dy[R,N] w[N,K])"""
     R, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
     return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop, residual=residual,
-                b_pre=_planes(w, "D", R), replay=True, a_amax=dy_amax, c_amax=dx_amax)
+                b_pre=_planes(w, "D", R), replay=True, a_amax=dy_amax, c_amax=dx_amax, a_drop=a_drop)
 
 
-def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None):
+def masked_grad(dy2, drop, w):
+    """The gradient that flows into a linear whose output went through `drop` (dropout or DropPath): -> (dz, a_drop).  A DropPath
+    (row-group) mask is handed to the dgrad and weight-gradient GEMMs as `a_drop` when both run on the fp16 kernels - they fold
+    it into the scale of the rows they stage, so no masked copy of dy is written or read (2 passes over [R, C] and one launch
+    per site); every other case applies the mask here (npvp_drop_apply)."""
+    if not drop.on:
+        return dy2, NO_DROP
+    R, N = dy2.shape
+    K = w.shape[1]
+    if (drop.mode == 1 and drop.g1 % 16 == 0 and drop.p < 0.5 and GEMM_PRECISION == 6 and DROP_PATH_IN_GEMM
+            and _planes(w, "D", R) is not None and _gemm_kernel_id(1, 0, R, K, N, 6, True) in (5, 7)
+            and _gemm_kernel_id(0, 0, N, K, R, 6, False) == 6):
+        return dy2, drop
+    return drop_apply(dy2, drop), NO_DROP
+
+
+DROP_PATH_IN_GEMM = os.environ.get("NPVP_DROP_PATH_IN_GEMM", "1") == "1"          # A/B switch
+
+
+def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None, a_drop=NO_DROP):
     """dw[N,K] = dy[R,N]^T x[R,K]; with_bias_grad also returns db[N] = column sums of dy, accumulated by the same
     kernel while it stages dy (no separate reduction pass).  into / into_b: ACCUMULATE into these existing
     gradient slices instead of allocating results (GradSink)."""
@@ -697,7 +717,7 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
     dw = into if acc else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = (into_b if acc else torch.empty(N, dtype=torch.float32, device=dy.device)) if with_bias_grad else None
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc,
-         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None, a_amax=dy_amax, b_amax=x_amax)
+         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None, a_amax=dy_amax, b_amax=x_amax, a_drop=a_drop)
     return (dw, db) if with_bias_grad else dw
 
 
@@ -1076,15 +1096,18 @@ class _Linear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         N = w.shape[0]
         dy2 = _c(dy).reshape(-1, N)
-        dz = drop_apply(dy2, ctx.drop) if ctx.drop.on else dy2
-        dx = linear_dgrad(dz, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dz, ad = masked_grad(dy2, ctx.drop, w)          # (a DropPath mask rides in the two GEMMs when they can take it)
+        else:
+            dz, ad = (drop_apply(dy2, ctx.drop) if ctx.drop.on else dy2), NO_DROP
+        dx = linear_dgrad(dz, w, a_drop=ad).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         sk = ctx.sink
         if sk and ctx.needs_input_grad[1] and want_b == (sk[1] is not None):
-            _sunk_wgrad(dz, x2, want_b, sk)
+            _sunk_wgrad(dz, x2, want_b, sk, a_drop=ad)
         elif ctx.needs_input_grad[1]:
-            dw = linear_wgrad(dz, x2, want_b)
+            dw = linear_wgrad(dz, x2, want_b, a_drop=ad)
             if want_b:
                 dw, db = dw
         elif want_b:
@@ -1102,11 +1125,11 @@ def _wgrad_slots(dy, x, dy_amax=None, x_amax=None):
     return None, None
 
 
-def _sunk_wgrad(dy, x, with_b, sk, dy_amax=None, x_amax=None):
+def _sunk_wgrad(dy, x, with_b, sk, dy_amax=None, x_amax=None, a_drop=NO_DROP):
     """accumulate dW (and db) of one linear into its gradient slots - on the wgrad stream when enabled"""
     dy_amax, x_amax = _wgrad_slots(dy, x, dy_amax, x_amax)
-    fn = lambda dy=dy, x=x, gw=sk[0][0], gb=(sk[1][0] if with_b else None), a1=dy_amax, a2=x_amax: \
-        linear_wgrad(dy, x, with_b, into=gw, into_b=gb, dy_amax=a1, x_amax=a2)
+    fn = lambda dy=dy, x=x, gw=sk[0][0], gb=(sk[1][0] if with_b else None), a1=dy_amax, a2=x_amax, ad=a_drop: \
+        linear_wgrad(dy, x, with_b, into=gw, into_b=gb, dy_amax=a1, x_amax=a2, a_drop=ad)
     if WgradStream.enabled:
         WgradStream.run(fn, dy, x, wrote=sk, urgent=2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] >= 3e10)
     else:
@@ -1160,16 +1183,16 @@ class _FFN(torch.autograd.Function):
         xn2, h, a, w1, w2 = ctx.saved_tensors
         C = xn2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
-        dz2 = drop_apply(dy2, ctx.d3) if ctx.d3.on else dy2
+        dz2, ad = masked_grad(dy2, ctx.d3, w2)
         sk = ctx.sink
         if sk:
-            dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)
-            _sunk_wgrad(dz2, a, True, sk[1])
+            dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2, a_drop=ad)
+            _sunk_wgrad(dz2, a, True, sk[1], a_drop=ad)
             dxn = linear_dgrad(dh, w1)
             _sunk_wgrad(dh, xn2, True, sk[0])
             return dxn.reshape(ctx.shape), dy, None, None, None, None, None
-        dw2, db2 = linear_wgrad(dz2, a, True)
-        dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2)
+        dw2, db2 = linear_wgrad(dz2, a, True, a_drop=ad)
+        dh = linear_dgrad(dz2, w2, act=3, aux_in=h, drop=ctx.d2, a_drop=ad)
         dw1, db1 = linear_wgrad(dh, xn2, True)
         dxn = linear_dgrad(dh, w1)
         return dxn.reshape(ctx.shape), dy, dw1, db1, dw2, db2, None
@@ -1646,13 +1669,13 @@ def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
     return du, dadd, dbeta, dgamma
 
 
-def _lin_grads(dy, x, w, b, sk):
+def _lin_grads(dy, x, w, b, sk, a_drop=NO_DROP):
     """weight (+ bias) gradient of y = x w^T + b: into the sink on the gradient stream (-> None, None) or returned"""
     has_b = b is not None
     if sk and (has_b == (sk[1] is not None)):
-        _sunk_wgrad(dy, x, has_b, sk)
+        _sunk_wgrad(dy, x, has_b, sk, a_drop=a_drop)
         return None, None
-    g = linear_wgrad(dy, x, has_b)
+    g = linear_wgrad(dy, x, has_b, a_drop=a_drop)
     return (g[0], g[1]) if has_b else (g, None)
 
 
@@ -1690,9 +1713,9 @@ class _SelfAttnSublayer(torch.autograd.Function):
         s_ln, s_qk, s_v, s_o = ctx.sinks
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
-        dz = drop_apply(dy2, drop) if drop.on else dy2
-        do = linear_dgrad(dz, wo)
-        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o)
+        dz, ad = masked_grad(dy2, drop, wo)
+        do = linear_dgrad(dz, wo, a_drop=ad)
+        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o, a_drop=ad)
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
         _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg, packed=dqk)
         dfused = linear_dgrad(dqk, wqk)
@@ -1740,9 +1763,9 @@ class _CrossAttnSublayer(torch.autograd.Function):
         s_ln, s_q, s_k, s_v, s_o = ctx.sinks
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
-        dz = drop_apply(dy2, drop) if drop.on else dy2
-        do = linear_dgrad(dz, wo)
-        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o)
+        dz, ad = masked_grad(dy2, drop, wo)
+        do = linear_dgrad(dz, wo, a_drop=ad)
+        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o, a_drop=ad)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(q, k, v, do, dq, dk, dv, cfg)
         dquery = linear_dgrad(dq, wq)
@@ -1784,10 +1807,10 @@ class _FfnSublayer(torch.autograd.Function):
         s_ln, s1, s2 = ctx.sinks
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
-        dz2 = drop_apply(dy2, d3) if d3.on else dy2
+        dz2, ad = masked_grad(dy2, d3, w2)
         dh_slot = _new_slot(dy2.device)
-        dh = tag_amax(linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2, dx_amax=dh_slot), dh_slot)
-        gw2, gb2 = _lin_grads(dz2, a, w2, b2, s2)
+        dh = tag_amax(linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2, dx_amax=dh_slot, a_drop=ad), dh_slot)
+        gw2, gb2 = _lin_grads(dz2, a, w2, b2, s2, a_drop=ad)
         dxn = linear_dgrad(dh, w1)
         gw1, gb1 = _lin_grads(dh, xn, w1, b1, s1)
         dx, glw, glb = _raw_ln_bwd(dxn, x2, lw, lb, lst, dy2, s_ln)

@@ -335,6 +335,37 @@ def test_dropout_statistics_and_replay(K):
     assert torch.equal(gx != 0, yy != 0)
 
 
+@pytest.mark.parametrize("R,g1,g2", [(4096, 512, 8), (8192, 64, 16)])
+def test_drop_path_mask_rides_in_the_gemms(K, R, g1, g2):
+    """The backward of a DropPath site: the row-group mask folded into the dgrad and weight-gradient GEMMs (a_drop: the scale of
+    the staged rows / of the K-step, bias gradient included) against the masked copy of dy (npvp_drop_apply) + plain GEMMs."""
+    from npvp_amd.ops import Drop
+    if K.GEMM_PRECISION != 6:
+        pytest.skip("a_drop is a feature of the fp16 kernels")
+    dev = torch.device(DEV)
+    N_out, K_in = 512, 512
+    K.rng.manual_seed(5, dev)
+    K.rng.begin_step(dev)
+    dy = O.seeded_randn((R, N_out), 301).to(DEV)
+    x = O.seeded_randn((R, K_in), 302).to(DEV)
+    w = torch.nn.Parameter((O.seeded_randn((N_out, K_in), 303) / K_in ** 0.5).to(DEV))
+    d = Drop(0.3, 1, g1, g2)
+    dz, ad = K.masked_grad(dy, d, w)
+    assert ad.on and dz is dy, "this shape must take the fused route"
+    dx = K.linear_dgrad(dz, w, a_drop=ad)
+    dw, db = K.linear_wgrad(dz, x, True, a_drop=ad)
+    dzm = K.drop_apply(dy, d)
+    groups = dzm.view(R // g1, -1)
+    dead = int((groups.abs().sum(1) == 0).sum())
+    assert 0 < dead < R // g1, "the mask must drop some groups and keep some"
+    dx_r = K.linear_dgrad(dzm, w)
+    dw_r, db_r = K.linear_wgrad(dzm, x, True)
+    for a, b, n in ((dx, dx_r, "dx"), (dw, dw_r, "dw"), (db, db_r, "db")):
+        e = float((a.double() - b.double()).norm() / b.double().norm())
+        assert e < 1e-6, f"{n}: {e:.3e}"
+    assert torch.equal(dx == 0, dx_r == 0), "dropped rows must be exactly zero in both routes"
+
+
 def test_mlpdwbn_backward_with_norm2_inside_the_fused_middle(K):
     """MlpDWBN backward, dropout ON: norm2's input gradient evaluated inside the fused middle's backward (frame sums + parameter
     gradients from npvp_frameln_act_bwd_pgrad, the dropout mask replayed element by element in npvp_mlpdw_mid_bwd_n2; dh2 never
