@@ -251,6 +251,8 @@ int npvp_transpose(const float* in, float* out, int batch, int R, int C, npvp_st
  * table [10][C] (9 weight rows + the bias row) that npvp_mlpdw_mid_bwd / npvp_dwconv3x3_wgrad produce: gw[c][tap] += dwtb[tap][c],
  * gb[c] += dwtb[9][c].  Accumulates in place (the flat gradient buffer of the optimiser). */
 int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, npvp_stream_t stream);
+/* forward direction: weight [C][1][3][3] + bias [C] (NULL = zeros) -> the tap-major table wtb [10][C] (9 tap rows + the bias row) */
+int npvp_dwtb_build(const float* w, const float* b, float* wtb, int C, npvp_stream_t stream);
 int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "npvp_drop_apply": (c_int, [c_p, c_p, c_ll, c_int, c_f, c_int, c_int, c_int, c_p, c_u, c_p, c_p]),
     "npvp_transpose": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_dwtb_accumulate": (c_int, [c_p, c_p, c_p, c_int, c_p]),
+    "npvp_dwtb_build": (c_int, [c_p, c_p, c_p, c_int, c_p]),
     "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_broadcast_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_colsum_workspace_bytes": (c_ll, [c_ll, c_int]),

@@ -189,6 +189,25 @@ __global__ void dwtb_accumulate_kernel(const float* __restrict__ dwtb, float* __
   }
 }
 
+// the inverse direction, forward: nn.Conv2d(C, C, 3, groups=C) parameters -> the tap-major table [10][C] the depthwise kernels read
+// (one launch for a transpose and a row copy)
+__global__ void dwtb_build_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ wtb, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 9 * C) {
+    const int tap = i / C, c = i - tap * C;
+    wtb[i] = w[c * 9 + tap];
+  } else if (i < 10 * C) {
+    wtb[i] = b ? b[i - 9 * C] : 0.f;
+  }
+}
+
+extern "C" int npvp_dwtb_build(const float* w, const float* b, float* wtb, int C, hipStream_t stream) {
+  NPVP_CHECK_ARG(C > 0 && w && wtb, "dwtb_build: bad arguments");
+  hipLaunchKernelGGL(dwtb_build_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, w, b, wtb, C);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
 extern "C" int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, hipStream_t stream) {
   NPVP_CHECK_ARG(C > 0 && dwtb && gw && gb, "dwtb_accumulate: bad arguments");
   hipLaunchKernelGGL(dwtb_accumulate_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, dwtb, gw, gb, C);

@@ -1432,15 +1432,14 @@ class _MlpDwbn(torch.autograd.Function):
         check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _row(stats, 0), _row(stats, 1), frames, 1e-5, st),
               "npvp_frame_stats_finalize")
         # tap-major depthwise weights [9][hid] + bias row: rebuilt when the parameters changed (optimiser step / in-place update),
-        # not per call (2 launches per MlpDWBN forward)
+        # not per call (one launch per MlpDWBN and step)
         key = (WeightPlanes.epoch, dww._version, dwb._version, dww.data_ptr(), dwb.data_ptr())
         hit = dww.__dict__.get("_npvp_wtb")
         if hit is not None and hit[0] == key:
             wtb = hit[1]
         else:
             wtb = torch.empty(10, hid, dtype=f32, device=dev)
-            check(L.npvp_transpose(_ptr(dww), _ptr(wtb), 1, hid, 9, st), "npvp_transpose")
-            wtb[9].copy_(dwb)
+            check(L.npvp_dwtb_build(_ptr(_c(dww)), _ptr(dwb), _ptr(wtb), hid, st), "npvp_dwtb_build")
             dww.__dict__["_npvp_wtb"] = (key, wtb)
         # fused middle
         h2 = torch.empty(R, hid, dtype=f32, device=dev)
