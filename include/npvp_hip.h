@@ -194,6 +194,9 @@ int npvp_mlpdw_mid_bwd(const float* dh2, const float* h1, const float* mean1, co
                        const float* b1n, const float* wt, float* da1, float* dwt_db, float* psum, int frames, int H, int W,
                        int Ch, int accumulate, void* workspace, long long ws_bytes, npvp_stream_t stream);
 int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate, npvp_stream_t stream);
+/* the partials of an accumulate = 2 call straight into the Conv2d parameter gradients (weight [Ch][1][3][3], bias [Ch]), in place:
+ * reduction over the chunks, transposition and accumulation in one launch */
+int npvp_mlpdw_mid_bwd_reduce_into(const void* workspace, float* gw, float* gb, int frames, int Ch, npvp_stream_t stream);
 /* The same with norm2's backward inside (ref VidHRFormer.py:385-387: act2(norm2(.)) + Dropout): da2 = gradient w.r.t.
  * a2 = drop(gelu(norm2(h2))); the kernel evaluates dh2 = rstd2 (g - s1 - hhat2 s2), g = da2 * mask * gelu'(y2) * w2n, element by
  * element while it fills its window, so dh2 is never written or read (two passes over the [R, Ch] tensor less).  psum2

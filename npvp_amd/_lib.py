@@ -48,6 +48,7 @@ SIGNATURES = {
     "npvp_mlpdw_mid_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_mlpdw_mid_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_bwd_reduce": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
+    "npvp_mlpdw_mid_bwd_reduce_into": (c_int, [c_p, c_p, c_p, c_int, c_int, c_p]),
     "npvp_mlpdw_mid_bwd_n2": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_u, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_frameln_act_bwd_pgrad": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,

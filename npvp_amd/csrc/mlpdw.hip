@@ -628,6 +628,29 @@ extern "C" int npvp_mlpdw_mid_bwd_n2(const float* da2, const float* h2, const fl
                         stream, &n2);
 }
 
+// partial sums [chunks][10][Ch] (npvp_mlpdw_mid_bwd* with accumulate = 2) -> the Conv2d parameter gradients, in place:
+// gw[c][tap] += sum_chunks part[.][tap][c], gb[c] += sum_chunks part[.][9][c]  (reduction, transposition and accumulation in ONE
+// launch: it replaces a sum_rows launch on the compute stream + npvp_dwtb_accumulate)
+__global__ void mid_bwd_reduce_into_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int Ch,
+                                           int nchunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // index into [10][Ch]
+  if (i >= 10 * Ch) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += part[(long long)k * 10 * Ch + i];
+  const int tap = i / Ch, c = i - tap * Ch;
+  if (tap < 9) gw[c * 9 + tap] += s; else gb[c] += s;
+}
+
+extern "C" int npvp_mlpdw_mid_bwd_reduce_into(const void* workspace, float* gw, float* gb, int frames, int Ch,
+                                              hipStream_t stream) {
+  NPVP_CHECK_ARG(workspace && gw && gb && frames > 0 && Ch > 0, "mlpdw_mid_bwd_reduce_into: bad arguments");
+  const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  hipLaunchKernelGGL(mid_bwd_reduce_into_kernel, dim3((10 * Ch + 255) / 256), dim3(256), 0, stream, (const float*)workspace, gw, gb,
+                     Ch, nchunks);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
 extern "C" int npvp_mlpdw_mid_bwd_reduce(const void* workspace, float* dwt_db, int frames, int Ch, int accumulate,
                                          hipStream_t stream) {
   const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;

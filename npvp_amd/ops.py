@@ -1570,25 +1570,27 @@ class _MlpDwbn(torch.autograd.Function):
         if MID_BWD_FENCE and WgradStream._pending is not None:
             WgradStream.flush()
             torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
+        sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
+        wmode = 2 if sk_dw else 0          # 2: the depthwise gradient partials stay in `ws` for the gradient stream (below)
         if fuse_n2:
             seed = rng.seed_tensor(dev) if d2.on else None
             check(L.npvp_mlpdw_mid_bwd_n2(_ptr(da2), _ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _ptr(psum2),
                                           hid // 16, d2.p, d2.salt, _ptr(seed), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w),
-                                          _ptr(n1b), _ptr(wtb), _ptr(da1), _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn,
+                                          _ptr(n1b), _ptr(wtb), _ptr(da1), _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, wmode, _ptr(ws), wsn,
                                           _stream()), "npvp_mlpdw_mid_bwd_n2")
             del da2, psum2
         else:
             check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
-                                       _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, 0, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
+                                       _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, wmode, _ptr(ws), wsn, _stream()), "npvp_mlpdw_mid_bwd")
             del dh2
-        sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
         if sk_dw:
-            # straight into the gradient slots (on the gradient stream, like every in-place gradient write): one launch instead
-            # of a transpose on this stream and autograd's two accumulate adds
-            fn = lambda t=dwtb, gw=sk_dw[0][0], gb=sk_dw[1][0], C=hid: check(
-                L.npvp_dwtb_accumulate(_ptr(t), _ptr(gw), _ptr(gb), C, _stream()), "npvp_dwtb_accumulate")
+            # straight into the gradient slots (on the gradient stream, like every in-place gradient write): the chunk partials
+            # are reduced, transposed and accumulated by ONE launch there - no reduction on this stream, no transpose, none of
+            # autograd's accumulate adds
+            fn = lambda ws=ws, gw=sk_dw[0][0], gb=sk_dw[1][0], F=frames, C=hid: check(
+                L.npvp_mlpdw_mid_bwd_reduce_into(_ptr(ws), _ptr(gw), _ptr(gb), F, C, _stream()), "npvp_mlpdw_mid_bwd_reduce_into")
             if WgradStream.enabled:
-                WgradStream.run(fn, dwtb, wrote=sk_dw)
+                WgradStream.run(fn, ws, wrote=sk_dw)
             else:
                 fn()
                 GradSink.wrote(*sk_dw)
