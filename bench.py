@@ -280,8 +280,11 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
         gsync.remove()
     del model, opt, gsync, past, fut, out, step
     gc.collect()
-    # (no torch.cuda.empty_cache() here: handing ~100 GB back to the driver made a LATER workload's first new allocation block the
-    # host for 3 - 4 s inside its timed steps, about one default run in five; the cached blocks are reused instead)
+    # The cache goes back to the driver: with c2's ~100 GB of cached blocks in the allocator the host-bound 8-clip workloads that
+    # follow ran 10 % slower (every torch.empty walks a long free list).  The multi-second stalls this once caused inside a LATER
+    # workload's timed steps (its pool grew there, and hipMalloc right after a large hipFree is slow) are closed at the other end:
+    # the warm-up now grows the pool, with slack, before the clock starts (see run_workload).
+    torch.cuda.empty_cache()
     return res
 
 

@@ -697,14 +697,17 @@ def masked_grad(dy2, drop, w):
         return dy2, NO_DROP
     R, N = dy2.shape
     K = w.shape[1]
-    if (drop.mode == 1 and drop.g1 % 16 == 0 and drop.p < 0.5 and GEMM_PRECISION == 6 and DROP_PATH_IN_GEMM
+    if (drop.mode == 1 and drop.g1 % 16 == 0 and drop.p < 0.5 and GEMM_PRECISION == 6 and R <= DROP_PATH_IN_GEMM_ROWS
             and _planes(w, "D", R) is not None and _gemm_kernel_id(1, 0, R, K, N, 6, True) in (5, 7)
             and _gemm_kernel_id(0, 0, N, K, R, 6, False) == 6):
         return dy2, drop
     return drop_apply(dy2, drop), NO_DROP
 
 
-DROP_PATH_IN_GEMM = os.environ.get("NPVP_DROP_PATH_IN_GEMM", "1") == "1"          # A/B switch
+# Up to this many token rows (the launch-bound shards: c4 36.4 -> 35.1 ms).  On the large workloads the step does not change
+# (c2: 245.6 vs 246.2 ms) and the only effect is on what shares the device with what: without the masking pass in front of it the
+# weight-gradient GEMM of the site starts earlier and runs beside its dgrad GEMM (event-pair time of the dgrad launches +10 %).
+DROP_PATH_IN_GEMM_ROWS = int(os.environ.get("NPVP_DROP_PATH_IN_GEMM_ROWS", "32768"))
 
 
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None, a_drop=NO_DROP):
