@@ -271,6 +271,57 @@ __global__ void posfuse_apply_kernel(const float* __restrict__ x, const float* _
   amax_slot_commit_block(amax, am, ared, peek);
 }
 
+// The positional fuse forward in ONE pass for frames that fit a block's registers (8 x 8 x 512 floats = 32 per thread of 1024):
+// load the frame (+ add), exact two-pass statistics on the registers, apply, store.  One read of x instead of two and one launch
+// instead of two (frame_stats_kernel + posfuse_apply_kernel).
+template <int NV4>
+__global__ __launch_bounds__(1024) void posfuse_fwd_frame_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                                 const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                                 float* __restrict__ y, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int T, float eps, float* __restrict__ amax) {
+  constexpr int PF = NV4 * 4096;
+  __shared__ float red[16];
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  const int f = blockIdx.x, n = f / T, t = f - n * T;
+  const float* xf = x + (long long)f * PF;
+  const float* af = add ? add + (long long)n * PF : nullptr;
+  float4 v[NV4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) {
+    const int e = (k * 1024 + threadIdx.x) * 4;
+    v[k] = ld4(xf + e);
+    if (af) { const float4 a = ld4(af + e); v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w; }
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mu = block_sum<16>(s, red) * (1.f / PF);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) {
+    const float a0 = v[k].x - mu, a1 = v[k].y - mu, a2 = v[k].z - mu, a3 = v[k].w - mu;
+    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  const float rs = rsqrtf(block_sum<16>(q, red) * (1.f / PF) + eps);
+  if (threadIdx.x == 0) { mean[f] = mu; rstd[f] = rs; }
+  float am = 0.f;
+  const float* bt = beta + (long long)t * PF;
+  const float* gt = gamma ? gamma + (long long)t * PF : nullptr;
+  float* yf = y + (long long)f * PF;
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) {
+    const int e = (k * 1024 + threadIdx.x) * 4;
+    float4 o;
+    o.x = (v[k].x - mu) * rs; o.y = (v[k].y - mu) * rs; o.z = (v[k].z - mu) * rs; o.w = (v[k].w - mu) * rs;
+    if (gt) { const float4 g = ld4(gt + e); o.x *= 1.f + g.x; o.y *= 1.f + g.y; o.z *= 1.f + g.z; o.w *= 1.f + g.w; }
+    const float4 b = ld4(bt + e);
+    o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    st4(yf + e, o);
+    am = amax4(am, o);
+  }
+  amax_slot_commit_block(amax, am, ared, peek);
+}
+
 // backward statistics: s1[f] = mean(g), s2[f] = mean(g * uhat), g = dy * (1 + gamma)
 __global__ __launch_bounds__(512) void posfuse_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ add,
@@ -713,6 +764,13 @@ extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* b
                                 float* mean, float* rstd, int N, int T, int per_frame, float eps, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse: bad shape");
   const int frames = N * T;
+  static const int one_pass = !(getenv("NPVP_POSFUSE_ONE_PASS") && atoi(getenv("NPVP_POSFUSE_ONE_PASS")) == 0);      // A/B switch
+  if (one_pass && per_frame == 32768) {          // 8 x 8 x 512: the frame lives in the block's registers
+    hipLaunchKernelGGL((posfuse_fwd_frame_kernel<8>), dim3(frames), dim3(1024), 0, stream, x, add, beta, gamma, y, mean, rstd, T,
+                       eps, amax);
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
+  }
   hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
   NPVP_CHECK_LAUNCH();
   const long long total4 = (long long)frames * per_frame / 4;
