@@ -186,6 +186,18 @@ int npvp_dwconv3x3_stats(const float* a, const float* wt, const float* bias, flo
 int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const float* rstd1, const float* w1n, const float* b1n,
                        const float* wt, const float* bias, float* h2, float* mean2, float* rstd2, int frames, int H, int W,
                        int Ch, float eps, void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* The forward of MlpDWBN's middle and of its frame LayerNorms WITHOUT statistics launches: the consumer merges the partial
+ * (mean_j, M2_j) pairs its producer left (part [frames][J][2], nb values per partial) and writes mean / rstd (outputs, for backward).
+ * npvp_mlpdw_mid_fwd_parts: part1 = the rowstats of the fc1 GEMM (J1 = Ch / 64, nb1 = 4096); part2 [frames][Ch / 512][2] (32 768
+ * values each) receives h2's partials.  npvp_frameln_act_fwd_parts: npvp_frameln_act_fwd with (part, J, nb, eps) in, mean / rstd
+ * out; per_frame % 4096 == 0. */
+int npvp_mlpdw_mid_fwd_parts(const float* h1, const float* part1, int J1, float nb1, float* mean1, float* rstd1, const float* w1n,
+                             const float* b1n, const float* wt, const float* bias, float* h2, float* part2, int frames, int H,
+                             int W, int Ch, float eps, npvp_stream_t stream);
+int npvp_frameln_act_fwd_parts(const float* h, const float* part, int J, float nb, float eps, float* mean, float* rstd,
+                               const float* w, const float* b, const float* res, float* out, int frames, int per_frame,
+                               float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt, int frames_per_sample,
+                               const unsigned long long* seed, float* out_amax, npvp_stream_t stream);
 /* Backward: da1 = conv^T(dh2); dwt_db [10][Ch] (9 tap rows + bias row; accumulate 1: +=, 2: leave the partials in workspace
  * for npvp_mlpdw_mid_bwd_reduce) with a1 recomputed from h1; psum [frames][Ch/256][2] = partial (sum g, sum g*hhat),
  * g = da1 * gelu'(y1) * w1n: the statistics of norm1's backward (npvp_frameln_act_bwd_apply, nparts = Ch/256). */

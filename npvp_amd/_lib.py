@@ -45,6 +45,9 @@ SIGNATURES = {
     "npvp_dwconv3x3": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
     "npvp_dwconv3x3_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_ll, c_p]),
+    "npvp_mlpdw_mid_fwd_parts": (c_int, [c_p, c_p, c_int, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p]),
+    "npvp_frameln_act_fwd_parts": (c_int, [c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
+                                           c_p, c_p, c_p]),
     "npvp_mlpdw_mid_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_mlpdw_mid_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_mlpdw_mid_bwd_reduce": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),

@@ -137,6 +137,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// mean / rstd of a frame from the J partial (mean_j, M2_j) pairs its producer left (each over nb values): exactly the arithmetic
+// of frame_stats_finalize_kernel, evaluated by the CONSUMER (wave-uniform loads) instead of a launch of its own
+__device__ __forceinline__ void frame_stats_merge(const float* __restrict__ part, long long f, int J, float nb, float eps, float& mu,
+                                                  float& rs) {
+  float m = 0.f;
+  for (int j = 0; j < J; ++j) m += part[(f * J + j) * 2];
+  m /= J;
+  float m2 = 0.f;
+  for (int j = 0; j < J; ++j) { const float d = part[(f * J + j) * 2] - m; m2 += part[(f * J + j) * 2 + 1] + nb * d * d; }
+  mu = m;
+  rs = rsqrtf(m2 / (nb * J) + eps);
+}
+
 // erf-GELU (nn.GELU default) and its derivative.  libm's erff costs ~45 VALU instructions with divergent branches and
 // made the frame-LN kernels VALU bound (frame-LN backward statistics: 94 us for 336 MB = 3.6 TB/s).  Phi(x) is
 // evaluated branch-free from ONE exponential shared with the density:

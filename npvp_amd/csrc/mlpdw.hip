@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256, 4) void mlpdw_mid_fwd_kernel(const float* __re
                                                             const float* __restrict__ rstd1, const float* __restrict__ w1n,
                                                             const float* __restrict__ b1n, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ h2,
-                                                            float* __restrict__ part, int Ch) {
+                                                            float* __restrict__ part, int Ch, const float* __restrict__ part1,
+                                                            int J1, float nb1, float eps1, float* __restrict__ mean1_out,
+                                                            float* __restrict__ rstd1_out) {
   constexpr int HH = 8, WW = 8;
   __shared__ float red[4];
   // a block lies inside one frame ((Ch / VEC) % 256 == 0): the frame base is wave-uniform (SGPR pair) and every access is
@@ -139,7 +141,11 @@ __global__ __launch_bounds__(256, 4) void mlpdw_mid_fwd_kernel(const float* __re
   const int bpf = Ch / VEC / 256;                                   // blocks per frame
   const long long f = blockIdx.x / bpf;
   const int c = ((blockIdx.x - (int)f * bpf) * 256 + threadIdx.x) * VEC;
-  const float mu = mean1[f], rs = rstd1[f];
+  float mu, rs;
+  if (part1) {          // norm1's statistics from the partials the fc1 GEMM's epilogue left (no finalize launch); saved for backward
+    frame_stats_merge(part1, f, J1, nb1, eps1, mu, rs);
+    if (blockIdx.x == f * bpf && threadIdx.x == 0) { mean1_out[f] = mu; rstd1_out[f] = rs; }
+  } else { mu = mean1[f]; rs = rstd1[f]; }
   Vec<VEC> wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wv[t] = ldv<VEC>(wt + t * Ch + c);
@@ -564,10 +570,26 @@ extern "C" int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const flo
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * J * 8, "mlpdw_mid_fwd: workspace too small");
   const long long nthreads = (long long)frames * (Ch / 2);
   hipLaunchKernelGGL((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, mean1, rstd1, w1n, b1n,
-                     wt, bias, h2, (float*)workspace, Ch);
+                     wt, bias, h2, (float*)workspace, Ch, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr, (float*)nullptr);
   NPVP_CHECK_LAUNCH();
   hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
                      32768.f, mean2, rstd2, frames, eps);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// The same without either statistics launch: norm1's statistics come as the partials part1 [frames][J1][2] (over nb1 values each)
+// that the fc1 GEMM's epilogue left (rowstats of npvp_gemm_f32: J1 = Ch / 64, nb1 = 4096) and are merged by every block for its
+// frame (mean1 / rstd1 are OUTPUTS here, for backward); h2's partials part2 [frames][Ch / 512][2] (32 768 values each) are left
+// for npvp_frameln_act_fwd_parts.
+extern "C" int npvp_mlpdw_mid_fwd_parts(const float* h1, const float* part1, int J1, float nb1, float* mean1, float* rstd1,
+                                        const float* w1n, const float* b1n, const float* wt, const float* bias, float* h2,
+                                        float* part2, int frames, int H, int W, int Ch, float eps, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 512 == 0, "mlpdw_mid_fwd_parts: needs an 8x8 grid and Ch % 512 == 0");
+  NPVP_CHECK_ARG(part1 && J1 > 0 && nb1 > 0.f && mean1 && rstd1 && part2, "mlpdw_mid_fwd_parts: bad arguments");
+  const long long nthreads = (long long)frames * (Ch / 2);
+  hipLaunchKernelGGL((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, (const float*)nullptr,
+                     (const float*)nullptr, w1n, b1n, wt, bias, h2, part2, Ch, part1, J1, nb1, eps, mean1, rstd1);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

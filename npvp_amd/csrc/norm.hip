@@ -528,6 +528,40 @@ __global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out, flo
   amax_slot_commit_block(amax, am, ared, peek);
 }
 
+// The same with the frame statistics merged in the kernel from the producer's partials (no finalize launch): a block handles
+// 4096 consecutive elements of ONE frame (per_frame % 4096 == 0), merges the frame's J partial pairs, and the frame's first
+// block leaves mean / rstd for backward.
+__global__ __launch_bounds__(256) void frameln_act_fwd_parts_kernel(FlnParams p, const float* __restrict__ part, int J, float nb,
+                                                                    float eps, float* __restrict__ mean_out,
+                                                                    float* __restrict__ rstd_out, float* __restrict__ out,
+                                                                    float* __restrict__ amax) {
+  __shared__ float ared[16];
+  const unsigned int peek = amax_peek_block(amax);
+  const int bpf = p.per_frame / 4096;
+  const long long f = blockIdx.x / bpf;
+  const int e0 = (blockIdx.x - (int)f * bpf) * 4096;
+  const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
+  float mu, rs;
+  frame_stats_merge(part, f, J, nb, eps, mu, rs);
+  if (e0 == 0 && threadIdx.x == 0) { mean_out[f] = mu; rstd_out[f] = rs; }
+  float am = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = e0 + (k * 256 + threadIdx.x) * 4;
+    const long long g0 = f * p.per_frame + e;
+    const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e);
+    float4 o;
+    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, f, g0 + 0);
+    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, f, g0 + 1);
+    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, f, g0 + 2);
+    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, f, g0 + 3);
+    if (p.res) { const float4 r = ld4(p.res + g0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    st4(out + g0, o);
+    am = amax4(am, o);
+  }
+  amax_slot_commit_block(amax, am, ared, peek);
+}
+
 // dy_ln = dout * scale * gelu'(y);  g = dy_ln * w;  s1 = mean(g), s2 = mean(g*hhat)
 constexpr int FLN_PARTS = 4;     // blocks per frame in the backward statistics pass
 __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p, const float* __restrict__ dout,
@@ -850,6 +884,23 @@ extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const flo
   FlnParams p;
   fill_fln(p, h, mean, rstd, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
   hipLaunchKernelGGL(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out, amax);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// frame statistics from the producer's partials part [frames][J][2] (mean_j, M2_j over nb values each: the rowstats of
+// npvp_gemm_f32 or the part2 of npvp_mlpdw_mid_fwd_parts); mean / rstd [frames] are OUTPUTS (for backward).  per_frame % 4096 == 0.
+extern "C" int npvp_frameln_act_fwd_parts(const float* h, const float* part, int J, float nb, float eps, float* mean, float* rstd,
+                                          const float* w, const float* b, const float* res, float* out, int frames,
+                                          int per_frame, float drop_p, unsigned int salt, float dp_p, unsigned int dp_salt,
+                                          int frames_per_sample, const unsigned long long* seed, float* amax, hipStream_t stream) {
+  NPVP_CHECK_ARG(frames > 0 && per_frame % 4096 == 0 && part && J > 0 && nb > 0.f && mean && rstd, "frameln_act_fwd_parts: bad arguments");
+  NPVP_CHECK_ARG((drop_p == 0.f && dp_p == 0.f) || seed, "frameln_act: dropout needs a device seed");
+  NPVP_CHECK_ARG((long long)frames * (per_frame / 4096) < (1ll << 31), "frameln_act_fwd_parts: too many blocks");
+  FlnParams p;
+  fill_fln(p, h, nullptr, nullptr, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
+  hipLaunchKernelGGL(frameln_act_fwd_parts_kernel, dim3((unsigned)((long long)frames * (per_frame / 4096))), dim3(256), 0, stream, p,
+                     part, J, nb, eps, mean, rstd, out, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

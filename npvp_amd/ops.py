@@ -1432,8 +1432,8 @@ class _MlpDwbn(torch.autograd.Function):
         gemm(1, 1, R, hid, C, x, x.stride(0), w1, w1.stride(0), h1, bias=b1, b_pre=_planes(w1, "F", R),
              rowstats=part)
         stats = torch.empty(6, frames, dtype=f32, device=dev)               # mean1, rstd1, mean2, rstd2, mean3, rstd3
-        check(L.npvp_frame_stats_finalize(_ptr(part), hid // 64, 4096.0, _row(stats, 0), _row(stats, 1), frames, 1e-5, st),
-              "npvp_frame_stats_finalize")
+        # (no statistics launches: each consumer below merges the partial (mean, M2) pairs its producer left and writes
+        # mean / rstd into `stats` for backward)
         # tap-major depthwise weights [9][hid] + bias row: rebuilt when the parameters changed (optimiser step / in-place update),
         # not per call (one launch per MlpDWBN and step)
         key = (WeightPlanes.epoch, dww._version, dwb._version, dww.data_ptr(), dwb.data_ptr())
@@ -1446,30 +1446,30 @@ class _MlpDwbn(torch.autograd.Function):
             dww.__dict__["_npvp_wtb"] = (key, wtb)
         # fused middle
         h2 = torch.empty(R, hid, dtype=f32, device=dev)
-        ws, wsn = _ws(frames * (hid // 512) * 8, dev)
-        check(L.npvp_mlpdw_mid_fwd(_ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _row(wtb, 9),
-                                   _ptr(h2), _row(stats, 2), _row(stats, 3), frames, 8, 8, hid, 1e-5, _ptr(ws), wsn, st),
-              "npvp_mlpdw_mid_fwd")
+        part2 = torch.empty(frames * (hid // 512) * 2, dtype=f32, device=dev)
+        check(L.npvp_mlpdw_mid_fwd_parts(_ptr(h1), _ptr(part), hid // 64, 4096.0, _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b),
+                                         _ptr(wtb), _row(wtb, 9), _ptr(h2), _ptr(part2), frames, 8, 8, hid, 1e-5, st),
+              "npvp_mlpdw_mid_fwd_parts")
         d2, d3, dp = Drop(p_drop), Drop(p_drop), Drop(p_dp, 1)
         DropRecorder.note(d2, "elem", R * hid)
         seed = rng.seed_tensor(dev) if (d2.on or dp.on) else None
         a2 = torch.empty(R, hid, dtype=f32, device=dev)
         a2_slot = _new_slot(dev)
-        check(L.npvp_frameln_act_fwd(_ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _p(0), _ptr(a2), frames, PFh,
-                                     d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), _ptr(a2_slot), st), "npvp_frameln_act_fwd")
+        check(L.npvp_frameln_act_fwd_parts(_ptr(h2), _ptr(part2), hid // 512, 32768.0, 1e-5, _row(stats, 2), _row(stats, 3), _ptr(n2w),
+                                           _ptr(n2b), None, _ptr(a2), frames, PFh, d2.p, d2.salt, 0.0, 0, 1, _ptr(seed), _ptr(a2_slot),
+                                           st), "npvp_frameln_act_fwd_parts")
         tag_amax(a2, a2_slot)
         # fc2 (+ statistics), norm3 + GELU + dropout + residual + drop-path
         h3 = torch.empty(R, Co, dtype=f32, device=dev)
         part3 = torch.empty(frames * (Co // 64) * 2, dtype=f32, device=dev)
         gemm(1, 1, R, Co, hid, a2, hid, w2, w2.stride(0), h3, bias=b2, b_pre=_planes(w2, "F", R),
              rowstats=part3)
-        check(L.npvp_frame_stats_finalize(_ptr(part3), Co // 64, 4096.0, _row(stats, 4), _row(stats, 5), frames, 1e-5, st),
-              "npvp_frame_stats_finalize")
         DropRecorder.note(d3, "elem", R * Co)
         DropRecorder.note(dp, "group", frames // max(1, T))
         out = torch.empty(R, Co, dtype=f32, device=dev)
-        check(L.npvp_frameln_act_fwd(_ptr(h3), _row(stats, 4), _row(stats, 5), _ptr(n3w), _ptr(n3b), _ptr(res), _ptr(out), frames,
-                                     PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed), _p(0), st), "npvp_frameln_act_fwd")
+        check(L.npvp_frameln_act_fwd_parts(_ptr(h3), _ptr(part3), Co // 64, 4096.0, 1e-5, _row(stats, 4), _row(stats, 5), _ptr(n3w),
+                                           _ptr(n3b), _ptr(res), _ptr(out), frames, PFo, d3.p, d3.salt, dp.p, dp.salt, T, _ptr(seed),
+                                           None, st), "npvp_frameln_act_fwd_parts")
         ctx.save_for_backward(x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b)
         ctx.cfg = (frames, T, d2, d3, dp, res is not None, b1 is not None, b2 is not None)
         ctx.sinks = (_wb_sink(w1, b1), _wb_sink(w2, b2), _ln_sink(n1w, n1b), _ln_sink(n2w, n2b), _ln_sink(n3w, n3b))
