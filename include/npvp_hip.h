@@ -143,6 +143,12 @@ int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const 
  * reference's autograd sums them where beta / gamma broadcast over N).  npvp_posfuse_bwd_fused(N, T, per_frame) == 1: they come out
  * of the apply pass itself (the batch loop runs inside the thread; dyxh is not touched and may be NULL); == 0 (few (t, e) columns,
  * many samples): dyxh [N*T][per_frame] is scratch for dy*uhat and two reductions follow. */
+/* The pre-norm LayerNorm of an attention sub-layer and the positional fuse of its output in ONE kernel (frames of P = 64 token rows,
+ * C = 512): y1 = LayerNorm(x) [N*T*P][C] with its row statistics ln_mean / ln_rstd [N*T*P], fused = posfuse(y1 (+ add)) with
+ * its frame statistics pf_mean / pf_rstd [N*T]; the same results as npvp_layernorm_fwd followed by npvp_posfuse_fwd. */
+int npvp_ln_posfuse_fwd(const float* x, const float* lw, const float* lb, float ln_eps, float* y1, float* ln_mean, float* ln_rstd,
+                        const float* add, const float* beta, const float* gamma, float* fused, float* pf_mean, float* pf_rstd,
+                        int N, int T, int P, int C, float pf_eps, float* y1_amax, float* fused_amax, npvp_stream_t stream);
 int npvp_posfuse_bwd_fused(int N, int T, int per_frame);
 int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
                      const float* rstd, float* du, float* dyxh, float* dbeta, float* dgamma, int N, int T, int per_frame,

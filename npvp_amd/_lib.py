@@ -36,6 +36,8 @@ SIGNATURES = {
     "npvp_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p, c_p]),
     "npvp_posfuse_instance_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_p]),
     "npvp_posfuse_instance_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
+    "npvp_ln_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f,
+                                    c_p, c_p, c_p]),
     "npvp_posfuse_bwd_fused": (c_int, [c_int, c_int, c_int]),
     "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p, c_p]),

@@ -322,6 +322,88 @@ __global__ __launch_bounds__(1024) void posfuse_fwd_frame_kernel(const float* __
   amax_slot_commit_block(amax, am, ared, peek);
 }
 
+// Token LayerNorm AND the positional fuse of its output in one kernel, for 64-token frames of 512 channels (the pre-norm of every
+// attention sub-layer: ref/models/VidHRFormer.py:87,94,210,217,235): block = one frame, wave = 4 token rows (a row is 64 lanes x 2
+// float4, as in ln_fwd_kernel), the frame stays in registers from the load of x to the store of the fused tensor.  Outputs: x1 =
+// LN(x) (the v projection's input, saved for backward), its row statistics, fused = GN(x1 + add) (1 + gamma) + beta, the frame
+// statistics, and both amax bounds.  One read of x and one launch instead of LayerNorm + a second pass over x1.
+__global__ __launch_bounds__(1024) void ln_posfuse_fwd_frame_kernel(const float* __restrict__ x, const float* __restrict__ lw,
+                                                                    const float* __restrict__ lb, float ln_eps, float* __restrict__ y1,
+                                                                    float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
+                                                                    const float* __restrict__ add, const float* __restrict__ beta,
+                                                                    const float* __restrict__ gamma, float* __restrict__ fused,
+                                                                    float* __restrict__ pf_mean, float* __restrict__ pf_rstd, int T,
+                                                                    float pf_eps, float* __restrict__ amax1, float* __restrict__ amax2) {
+  constexpr int C = 512, P = 64, PF = P * C;
+  __shared__ float red[16];
+  __shared__ float ared1[16];
+  __shared__ float ared2[16];
+  const unsigned int peek1 = amax_peek_block(amax1), peek2 = amax_peek_block(amax2);
+  const int f = blockIdx.x, n = f / T, t = f - n * T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ww[2], bb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ww[i] = ld4(lw + (i * 64 + lane) * 4); bb[i] = ld4(lb + (i * 64 + lane) * 4); }
+  float4 v[4][2];
+  float am1 = 0.f, su = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = wave * 4 + r;
+    const long long base = (long long)f * PF + (long long)row * C;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { v[r][i] = ld4(x + base + (i * 64 + lane) * 4); s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w); }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float a = v[r][i].x - mu, b2 = v[r][i].y - mu, c = v[r][i].z - mu, d = v[r][i].w - mu;
+      q += a * a + b2 * b2 + c * c + d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / C) + ln_eps);
+    if (lane == 0) { ln_mean[(long long)f * P + row] = mu; ln_rstd[(long long)f * P + row] = rs; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      float4 o;
+      o.x = (v[r][i].x - mu) * rs * ww[i].x + bb[i].x; o.y = (v[r][i].y - mu) * rs * ww[i].y + bb[i].y;
+      o.z = (v[r][i].z - mu) * rs * ww[i].z + bb[i].z; o.w = (v[r][i].w - mu) * rs * ww[i].w + bb[i].w;
+      st4(y1 + base + c0, o);
+      am1 = amax4(am1, o);
+      if (add) { const float4 a = ld4(add + (long long)n * PF + row * C + c0); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+      v[r][i] = o;                                   // u = LN(x) + add: what the positional fuse normalises
+      su += (o.x + o.y) + (o.z + o.w);
+    }
+  }
+  amax_slot_commit_block(amax1, am1, ared1, peek1);
+  const float mu = block_sum<16>(su, red) * (1.f / PF);
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float a0 = v[r][i].x - mu, a1 = v[r][i].y - mu, a2 = v[r][i].z - mu, a3 = v[r][i].w - mu;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  const float rs = rsqrtf(block_sum<16>(q, red) * (1.f / PF) + pf_eps);
+  if (threadIdx.x == 0) { pf_mean[f] = mu; pf_rstd[f] = rs; }
+  float am2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = (wave * 4 + r) * C + (i * 64 + lane) * 4;
+      float4 o;
+      o.x = (v[r][i].x - mu) * rs; o.y = (v[r][i].y - mu) * rs; o.z = (v[r][i].z - mu) * rs; o.w = (v[r][i].w - mu) * rs;
+      if (gamma) { const float4 g = ld4(gamma + (long long)t * PF + e); o.x *= 1.f + g.x; o.y *= 1.f + g.y; o.z *= 1.f + g.z; o.w *= 1.f + g.w; }
+      const float4 b = ld4(beta + (long long)t * PF + e);
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+      st4(fused + (long long)f * PF + e, o);
+      am2 = amax4(am2, o);
+    }
+  amax_slot_commit_block(amax2, am2, ared2, peek2);
+}
+
 // backward statistics: s1[f] = mean(g), s2[f] = mean(g * uhat), g = dy * (1 + gamma)
 __global__ __launch_bounds__(512) void posfuse_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ add,
@@ -810,6 +892,20 @@ extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* b
   const long long total4 = (long long)frames * per_frame / 4;
   hipLaunchKernelGGL(posfuse_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, x, add, beta, gamma,
                      (const float*)mean, (const float*)rstd, y, T, per_frame, total4, amax);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// LayerNorm(C = 512) + positional fuse of frames of P = 64 token rows in one kernel (see ln_posfuse_fwd_frame_kernel): x [N*T*P][C];
+// y1 = LN(x), ln_mean / ln_rstd [N*T*P]; fused [N*T][P*C], pf_mean / pf_rstd [N*T]; add [N][P*C] or NULL, beta / gamma [T][P*C]
+extern "C" int npvp_ln_posfuse_fwd(const float* x, const float* lw, const float* lb, float ln_eps, float* y1, float* ln_mean,
+                                   float* ln_rstd, const float* add, const float* beta, const float* gamma, float* fused,
+                                   float* pf_mean, float* pf_rstd, int N, int T, int P, int C, float pf_eps, float* y1_amax,
+                                   float* fused_amax, hipStream_t stream) {
+  NPVP_CHECK_ARG(N > 0 && T > 0 && P == 64 && C == 512, "ln_posfuse_fwd: frames of 64 token rows x 512 channels only");
+  NPVP_CHECK_ARG(x && lw && lb && y1 && ln_mean && ln_rstd && beta && fused && pf_mean && pf_rstd, "ln_posfuse_fwd: null argument");
+  hipLaunchKernelGGL(ln_posfuse_fwd_frame_kernel, dim3(N * T), dim3(1024), 0, stream, x, lw, lb, ln_eps, y1, ln_mean, ln_rstd, add,
+                     beta, gamma, fused, pf_mean, pf_rstd, T, pf_eps, y1_amax, fused_amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

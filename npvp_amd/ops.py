@@ -1665,6 +1665,27 @@ def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
     return tag_amax(y, slot), st
 
 
+LN_POSFUSE_ONE_KERNEL = os.environ.get("NPVP_LN_POSFUSE", "1") == "1"          # A/B switch
+
+
+def _raw_ln_posfuse_fwd(x2, lw, lb, eps, add, beta, gamma, N, T):
+    """LayerNorm then positional fuse of its output: -> x1 = LN(x2), its statistics [2, rows], fused, its statistics [2, N*T].
+    One kernel for frames of 64 token rows x 512 channels (npvp_ln_posfuse_fwd), the two-kernel route otherwise."""
+    rows, C = x2.shape
+    if not (LN_POSFUSE_ONE_KERNEL and C == 512 and rows == N * T * 64):
+        x1, lst = _raw_ln_fwd(x2, lw, lb, eps)
+        fused, pst = _raw_posfuse_fwd(x1, add, beta, gamma, N, T)
+        return x1, lst, fused, pst
+    x1, fused = torch.empty_like(x2), torch.empty_like(x2)
+    lst = torch.empty(2, rows, dtype=torch.float32, device=x2.device)
+    pst = torch.empty(2, N * T, dtype=torch.float32, device=x2.device)
+    s1, s2 = _new_slot(x2.device), _new_slot(x2.device)
+    check(lib().npvp_ln_posfuse_fwd(_ptr(x2), _ptr(lw), _ptr(lb), eps, _ptr(x1), _row(lst, 0), _row(lst, 1), _ptr(add), _ptr(beta),
+                                    _ptr(gamma), _ptr(fused), _row(pst, 0), _row(pst, 1), N, T, 64, C, 1e-5, _ptr(s1), _ptr(s2),
+                                    _stream()), "npvp_ln_posfuse_fwd")
+    return tag_amax(x1, s1), lst, tag_amax(fused, s2), pst
+
+
 def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
     """-> du [like x], dadd, dbeta, dgamma"""
     PF = x.numel() // (N * T)
@@ -1695,11 +1716,10 @@ class _SelfAttnSublayer(torch.autograd.Function):
         _chk(x, lw, lb, beta, gamma, add, wqk, bqk, wv, bv, wo, bo)
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
-        x1, lst = _raw_ln_fwd(x2, lw, lb, eps)
         beta_c = _c(beta)
         gamma_c = None if gamma is None else _c(gamma)
         add_c = None if add is None else _c(add)
-        fused, pst = _raw_posfuse_fwd(x1, add_c, beta_c, gamma_c, N, T)
+        x1, lst, fused, pst = _raw_ln_posfuse_fwd(x2, lw, lb, eps, add_c, beta_c, gamma_c, N, T)
         qk = linear_fwd(fused, wqk, bqk)
         v = linear_fwd(x1, wv, bv)
         o = torch.empty_like(v)
@@ -1744,11 +1764,10 @@ class _CrossAttnSublayer(torch.autograd.Function):
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
         k2, m2 = _c(key).reshape(-1, C), _c(memory).reshape(-1, C)
-        x1, lst = _raw_ln_fwd(x2, lw, lb, eps)
         beta_c = _c(beta)
         gamma_c = None if gamma is None else _c(gamma)
         add_c = None if add is None else _c(add)
-        query, pst = _raw_posfuse_fwd(x1, add_c, beta_c, gamma_c, N, T)
+        x1, lst, query, pst = _raw_ln_posfuse_fwd(x2, lw, lb, eps, add_c, beta_c, gamma_c, N, T)
         q = linear_fwd(query, wq, bq)
         k = linear_fwd(k2, wk, bk)
         v = linear_fwd(m2, wv, bv)

@@ -366,6 +366,32 @@ def test_drop_path_mask_rides_in_the_gemms(K, R, g1, g2):
     assert torch.equal(dx == 0, dx_r == 0), "dropped rows must be exactly zero in both routes"
 
 
+@pytest.mark.parametrize("with_add,with_gamma", [(True, False), (False, True)])
+def test_layernorm_and_positional_fuse_in_one_kernel(K, with_add, with_gamma):
+    """npvp_ln_posfuse_fwd (frames of 64 token rows x 512 channels held in a block's registers) against npvp_layernorm_fwd followed
+    by npvp_posfuse_fwd: LN output, fused output, both sets of statistics, both amax bounds."""
+    N, T, P, C = 3, 4, 64, 512
+    x = (0.7 + 1.3 * O.seeded_randn((N * T * P, C), 611)).to(DEV)
+    lw, lb = (1 + 0.1 * O.seeded_randn((C,), 612)).to(DEV), (0.1 * O.seeded_randn((C,), 613)).to(DEV)
+    add = O.seeded_randn((N, P, C), 614).to(DEV) if with_add else None
+    beta = O.seeded_randn((T, P, C), 615).to(DEV)
+    gamma = (0.3 * O.seeded_randn((T, P, C), 616)).to(DEV) if with_gamma else None
+    keep = K.LN_POSFUSE_ONE_KERNEL
+    try:
+        K.LN_POSFUSE_ONE_KERNEL = True
+        a = K._raw_ln_posfuse_fwd(x, lw, lb, 1e-5, add, beta, gamma, N, T)
+        K.LN_POSFUSE_ONE_KERNEL = False
+        b = K._raw_ln_posfuse_fwd(x, lw, lb, 1e-5, add, beta, gamma, N, T)
+    finally:
+        K.LN_POSFUSE_ONE_KERNEL = keep
+    for u, v, n in zip(a, b, ["x1", "ln_stats", "fused", "pf_stats"]):
+        e = float((u.double() - v.double()).norm() / v.double().norm())
+        assert e < 2e-6, f"{n}: {e:.3e}"
+    if K.GEMM_PRECISION == 6:
+        for u, v in ((a[0], b[0]), (a[2], b[2])):
+            assert abs(K.amax_of(u).read() - float(u.abs().max())) == 0.0 and abs(K.amax_of(v).read() - float(v.abs().max())) == 0.0
+
+
 def test_mlpdwbn_backward_with_norm2_inside_the_fused_middle(K):
     """MlpDWBN backward, dropout ON: norm2's input gradient evaluated inside the fused middle's backward (frame sums + parameter
     gradients from npvp_frameln_act_bwd_pgrad, the dropout mask replayed element by element in npvp_mlpdw_mid_bwd_n2; dh2 never
