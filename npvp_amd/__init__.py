@@ -8,7 +8,7 @@ anywhere, but calling an op without the built library or without a GPU raises - 
 from .models import (Predictor, VidHRFormerEncoder, VidHRformerDecoderNAR, VidHRFormerBlockEnc, VidHRFormerBlockDecNAR,
                      SpatialLocalMultiheadAttention, MlpDWBN, MultiheadAttention, CoorGenerator, NRMLP, PosFeatFuser,
                      EventEncoder, L1Loss, Div_KL, DropPath, ResnetEncoder, ResnetDecoder, build_frozen_autoencoder, to_device_layout)
-from .trainer import (FlatAdamW, predictor_train_step, full_train_step, cosine_warm_restarts_lr, build_predictor_from_cfg,
+from .trainer import (FlatAdamW, predictor_train_step, full_train_step, predictor_val_step, full_val_step, cosine_warm_restarts_lr, build_predictor_from_cfg,
                       context_lists, rand_context_collate, rand_context_batch_process, vfi_batch_process,
                       save_lightning_checkpoint, load_lightning_checkpoint, GraphedTrainStep)
 from . import ops
@@ -16,7 +16,7 @@ from . import metrics, data
 
 __all__ = ["Predictor", "VidHRFormerEncoder", "VidHRformerDecoderNAR", "VidHRFormerBlockEnc", "VidHRFormerBlockDecNAR",
            "SpatialLocalMultiheadAttention", "MlpDWBN", "MultiheadAttention", "CoorGenerator", "NRMLP", "PosFeatFuser",
-           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "to_device_layout", "FlatAdamW", "predictor_train_step", "full_train_step", "context_lists",
+           "EventEncoder", "L1Loss", "Div_KL", "DropPath", "ResnetEncoder", "ResnetDecoder", "build_frozen_autoencoder", "to_device_layout", "FlatAdamW", "predictor_train_step", "full_train_step", "predictor_val_step", "full_val_step", "context_lists",
            "rand_context_collate", "rand_context_batch_process", "vfi_batch_process",
            "save_lightning_checkpoint", "load_lightning_checkpoint", "GraphedTrainStep",
            "cosine_warm_restarts_lr", "build_predictor_from_cfg", "ops", "metrics", "data"]

@@ -268,6 +268,50 @@ def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF
                                 frozen_dec=dec, future_frames=future_frames, sync=sync, grad_sync=grad_sync)
 
 
+def predictor_val_step(predictor, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, frozen_dec=None, future_frames=None,
+                       sync=True):
+    """LitPredictor.validation_step + shared_step (ref/models/Predictor.py:150-170,172-194) on frozen-encoder features.
+    Lightning runs validation with the module in eval mode under no_grad: dropout and drop-path are off, the EventEncoder's
+    BatchNorm uses running statistics, and a stochastic predictor - still handed the ground-truth target features
+    (shared_step :181-183) - runs both encoder passes, returns the 5-tuple and decodes from the PRIOR sample zo
+    (ref :312-321).  Returns the scalars the reference logs as loss_val / PF_L1_val / KL_loss_val / Image_L1_val, and the
+    prediction.  The module's train / eval state is restored."""
+    dev = past_feats.device
+    was_training = predictor.training
+    predictor.eval()
+    try:
+        with torch.no_grad():
+            if predictor.stochastic:
+                pred, mu_o, lv_o, mu_p, lv_p = predictor(past_feats, future_feats)
+                kl = Div_KL(KL_beta)(mu_o, lv_o, mu_p, lv_p)
+            else:
+                pred = predictor(past_feats)
+                kl = torch.zeros((), dtype=torch.float32, device=dev)
+            pf = L1Loss(lam=lam_PF_L1)(pred, future_feats)
+            loss = pf + kl
+            img = None
+            if frozen_dec is not None:
+                img = L1Loss()(frozen_dec(pred), future_frames)
+                loss = loss + img
+    finally:
+        predictor.train(was_training)
+    out = {"loss": loss, "PF_L1": pf, "KL": kl, "Image_L1": img}
+    if sync:
+        out = {k: (None if v is None else float(v)) for k, v in out.items()}
+    out["pred"] = pred
+    return out
+
+
+def full_val_step(predictor, enc, dec, past_frames, future_frames, lam_PF_L1=0.01, KL_beta=1e-8, sync=True):
+    """validation_step from pixels (ref/models/Predictor.py:150-170,172-194): frozen encoder, predictor (eval), frozen decoder."""
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        past_feats = enc(past_frames)
+        future_feats = enc(future_frames)
+    return predictor_val_step(predictor, past_feats, future_feats, lam_PF_L1, KL_beta, frozen_dec=dec,
+                              future_frames=future_frames, sync=sync)
+
+
 # ---- batch shaping of the reference's other Stage-2 modes (ref/models/Predictor.py:30-40,62-70,241-262 and the
 # ---- random-context collate ref/utils/dataset.py:162-178): SURVEY 8f "next" row #2
 def context_lists(P, num_past, num_future):

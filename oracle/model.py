@@ -16,7 +16,7 @@ __all__ = [
     "CoorGenerator", "NRMLP", "PosFeatFuser", "EventEncoder", "MultiheadAttention",
     "SpatialLocalMultiheadAttention", "MlpDWBN", "VidHRFormerBlockEnc",
     "VidHRFormerEncoder", "VidHRFormerBlockDecNAR", "VidHRformerDecoderNAR",
-    "Predictor", "L1Loss", "Div_KL", "predictor_train_step", "full_train_step", "build_predictor_from_cfg",
+    "Predictor", "L1Loss", "Div_KL", "predictor_train_step", "full_train_step", "predictor_val_step", "full_val_step", "build_predictor_from_cfg",
     "rand_context_batch_process",
 ]
 
@@ -517,6 +517,42 @@ def full_train_step(predictor, opt, enc, dec, past_frames, future_frames, lam_PF
         past_feats, future_feats = enc(past_frames), enc(future_frames)
     return predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm,
                                 frozen_dec=dec, future_frames=future_frames)
+
+
+def predictor_val_step(predictor, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, frozen_dec=None, future_frames=None):
+    """LitPredictor.validation_step + shared_step (ref/models/Predictor.py:150-170,172-194) restated without Lightning,
+    taking the frozen encoder's features: Lightning runs it with the module in eval mode under no_grad, so a stochastic
+    predictor is still handed the ground-truth target features (shared_step :181-183), runs BOTH encoders, returns the
+    5-tuple and decodes from the PRIOR sample zo (ref :312-321); dropout / drop-path are off and the EventEncoder's
+    BatchNorm uses its running statistics.  Scalars as the reference logs them (*_val), plus the prediction."""
+    was_training = predictor.training
+    predictor.eval()
+    try:
+        with torch.no_grad():
+            if predictor.stochastic:
+                pred, mu_o, lv_o, mu_p, lv_p = predictor(past_feats, future_feats)
+                kl = Div_KL(KL_beta)(mu_o, lv_o, mu_p, lv_p)
+            else:
+                pred = predictor(past_feats)
+                kl = torch.zeros((), dtype=pred.dtype)
+            pf = L1Loss(lam=lam_PF_L1)(pred, future_feats)
+            loss = pf + kl
+            img = None
+            if frozen_dec is not None:
+                img = L1Loss()(frozen_dec(pred), future_frames)
+                loss = loss + img
+    finally:
+        predictor.train(was_training)
+    return {"loss": float(loss), "PF_L1": float(pf), "KL": float(kl), "Image_L1": None if img is None else float(img),
+            "pred": pred}
+
+
+def full_val_step(predictor, enc, dec, past_frames, future_frames, lam_PF_L1=0.01, KL_beta=1e-8):
+    """validation_step from pixels (ref/models/Predictor.py:150-170,172-194)."""
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        past_feats, future_feats = enc(past_frames), enc(future_frames)
+    return predictor_val_step(predictor, past_feats, future_feats, lam_PF_L1, KL_beta, frozen_dec=dec, future_frames=future_frames)
 
 
 def rand_context_batch_process(predictor, batch):

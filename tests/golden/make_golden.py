@@ -102,10 +102,85 @@ def grads(out, cot, inputs):
     return gs
 
 
+def gen_val_steps(R):
+    """LitPredictor.validation_step (ref/models/Predictor.py:150-170) = shared_step (:172-194) in eval mode under no_grad
+    (what Lightning's validation loop does) + the three losses, restated on the reference's own modules: NPVP-S is handed the
+    ground-truth target features, returns the 5-tuple and decodes from the prior sample zo (:312-321)."""
+    import npvp_amd
+    real_randn = torch.randn
+    h = torch.linspace(0, 7, 8)
+    N, To, Tp = 2, 3, 4
+    to, tp = torch.linspace(0, To - 1, To), torch.linspace(To, To + Tp - 1, Tp)
+    kw = dict(evt_former=True, learn_evt_token=False, evt_former_num_layers=2, rand_context=False)     # dropout / drop_path at their 0.1 defaults: eval must ignore them
+    renc = R.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    rdec = R.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    menc = npvp_amd.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    mdec = npvp_amd.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    for m_, sd in ((renc, 121), (menc, 121), (rdec, 122), (mdec, 122)):
+        O.key_hashed_fill(m_, sd); m_.eval()
+        for p_ in m_.parameters():
+            p_.requires_grad_(False)
+    g_ = torch.Generator().manual_seed(153)
+    pf, ff = torch.rand(N, To, 1, 64, 64, generator=g_), torch.rand(N, Tp, 1, 64, 64, generator=g_)
+    eps = O.seeded_randn((N, 512, 8, 8), 154)
+    for variant, stochastic in (("D", False), ("S", True)):
+        ref = R.Predictor(8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, stochastic, 2, norm=nn.LayerNorm(512), **kw)
+        mine = oracle.Predictor(8, 8, To + Tp, h, h, to, tp, 512, 'Add', 'layer', 256, 1, stochastic, 2, **kw)
+        O.key_hashed_fill(ref, 151); O.key_hashed_fill(mine, 151)
+        if stochastic:
+            mine.evt_prior.eps_fn = mine.evt_posterior.eps_fn = lambda shape: eps
+        # reference side: Lightning's validation loop = module.eval() + no_grad around validation_step
+        ref.eval()
+        with torch.no_grad():
+            past_feats, fut_feats = renc(pf), renc(ff)
+            torch.randn = lambda *a, **k: eps
+            try:
+                o = ref(past_feats, fut_feats) if stochastic else ref(past_feats)
+            finally:
+                torch.randn = real_randn
+            pred = o[0] if stochastic else o
+            kl = R.Div_KL(1e-6)(*o[1:]) if stochastic else torch.zeros(())
+            frames = rdec(pred)
+            img = R.L1Loss()(frames, ff); pfl = R.L1Loss(lam=0.01)(pred, fut_feats)
+            loss = img + pfl + kl
+        mine.train()                          # the step itself must switch to eval (and back)
+        sm = oracle.full_val_step(mine, menc, mdec, pf, ff, 0.01, 1e-6)
+        assert mine.training
+        check(f"val_step[{variant}].loss", torch.tensor(sm["loss"]), loss); check(f"val_step[{variant}].Image_L1", torch.tensor(sm["Image_L1"]), img)
+        check(f"val_step[{variant}].PF_L1", torch.tensor(sm["PF_L1"]), pfl); check(f"val_step[{variant}].pred", sm["pred"], pred)
+        if stochastic:
+            check(f"val_step[{variant}].KL", torch.tensor(sm["KL"]), kl)
+        # predictor-only flavour on the same features (what the bench's predictor-only step validates with)
+        sp = oracle.predictor_val_step(mine, past_feats, fut_feats, 0.01, 1e-6)
+        check(f"val_step[{variant}].features_only.loss", torch.tensor(sp["loss"]), pfl + kl)
+        save(f"val_step_{variant}", loss=npy(loss), img=npy(img), pf=npy(pfl), kl=npy(kl), pred=npy(pred), frames_strided=npy(frames.flatten()[::5]),
+             loss_features_only=npy(pfl + kl), meta=np.array([N, To, Tp, 151, 121, 122, 153, 154]))
+
+
+def write_report(append=False):
+    path = os.path.join(HERE, "ORACLE_VS_REFERENCE.txt")
+    if append:
+        keep = [l for l in open(path).read().splitlines() if l and not l.startswith("val_step")]
+        with open(path, "w") as f:
+            f.write("\n".join(keep) + "\n")
+            for n_, e in REPORT:
+                f.write(f"{n_:64s} {e:.3e}\n")
+    else:
+        with open(path, "w") as f:
+            f.write("# oracle (CPU restatement) vs imported reference, rel-L2, torch %s, generated by make_golden.py\n" % torch.__version__)
+            for n_, e in REPORT:
+                f.write(f"{n_:64s} {e:.3e}\n")
+    print(f"max oracle-vs-reference rel-L2 over {len(REPORT)} checks: {max(e for _, e in REPORT):.3e}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R, RV, RS = import_reference()
+    if "val" in sys.argv[1:]:                 # only the validation-step fixtures (the others regenerate bit-identically anyway)
+        gen_val_steps(R)
+        write_report(append=True)
+        return
 
     # ------------------------------------------------------------------ posfuse
     for norm in ("layer", "instance"):
@@ -574,11 +649,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "metrics.npz"), **arrays)
     print("wrote metrics.npz")
 
-    with open(os.path.join(HERE, "ORACLE_VS_REFERENCE.txt"), "w") as f:
-        f.write("# oracle (CPU restatement) vs imported reference, rel-L2, torch %s, generated by make_golden.py\n" % torch.__version__)
-        for n_, e in REPORT:
-            f.write(f"{n_:64s} {e:.3e}\n")
-    print(f"max oracle-vs-reference rel-L2 over {len(REPORT)} checks: {max(e for _, e in REPORT):.3e}")
+    gen_val_steps(R)
+    write_report()
 
 
 if __name__ == "__main__":

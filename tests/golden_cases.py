@@ -305,6 +305,35 @@ def case_full_step(pred_impl, ae_impl, dev, make_opt=None, device_layout=None):
                 w_evt_fc1=sd["EVT_Former.layers.0.SpatialFFN.fc1.bias"].flatten()[:256].clone())
 
 
+def case_val_step(pred_impl, ae_impl, dev, variant="S", device_layout=None):
+    """validation_step (ref Predictor.py:150-170): the step is entered with the module in TRAIN mode and must itself run in
+    eval mode under no_grad (NPVP-S: with the ground truth, 5-tuple, decoded from the prior sample) and restore the mode."""
+    stochastic = variant == "S"
+    N, To, Tp = 2, 3, 4
+    m = _small_predictor(pred_impl, stochastic, 151, dev, dropout=0.1, drop_path=0.1)
+    enc = ae_impl.ResnetEncoder(1, ngf=64, n_downsampling=3, num_res_blocks=2, learn_3d=False)
+    dec = ae_impl.ResnetDecoder(1, ngf=64, n_downsampling=3, out_layer='Sigmoid')
+    O.key_hashed_fill(enc, 121); O.key_hashed_fill(dec, 122)
+    for q in list(enc.parameters()) + list(dec.parameters()):
+        q.requires_grad_(False)
+    enc, dec = (enc.to(dev), dec.to(dev)) if device_layout is None else device_layout(enc, dec, dev)
+    enc, dec = enc.eval(), dec.eval()
+    g_ = torch.Generator().manual_seed(153)
+    pf, ff = torch.rand(N, To, 1, 64, 64, generator=g_).to(dev), torch.rand(N, Tp, 1, 64, 64, generator=g_).to(dev)
+    eps = O.seeded_randn((N, 512, 8, 8), 154).to(dev)
+    if stochastic:
+        m.evt_prior.eps_fn = m.evt_posterior.eps_fn = lambda shape: eps
+    m.train()
+    s = pred_impl.full_val_step(m, enc, dec, pf, ff, 0.01, 1e-6)
+    assert m.training, "the validation step must restore the module's training mode"
+    with torch.no_grad():
+        past_feats, fut_feats = enc(pf), enc(ff)
+        frames = dec(s["pred"])
+    sp = pred_impl.predictor_val_step(m, past_feats, fut_feats, 0.01, 1e-6)
+    return dict(loss=torch.tensor(s["loss"]), img=torch.tensor(s["Image_L1"]), pf=torch.tensor(s["PF_L1"]), kl=torch.tensor(s["KL"]),
+                pred=s["pred"], frames_strided=frames.flatten()[::5], loss_features_only=torch.tensor(sp["loss"]))
+
+
 def case_randctx(impl, dev):
     """Unified model: Predictor(rand_context=True) with an unsorted random context / target split of T=7 steps."""
     N, T = 2, 7

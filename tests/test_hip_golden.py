@@ -137,6 +137,17 @@ def test_full_step_from_pixels(impl, layout):
                tag=f"full_step[{MODE},{layout}]")
 
 
+@pytest.mark.parametrize("layout", ["nchw", "encoder_channels_last"])
+@pytest.mark.parametrize("variant", ["D", "S"])
+def test_validation_step(impl, variant, layout):
+    """LitPredictor.validation_step (ref Predictor.py:150-170,172-194) against the reference's vectors: eval mode under no_grad
+    (dropout / drop-path 0.1 configured but inactive, BatchNorm on running statistics), NPVP-S handed the ground truth ->
+    5-tuple, prediction decoded from the PRIOR sample zo (ref :312-321), the *_val losses; the module's train mode restored."""
+    dl = impl.to_device_layout if layout == "encoder_channels_last" else None
+    GC.compare(GC.case_val_step(impl, impl, DEV, variant, device_layout=dl), GC.load(f"val_step_{variant}"), TOL,
+               tag=f"val_step_{variant}[{MODE},{layout}]")
+
+
 def test_grad_sink_matches_autograd_accumulation(impl):
     """ops.GradSink (backward kernels accumulate parameter gradients straight into the flat gradient buffer) against
     the plain autograd route (temporaries + AccumulateGrad adds): same flat gradient, tied LayerNorm and the twice-used

@@ -96,3 +96,10 @@ def test_reset_pos_coor_fractional_times():
 def test_full_step_from_pixels():
     import npvp_amd
     GC.compare(GC.case_full_step(oracle, npvp_amd, "cpu"), GC.load("train_step_full_S"), TOL)
+
+
+@pytest.mark.parametrize("variant", ["D", "S"])
+def test_validation_step(variant):
+    """LitPredictor.validation_step (ref Predictor.py:150-170): eval mode, NPVP-S with ground truth decodes from the prior."""
+    import npvp_amd
+    GC.compare(GC.case_val_step(oracle, npvp_amd, "cpu", variant), GC.load(f"val_step_{variant}"), TOL)
