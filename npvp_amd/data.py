@@ -1,6 +1,7 @@
 """Frame-folder clip loader feeding the device: the part of ref/utils/dataset.py the Stage-2 loop needs -
-`LitDataModule`'s per-dataset transforms and constants (:25-60), the folder walkers of `BAIRDataset` (:401-414) and
-`CityScapesDataset` (:420-443) and the 95 / 5 train / validation split (:84-88), `ClipDataset` (:517-575), the `Vid*` transforms (:780-900) and the implicit DistributedSampler -
+`LitDataModule`'s per-dataset transforms, constants and splits (:25-135), the clip builders of all five datasets - `KTHDataset`
+(:267-360), `BAIRDataset` (:362-414), `CityScapesDataset` (:416-443), `KITTIDataset` (:445-515), `StochasticMovingMNIST` (:677-778) -,
+`ClipDataset` (:517-575), the `Vid*` transforms (:780-900) and the implicit DistributedSampler -
 re-designed around the GPU instead of around torchvision:
 
   * worker threads decode with PIL and do the GEOMETRIC transforms (centre crop, resize, flips) on uint8 images;
@@ -8,8 +9,11 @@ re-designed around the GPU instead of around torchvision:
     copy stream, and `npvp_u8hwc_to_f32chw` (csrc/data.hip) does ToTensor + Normalize + the HWC->CHW transpose in one pass;
   * the sampler is rank-strided over a seeded permutation (one process per GPU, no data traffic between ranks).
 
-torchvision / cv2 are not needed (and are absent in this image).  The reference's module cannot be imported here for the
-same reason, so this file is pinned by its own property tests (tests/test_data.py), not by reference-generated vectors.
+torchvision / cv2 are not needed (and are absent in this image).  Pinning: the five clip builders and the SM-MNIST trajectory
+generator are checked against vectors the REFERENCE's own classes produced on synthetic trees (tests/golden/make_loader_golden.py:
+its module imports with empty stand-ins for torchvision / cv2, which those code paths never touch); what does need torchvision -
+`ClipDataset.__getitem__`'s PIL transforms, datasets.MNIST's file reader - is restated from the source text and covered by
+property tests only (tests/test_data.py).
 """
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -77,6 +81,173 @@ def cityscapes_clips(frames_dir, clip_length):
     return clips
 
 
+def _cut_clips(files, clip_length):
+    """non-overlapping clips, the remainder dropped half at each end (the same four lines in every reference walker)"""
+    n, rem = len(files) // clip_length, len(files) % clip_length
+    files = files[rem // 2: rem // 2 + n * clip_length]
+    return [files[i * clip_length:(i + 1) * clip_length] for i in range(n)]
+
+
+KTH_ACTIONS = ('boxing', 'handclapping', 'handwaving', 'jogging_no_empty', 'running_no_empty', 'walking_no_empty')
+
+
+def kth_clips(kth_dir, clip_length, person_ids, actions=KTH_ACTIONS):
+    """ref KTHDataset.__getFramesFolder__ + __getClips__ (dataset.py:327-360): the frame folders `<action>/personNN_...` of all
+    actions (entries with '.avi' in their name skipped), sorted by full path, kept when the person id - the last two characters
+    of the folder name's first '_' field - is in `person_ids`; every folder cut into non-overlapping clips."""
+    root = Path(kth_dir).absolute()
+    folders = []
+    for a in actions:
+        folders.extend(root / a / s_ for s_ in os.listdir(root / a) if '.avi' not in s_)
+    clips = []
+    for ff in sorted(folders):
+        if int(ff.name.strip().split('_')[0][-2:]) in person_ids:
+            clips += _cut_clips(sorted(ff.glob('*')), clip_length)
+    return clips
+
+
+def kth_clip_lists(kth_dir, clip_length, train=True, val=True, val_person_ids=(5,), actions=KTH_ACTIONS):
+    """ref KTHDataset.__init__ (dataset.py:273-313): persons 1..16 train, 17..25 test.  With `val_person_ids` given (LitDataModule
+    passes [5], :38) the validation clips are those persons' - and, as in the reference, they are NOT taken out of the training
+    ids (only the `val_person_ids is None` branch removes its randomly drawn person).  Returns {'train', 'val'} or {'test'}."""
+    if not train:
+        return {"test": kth_clips(kth_dir, clip_length, list(range(17, 26)), actions)}
+    person_ids = list(range(1, 17))
+    out = {}
+    if val:
+        if val_person_ids is None:
+            import random
+            val_person_ids = [random.randint(1, 17)]
+            person_ids.remove(val_person_ids[0])
+        out["val"] = kth_clips(kth_dir, clip_length, list(val_person_ids), actions)
+    out["train"] = kth_clips(kth_dir, clip_length, person_ids, actions)
+    return out
+
+
+def kitti_clip_lists(kitti_dir, clip_length, test_folder_ids=(10, 11, 12, 13), train=True, val=True):
+    """ref KITTIDataset (dataset.py:445-515): the drive folders sorted by name; the ones at `test_folder_ids` are the test set, of
+    the rest the first two are validation and the others training; every folder cut into non-overlapping clips."""
+    root = Path(kitti_dir).absolute()
+    folders = sorted(os.listdir(root))
+    cut = lambda names: [c for f in names for c in _cut_clips(sorted((root / f).glob('*')), clip_length)]
+    if not train:
+        return {"test": cut([folders[i] for i in test_folder_ids])}
+    tr = [f for i, f in enumerate(folders) if i not in test_folder_ids]
+    return {"val": cut(tr[0:2]), "train": cut(tr[2:])} if val else {"train": cut(tr)}
+
+
+def load_mnist_digits(root, train=True, digit_size=32):
+    """The digit images StochasticMovingMNIST draws from (ref dataset.py:693-700: torchvision datasets.MNIST(root, train,
+    transform=Resize(32) + ToTensor)) without torchvision: the raw idx file `<root>/MNIST/raw/{train,t10k}-images-idx3-ubyte[.gz]`,
+    every 28 x 28 image resized with PIL's bilinear filter (what Resize does to a PIL image) and scaled to [0, 1].
+    Returns float32 (N, digit_size, digit_size)."""
+    import gzip
+    from PIL import Image
+    name = ("train" if train else "t10k") + "-images-idx3-ubyte"
+    base = Path(root) / "MNIST" / "raw" / name
+    if base.exists():
+        raw = base.read_bytes()
+    elif base.with_suffix(".gz").exists() or Path(str(base) + ".gz").exists():
+        raw = gzip.open(str(base) + ".gz", "rb").read()
+    else:
+        raise FileNotFoundError(f"{base}[.gz]: MNIST idx file not found (the reference passes download=False too)")
+    magic, n, h, w = np.frombuffer(raw[:16], dtype=">i4")
+    if magic != 2051:
+        raise ValueError(f"{base}: not an idx3-ubyte image file")
+    imgs = np.frombuffer(raw, dtype=np.uint8, offset=16).reshape(n, h, w)
+    out = np.empty((n, digit_size, digit_size), dtype=np.float32)
+    for i in range(n):
+        out[i] = np.asarray(Image.fromarray(imgs[i], mode='L').resize((digit_size, digit_size), Image.BILINEAR), dtype=np.float32) / 255.0
+    return out
+
+
+class StochasticMovingMNIST:
+    """ref StochasticMovingMNIST (dataset.py:677-778; after edenton/svg): `num_digits` digits bounce inside an image_size^2 frame,
+    a new random velocity at every wall hit (or a mirrored one when `deterministic`); len = number of digit images, the clip for
+    an index is DRAWN, not stored.  Random stream exactly as the reference's: numpy's legacy global generator seeded ONCE with the
+    first index asked for (`set_seed`, per loader worker there) - here a private RandomState with the same stream, one per dataset
+    object, so concurrent loader threads must go through `__getitem__` under its lock (it is a few hundred microseconds).
+    `digits`: float32 (N, 32, 32) in [0, 1] (load_mnist_digits).  __getitem__ gives the clip as uint8 (T, H, W, 1) = what the
+    reference's ToPILImage makes of the float frames (x 255, truncated), ready for ClipLoader (mean 0, std 1: VidToTensor only)."""
+
+    def __init__(self, digits, num_past_frames, num_future_frames, num_digits=2, image_size=64, deterministic=False):
+        import threading
+        self.digits = np.ascontiguousarray(digits, dtype=np.float32)
+        self.num_past_frames, self.num_future_frames = num_past_frames, num_future_frames
+        self.seq_len = num_past_frames + num_future_frames
+        self.num_digits, self.image_size, self.digit_size = num_digits, image_size, 32
+        self.deterministic = deterministic
+        self.N = len(self.digits)
+        self.epoch = 0
+        self._rng = None
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return self.N
+
+    def clip_float(self, index):
+        """the reference's __getnparray__: float32 (T, 1, H, W), overlapping digits clipped to 1"""
+        with self._lock:
+            if self._rng is None:
+                self._rng = np.random.RandomState(int(index))
+            rng, S, dsz = self._rng, self.image_size, self.digit_size
+            x = np.zeros((self.seq_len, S, S, 1), dtype=np.float32)
+            for _ in range(self.num_digits):
+                digit = self.digits[rng.randint(self.N)]
+                sx, sy = rng.randint(S - dsz), rng.randint(S - dsz)
+                dx, dy = rng.randint(-4, 5), rng.randint(-4, 5)
+                for t in range(self.seq_len):
+                    if sy < 0:
+                        sy = 0
+                        if self.deterministic:
+                            dy = -dy
+                        else:
+                            dy = rng.randint(1, 5); dx = rng.randint(-4, 5)
+                    elif sy >= S - 32:
+                        sy = S - 32 - 1
+                        if self.deterministic:
+                            dy = -dy
+                        else:
+                            dy = rng.randint(-4, 0); dx = rng.randint(-4, 5)
+                    if sx < 0:
+                        sx = 0
+                        if self.deterministic:
+                            dx = -dx
+                        else:
+                            dx = rng.randint(1, 5); dy = rng.randint(-4, 5)
+                    elif sx >= S - 32:
+                        sx = S - 32 - 1
+                        if self.deterministic:
+                            dx = -dx
+                        else:
+                            dx = rng.randint(-4, 0); dy = rng.randint(-4, 5)
+                    x[t, sy:sy + 32, sx:sx + 32, 0] += digit
+                    sy += dy
+                    sx += dx
+        x[x > 1] = 1.
+        return x.transpose(0, 3, 1, 2)
+
+    def __getitem__(self, index):
+        x = self.clip_float(index).transpose(0, 2, 3, 1)          # (T, H, W, 1)
+        return np.ascontiguousarray((x * np.float32(255.0)).astype(np.uint8))      # ToPILImage: mul(255).byte()
+
+
+class ClipSubset:
+    """torch.utils.data.Subset for ClipDataset-likes (the 95 / 5 splits): forwards the frame counts and the epoch"""
+
+    def __init__(self, dataset, indices):
+        self.dataset, self.indices = dataset, list(indices)
+        self.num_past_frames, self.num_future_frames = dataset.num_past_frames, dataset.num_future_frames
+
+    epoch = property(lambda self: self.dataset.epoch, lambda self, e: setattr(self.dataset, "epoch", e))
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        return self.dataset[self.indices[i]]
+
+
 def train_val_split(dataset_len, train_ratio=0.95, seed=2021):
     """index lists of the reference's BAIR / SM-MNIST 95 / 5 train / validation split: torch random_split with
     Generator().manual_seed(2021) (dataset.py:84-88,100-103)"""
@@ -125,24 +296,57 @@ class ClipDataset:
         return np.ascontiguousarray(np.stack(frames, 0))
 
 
-# folder walkers by dataset.  KTH (person / action splits, dataset.py:253-360), KITTI (test-folder ids + overlapping windows,
-# :445-515) and SM-MNIST (generated digits, :578-700) are NOT folder-of-frame-folders trees: they have no walker here.
+# folder walkers of the datasets whose clips come from ONE tree of frame folders
 WALKERS = {"BAIR": frame_folder_clips, "CityScapes": cityscapes_clips}
 
 
 def build_dataset(name, frames_dir, num_past_frames, num_future_frames, train=True, seed=0):
-    """the reference's per-dataset recipe (LitDataModule, dataset.py:33-60) for the datasets whose clips come from a tree of
-    frame folders: BAIR (frames_dir = <dir>/train or /test; the reference then splits train 95 / 5: train_val_split) and
-    CityScapes (frames_dir = <dir>/train, /val or /test).  The per-dataset constants of KTH / KITTI / SM-MNIST are in DATASETS
-    for ClipDataset users who bring their own clip lists; their walkers are not built."""
+    """ClipDataset over one tree of frame folders with the dataset's constants (LitDataModule.__init__, dataset.py:33-60): BAIR
+    (frames_dir = <dir>/train or /test) and CityScapes (frames_dir = <dir>/train, /val or /test).  The whole per-dataset recipe,
+    splits included, for all five datasets: build_split."""
     d = DATASETS[name]
     if name not in WALKERS:
-        raise NotImplementedError(f"{name}: the reference builds its clip list from dataset-specific structure (person / action "
-                                  "splits, test-folder ids, generated digits), not from a tree of frame folders; pass your own "
-                                  "clip lists to ClipDataset with DATASETS[name]'s constants")
+        raise ValueError(f"{name}: not a single tree of frame folders - use build_split(name, dataset_dir, ..., split)")
     clips = WALKERS[name](frames_dir, num_past_frames + num_future_frames)
     return ClipDataset(num_past_frames, num_future_frames, clips, d["color"], d["center_crop"], d["resize"],
                        flips=train and d["train_flips"], seed=seed)
+
+
+def build_split(name, dataset_dir, num_past_frames, num_future_frames, split="train", seed=0):
+    """LitDataModule.setup (ref/utils/dataset.py:62-135) for one of its five datasets and one split ('train' | 'val' | 'test'),
+    `dataset_dir` = cfg.Dataset.dir:
+      KTH         persons 1..16 train (person 5 validation, not removed from train), 17..25 test (:66-70,108-111)
+      KITTI       drive folders 10..13 test, the first two others validation (:72-76,113-117)
+      BAIR        <dir>/train split 95 / 5 by random_split(seed 2021), <dir>/test (:78-86,119-121)
+      CityScapes  <dir>/train, <dir>/val, <dir>/test (:87-93,122-125)
+      SMMNIST     clips drawn from the MNIST train / test digits; train split 95 / 5 (:95-101,127-128)
+    Quirks kept: the validation sets get the TRAIN transform (flips), and so do the KITTI / CityScapes / SMMNIST test sets."""
+    if split not in ("train", "val", "test"):
+        raise ValueError(f"split must be 'train', 'val' or 'test', not {split!r}")
+    d, L = DATASETS[name], num_past_frames + num_future_frames
+    mk = lambda clips, flips: ClipDataset(num_past_frames, num_future_frames, clips, d["color"], d["center_crop"], d["resize"],
+                                          flips=flips and d["train_flips"], seed=seed)
+    if name == "KTH":
+        lists = kth_clip_lists(dataset_dir, L, train=split != "test", val=True, val_person_ids=(5,))
+        return mk(lists[split], flips=split != "test")
+    if name == "KITTI":
+        lists = kitti_clip_lists(dataset_dir, L, (10, 11, 12, 13), train=split != "test", val=True)
+        return mk(lists[split], flips=True)
+    if name == "BAIR":
+        if split == "test":
+            return mk(frame_folder_clips(Path(dataset_dir) / "test", L), flips=False)
+        whole = mk(frame_folder_clips(Path(dataset_dir) / "train", L), flips=True)
+        tr, va = train_val_split(len(whole))
+        return ClipSubset(whole, tr if split == "train" else va)
+    if name == "CityScapes":
+        return mk(cityscapes_clips(Path(dataset_dir) / split, L), flips=True)
+    if name == "SMMNIST":
+        ds = StochasticMovingMNIST(load_mnist_digits(dataset_dir, train=split != "test"), num_past_frames, num_future_frames)
+        if split == "test":
+            return ds
+        tr, va = train_val_split(len(ds))
+        return ClipSubset(ds, tr if split == "train" else va)
+    raise KeyError(name)
 
 
 def shard_indices(n, batch_size, rank=0, world=1, shuffle=True, seed=0, epoch=0, drop_last=True):

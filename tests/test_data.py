@@ -1,6 +1,7 @@
 """Frame-folder loader: folder walker, sampler and geometric transforms on the CPU; the uint8 -> normalised
-fp32 kernel and the loader end to end on the GPU.  The reference's dataset module needs torchvision / cv2 (absent here), so
-these are restated-semantics and property tests, not reference-vector tests."""
+fp32 kernel and the loader end to end on the GPU.  The five clip builders and the SM-MNIST generator are checked against vectors
+produced by the reference's own classes (tests/golden/make_loader_golden.py); the PIL transforms of ClipDataset need torchvision on
+the reference side (absent here), so those are restated-semantics and property tests, not reference-vector tests."""
 import os
 import sys
 
@@ -56,11 +57,86 @@ def test_cityscapes_walker_respects_sequences_and_gaps(tmp_path):
     # 13 frames -> 2 clips from frame 1 (remainder 3: one dropped in front); 6 frames -> 1 clip from frame 20; 5 frames -> 1 clip
     assert got == [[f"000001:{t}" for t in range(1, 6)], [f"000001:{t}" for t in range(6, 11)],
                    [f"000001:{t}" for t in range(20, 25)], [f"000002:{t}" for t in range(5, 10)]]
-    with pytest.raises(NotImplementedError):
-        D.build_dataset("KTH", root, 10, 10)
-    for name in ("KITTI", "SMMNIST"):
-        with pytest.raises(NotImplementedError):
+    for name in ("KTH", "KITTI", "SMMNIST"):           # not single trees of frame folders: build_split owns their recipes
+        with pytest.raises(ValueError):
             D.build_dataset(name, root, 4, 4)
+
+
+# ---- the five clip builders against what the REFERENCE's own walker classes produced on synthetic trees
+# ---- (tests/golden/make_loader_golden.py ran KTHDataset / KITTIDataset / BAIRDataset / CityScapesDataset; fixture = file names only)
+def _golden_tree(tmp_path, name):
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "loader_walkers.json")))[name]
+    root = tmp_path / name.lower()
+    for f in g["files"]:
+        (root / f).parent.mkdir(parents=True, exist_ok=True)
+        (root / f).touch()
+    rel = lambda clips: [[os.path.relpath(str(f), str(root.absolute())) for f in c] for c in clips]
+    return g, root, rel
+
+
+def test_kth_clip_lists_match_the_reference_walker(tmp_path):
+    """ref KTHDataset (dataset.py:267-360): persons 1..16 train, [5] validation (and still in train), 17..25 test, '.avi' skipped"""
+    g, root, rel = _golden_tree(tmp_path, "KTH")
+    lists = D.kth_clip_lists(root, g["clip_length"], train=True, val=True, val_person_ids=[5])
+    assert rel(lists["train"]) == g["train"] and rel(lists["val"]) == g["val"]
+    assert rel(D.kth_clip_lists(root, g["clip_length"], train=False, val=False)["test"]) == g["test"]
+    assert all(c in g["train"] for c in g["val"]), "the reference keeps the validation person in the training list"
+    ds = D.build_split("KTH", root, 4, 6, "val")
+    assert len(ds) == len(g["val"]) and ds.flips and ds.center_crop == (120, 120) and ds.resize == (64, 64)
+    assert not D.build_split("KTH", root, 4, 6, "test").flips
+
+
+def test_kitti_clip_lists_match_the_reference_walker(tmp_path):
+    """ref KITTIDataset (dataset.py:445-515): sorted drive folders, ids 10..13 test, the first two others validation"""
+    g, root, rel = _golden_tree(tmp_path, "KITTI")
+    lists = D.kitti_clip_lists(root, g["clip_length"], (10, 11, 12, 13), train=True, val=True)
+    assert rel(lists["train"]) == g["train"] and rel(lists["val"]) == g["val"]
+    assert rel(D.kitti_clip_lists(root, g["clip_length"], (10, 11, 12, 13), train=False)["test"]) == g["test"]
+    assert len(D.build_split("KITTI", root, 3, 4, "train")) == len(g["train"])
+    assert D.build_split("KITTI", root, 3, 4, "test").flips, "the reference gives its KITTI test set the TRAIN transform"
+
+
+def test_bair_and_cityscapes_walkers_match_the_reference(tmp_path):
+    """ref BAIRDataset / CityScapesDataset.__getClips__ (dataset.py:401-443); the reference lists folders unsorted: compared sorted"""
+    g, root, rel = _golden_tree(tmp_path, "BAIR")
+    assert sorted(rel(D.frame_folder_clips(root, g["clip_length"]))) == g["clips"]
+    g, root, rel = _golden_tree(tmp_path, "CityScapes")
+    assert sorted(rel(D.cityscapes_clips(root, g["clip_length"]))) == g["clips"]
+
+
+@pytest.mark.parametrize("tag", ["stochastic", "deterministic"])
+def test_stochastic_moving_mnist_matches_the_reference_generator(tag):
+    """ref StochasticMovingMNIST.__getnparray__ (dataset.py:716-778) run on seeded synthetic digits: the same clips, bit for bit
+    (numpy's legacy stream seeded once with the first index), and the uint8 frames its ToPILImage would hand to VidToTensor"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "smmnist.npz"))
+    ds = D.StochasticMovingMNIST(g["digits"], 5, 7, deterministic=tag == "deterministic")
+    idx = g[f"idx_{tag}"].tolist()
+    clips = np.stack([ds.clip_float(i) for i in idx], 0)
+    assert clips.shape == g[f"clips_{tag}"].shape and np.array_equal(clips, g[f"clips_{tag}"])
+    ds2 = D.StochasticMovingMNIST(g["digits"], 5, 7, deterministic=tag == "deterministic")
+    u8 = ds2[idx[0]]
+    assert u8.dtype == np.uint8 and u8.shape == (12, 64, 64, 1)
+    assert np.array_equal(u8[..., 0], (g[f"clips_{tag}"][0][:, 0] * np.float32(255)).astype(np.uint8))
+
+
+def test_mnist_idx_reader_and_95_5_split(tmp_path):
+    """load_mnist_digits reads torchvision's raw idx layout; build_split('SMMNIST') = the generator over it, split 95 / 5"""
+    raw = tmp_path / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, size=(40, 28, 28), dtype=np.uint8)
+    hdr = np.array([2051, 40, 28, 28], dtype=">i4").tobytes()
+    (raw / "train-images-idx3-ubyte").write_bytes(hdr + imgs.tobytes())
+    d = D.load_mnist_digits(tmp_path, train=True)
+    assert d.shape == (40, 32, 32) and d.dtype == np.float32 and 0.0 <= d.min() and d.max() <= 1.0
+    from PIL import Image
+    assert np.array_equal(d[3], np.asarray(Image.fromarray(imgs[3], 'L').resize((32, 32), Image.BILINEAR), dtype=np.float32) / 255.0)
+    tr, va = D.build_split("SMMNIST", tmp_path, 5, 15, "train"), D.build_split("SMMNIST", tmp_path, 5, 15, "val")
+    assert len(tr) == 38 and len(va) == 2 and tr[0].shape == (20, 64, 64, 1)
+    assert sorted(tr.indices + va.indices) == list(range(40))
+    with pytest.raises(FileNotFoundError):
+        D.load_mnist_digits(tmp_path, train=False)
 
 
 def test_train_val_split_is_torch_random_split():
