@@ -73,8 +73,17 @@ int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, long 
                   const float* residual, long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2,
                   const unsigned long long* seed, unsigned int salt, float alpha, int precision, float* colsum_a,
                   const void* b_pre, int accumulate, float* rowstats, const float* a_amax, const float* b_amax,
-                  float* c_amax, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt, void* workspace,
-                  long long ws_bytes, npvp_stream_t stream);
+                  float* c_amax, unsigned int* range_flag, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
+                  void* workspace, long long ws_bytes, npvp_stream_t stream);
+/* Range of the precision-6 (two-term fp16) arithmetic, per ROW.  Operands are scaled by ONE power of two per tensor (their amax
+ * slot), so a row that lies 2^18 or more below its tensor's bound would keep only subnormal low terms.  Forward / dgrad launches
+ * (kernel ids 5 / 7) repair this themselves: every thread keeps the running |max| of the rows of A it stages, and a tile in which
+ * some row lies that far below the bound is computed a second time with every row scaled by the power of two of its OWN maximum
+ * (exact; results bit-identical to the one-pass form when no row qualifies; cost: that tile twice).  A weight-gradient launch
+ * (kernel id 6; the rows of dW are the COLUMNS of its operand A = dy) only detects the condition per workgroup K-chunk and, if
+ * `range_flag` (nullable, a device counter the caller zeroed) is given, adds to it; the caller then re-runs that weight gradient
+ * with precision 4, whose bf16 terms have fp32's exponent range (npvp_amd.ops.linear_wgrad: at once in strict mode, from the next
+ * step on otherwise).  tests/test_hip_ops.py::test_heavy_tailed_rows_keep_their_precision. */
 /* adrop_p > 0 (precision 6, launches that npvp_gemm_kernel_id maps to the fp16 kernels 5 / 6 / 7 only; anything else is an
  * argument error): a ROW-GROUP mask on the rows of operand A - row r is multiplied by the DropPath decision of group
  * (r / adrop_g1) % adrop_g2 (0 or 1 / (1 - p); same (seed, salt) stream as the forward site).  This is the backward of a DropPath

@@ -18,7 +18,7 @@ SIGNATURES = {
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
-                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
+                              c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p,
                               c_f, c_int, c_int, c_u, c_p, c_ll, c_p]),
     "npvp_amax": (c_int, [c_p, c_ll, c_ll, c_ll, c_p, c_p]),
     "npvp_split_weight_f16": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p, c_p]),

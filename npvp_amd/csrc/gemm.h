@@ -34,6 +34,7 @@ struct GemmParams {
   // fp16 two-term kernels (gemm_f16.hip): amax slots (32 floats whose maximum bounds |operand|) of A and B; any kernel:
   // c_amax (nullable) receives the bound of the values this launch stores to C (the next GEMM's a_amax)
   const float* a_amax; const float* b_amax; float* c_amax;
+  unsigned int* range_flag;   // nullable; fp16 weight-gradient kernel: raised when a column of A lies 2^18 below its bound (see the kernel)
 };
 
 __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {

@@ -566,7 +566,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              float* aux_out, const float* residual, long long ldr, float drop_p, int drop_mode,
                              int drop_g1, int drop_g2, const unsigned long long* seed, unsigned int salt, float alpha,
                              int precision, float* colsum_a, const void* b_pre, int accumulate, float* rowstats,
-                             const float* a_amax, const float* b_amax, float* c_amax,
+                             const float* a_amax, const float* b_amax, float* c_amax, unsigned int* range_flag,
                              float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
                              void* workspace, long long ws_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
@@ -609,7 +609,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.splits = splits;
   p.colsum = colsum_a;
   p.rowstats = rowstats;
-  p.a_amax = a_amax; p.b_amax = b_amax; p.c_amax = c_amax;
+  p.a_amax = a_amax; p.b_amax = b_amax; p.c_amax = c_amax; p.range_flag = range_flag;
   NPVP_CHECK_ARG(!rowstats || (precision == 4 && a_kc && b_kc && M % 64 == 0 && N % 128 == 0 && act == 0 && !aux_out && !residual &&
                                drop_p == 0.f && !accumulate),
                  "gemm: rowstats needs the default (bf16x6) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");

@@ -51,6 +51,19 @@ __device__ __forceinline__ void split_f16(const f32x4 v, f16x4& hi, f16x4& lo) {
   lo[0] = la[0]; lo[1] = la[1]; lo[2] = lb[0]; lo[3] = lb[1];
 }
 
+// workgroup-wide OR of a per-thread predicate (every thread calls it; NW waves; `flags` = NW ints of LDS nobody else uses)
+template <int NW>
+__device__ __forceinline__ bool block_any(bool pred, int* flags, int wave) {
+  const bool w = __builtin_amdgcn_ballot_w64(pred) != 0ull;
+  if ((threadIdx.x & 63) == 0) flags[wave] = w ? 1 : 0;
+  __syncthreads();
+  int any = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) any |= flags[i];
+  __syncthreads();                                    // (the flags may be written again by a later call)
+  return __builtin_amdgcn_readfirstlane(any) != 0;
+}
+
 template <int TM, int TN, int WM, int WN, bool ROWSTATS>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(GemmParams p) {
   constexpr int NW = WM * WN, THREADS = 64 * NW;
@@ -119,7 +132,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R0) : "v"(a_off0), "s"(ab_) : "memory");          \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R1) : "v"(a_off1), "s"(ab_) : "memory"); }
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
-  { f16x4 hi_, lo_; split_f16((V) * ((ROWOFF) ? sa1 : sa0), hi_, lo_);                   \
+  { if (ROWOFF) rm1 = fmaxf(fmaxf(rm1, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));  \
+    else rm0 = fmaxf(fmaxf(rm0, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));         \
+    f16x4 hi_, lo_; split_f16((V) * ((ROWOFF) ? sa1 : sa0), hi_, lo_);                   \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
     *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
   // LDS-DMA with a scalar base + 32-bit lane offset, M0 = the piece's LDS address (the builtin takes a 64-bit per-lane pointer
@@ -133,6 +148,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
                      :: "s"(m0_), "v"(b_off[i_]), "s"(bb_) : "memory", "m0"); } }
   static_assert(NCHUNK % NW == 0, "the hand-counted waits assume CPW LDS-DMA pieces per wave and step");
 
+  // ROW GUARD.  One scale per TENSOR leaves a token row that lies far below the tensor's bound with few significant bits (its
+  // low terms are fp16 subnormals: an absolute error of 2^-40 of the bound).  Every thread therefore keeps the running |max| of
+  // the two rows it stages (rm0 / rm1: 4 v_max3 per K-step); when the K loop is done and some row of the tile turns out to lie
+  // 2^18 or more below the bound (its largest low term was subnormal), the TILE is computed again with every row scaled by the
+  // power of two of its OWN maximum - the staging already multiplies by a per-thread factor (sa0 / sa1), so the second pass is
+  // the same loop - and the accumulators are brought back to the tensor's scale (exact: powers of two) before the epilogue.
+  // Real training tensors never take the second pass (their smallest rows sit 2^15 below the bound, profiles/r04_f16_range_audit.txt);
+  // a tile whose rows span more than 2^18 costs twice.  Zero rows (dropped samples) and rows below 2^-111 are left alone.
+  __shared__ int guard_flags[NW];
+  float rm0 = 0.f, rm1 = 0.f;
+  bool rescued = false;
+  const float zrow = 1.f;
+  float rf0 = zrow, rf1 = zrow;                         // 2^-(distance of the row's exponent from the bound's), second pass only
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto run_tile = [&]() __attribute__((always_inline)) {
   // prologue: tile 0 -> stage 0 (B by DMA, A through the registers), A tiles 1 and 2 -> register sets
   NPVP_H_BLOAD(lds, 0)
   NPVP_H_ALOAD(ea0, ea1, 0)
@@ -176,7 +206,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   NPVP_H_STEP_(0, 0, 1, ea0, ea1, eb0, eb1, true)
   int kt = 1;
   for (; kt + 1 < nk; kt += 2) {
@@ -184,7 +213,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
     NPVP_H_STEP(kt + 1, 0, 1, ea0, ea1, eb0, eb1)
   }
   if (kt < nk) NPVP_H_STEP(kt, 1, 0, eb0, eb1, ea0, ea1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the clamped loads past the last tile)
+  // (the clamped loads past the last tile.  Both register sets are TIED to the wait: the last two steps' loads are never read,
+  //  and a dead asm output may be given a register that the code between the load and this wait uses for something else -
+  //  the load then lands in it.  Seen as intermittent wrong tiles once the row guard changed the register allocation.)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1), "+v"(eb0), "+v"(eb1) :: "memory");
+  };
+  run_tile();
+  {
+    rm0 = fmaxf(rm0, __shfl_xor(rm0, 1)); rm0 = fmaxf(rm0, __shfl_xor(rm0, 2));       // the four lanes that stage one row
+    rm1 = fmaxf(rm1, __shfl_xor(rm1, 1)); rm1 = fmaxf(rm1, __shfl_xor(rm1, 2));
+    const int et = (int)((__float_as_uint(sa) >> 23) & 0xffu);                         // sa = 2^(141 - E_bound): exponent field 268 - E_bound
+    const int e0 = (int)((__float_as_uint(rm0) >> 23) & 0xffu), e1 = (int)((__float_as_uint(rm1) >> 23) & 0xffu);
+    // distance of the row's exponent below the bound's: d = E_bound - E_row = (268 - et) - e
+    const int d0 = 268 - et - e0, d1 = 268 - et - e1;
+    const bool ok0 = e0 >= 16 && e0 != 255 && d0 > 0 && d0 <= 120, ok1 = e1 >= 16 && e1 != 255 && d1 > 0 && d1 <= 120;
+    // (a bound too small to scale - amax_scale returned 1 - reads as E_bound = 141 here; its rows have e < 16 and are left alone)
+    if (block_any<NW>((ok0 && d0 >= 18) || (ok1 && d1 >= 18), guard_flags, wave)) {
+      const float g0 = sa0 * pow2_recip(sa), g1 = sa1 * pow2_recip(sa);                // the row-group mask factors (1 without a_drop)
+      rf0 = ok0 ? __uint_as_float((unsigned int)(127 - d0) << 23) : 1.f;
+      rf1 = ok1 ? __uint_as_float((unsigned int)(127 - d1) << 23) : 1.f;
+      sa0 = (ok0 ? amax_scale(rm0) : sa) * g0;
+      sa1 = (ok1 ? amax_scale(rm1) : sa) * g1;
+      rescued = true;
+      run_tile();
+    }
+  }
 #undef NPVP_H_STEP
 #undef NPVP_H_STEP_
 #undef NPVP_H_BLOAD
@@ -215,7 +268,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
   float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;      // per-wave transposition scratch (the stages are idle:
-  static_assert(2 * STAGE >= (4 + NW * EPI_FLOATS) * 4, "scratch");         // the K loop ended on a barrier); 4 floats: amax commit
+  static_assert(2 * STAGE >= (4 + NW * EPI_FLOATS + BM) * 4, "scratch");    // the K loop ended on a barrier); 4 floats: amax commit
+  if (rescued) {                                                            // (workgroup-uniform) rows back to the tensor's scale
+    float* rowfac = reinterpret_cast<float*>(lds) + 4 + NW * EPI_FLOATS;
+    if (quad == 0) { rowfac[rl] = rf0; rowfac[rl + BM / 2] = rf1; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float f = rowfac[wm * TM * 32 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][g] *= f;
+      }
+  }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (NPVP_H_ABL & 1) {
 #pragma unroll
@@ -311,6 +377,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 
   const bool want_cs = p.colsum && tile_n == 0;
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  // COLUMN WATCH.  A column m of dy is a ROW of dW; one scale per tensor leaves an output feature whose gradients lie 2^18 or more
+  // below the tensor's bound with subnormal low terms.  Unlike gemm_f16_kernel's row guard this kernel does not repair such a
+  // chunk in place (a second pass around this loop is not expressible without disturbing its hand-counted asynchronous loads);
+  // it DETECTS it - every thread keeps the running |max| of the four columns of the A tile it stages (cm4) - and raises
+  // p.range_flag, on which the host re-runs the weight gradient in the bf16x6 arithmetic (fp32's exponent range).
+  f32x4 cm4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 ra[2], rb[4];
 #define NPVP_G_LOAD(KT)                                                                                     \
   { const int kt_ = min((KT), nk - 1);                                                                      \
@@ -330,7 +402,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   const long long arow0 = (long long)z * p.K;
   float am_ = 1.f;
 #define NPVP_G_AMASK(KT) { if (p.adrop.thresh) am_ = drop_spec_scale(p.adrop, aseed, arow0 + 16ll * min((KT), nk - 1), 0, 1); }
-#define NPVP_G_STORE_A(ST) { const float sam_ = sa * am_; NPVP_G_STORE((ST) + a_dst, ra[0], sam_, A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], sam_, A_PLANE) }
+#define NPVP_G_STORE_A(ST) { const float sam_ = sa * am_;                                                                        \
+    if (p.range_flag) cm4 = __builtin_elementwise_max(cm4, __builtin_elementwise_max(__builtin_elementwise_abs(ra[0]), __builtin_elementwise_abs(ra[1]))); \
+    NPVP_G_STORE((ST) + a_dst, ra[0], sam_, A_PLANE) NPVP_G_STORE((ST) + a_dst + 8 * ROWA, ra[1], sam_, A_PLANE) }
 #define NPVP_G_STORE_B(ST, I) NPVP_G_STORE((ST) + b_dst + (I) * 4 * ROWB, rb[I], sb, B_PLANE)
 
   NPVP_G_LOAD(0)
@@ -374,7 +448,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
     NPVP_G_STEP(kt + 1, 1, 0)
   }
   if (kt < nk) NPVP_G_STEP(kt, 0, 1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the clamped loads past the last tile still target ra / rb)
+  // (the clamped loads past the last tile still target ra / rb: TIED to the wait - a dead asm output may be given a register that
+  //  the code between the load and this wait uses for something else, and the load then lands in it; see gemm_f16_kernel)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) :: "memory");
+  if (p.range_flag) {
+    // column maxima of the chunk: 8 threads (ka = 0..7, all four waves) hold partial maxima of the same four columns
+    float* red = reinterpret_cast<float*>(lds);            // (the stages are idle: the loop ended on a barrier)
+    *reinterpret_cast<f32x4*>(red + ka * BM + 4 * cqa) = cm4;
+    __syncthreads();
+    bool flag = false;
+    if (t < BM) {
+      float m = red[t];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i * BM + t]);
+      const int et = (int)((__float_as_uint(sa) >> 23) & 0xffu), e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+      const int d = 268 - et - e;                           // exponent distance below the tensor's bound (sa = 2^(141 - E_bound))
+      flag = e >= 16 && e != 255 && d >= 18 && m0 + t < p.M;
+    }
+    const bool any = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+    if (any && lane == 0) atomicAdd(p.range_flag, 1u);
+    __syncthreads();                                        // (`red` is about to be reused)
+  }
 #undef NPVP_G_STEP
 #undef NPVP_G_WAIT
 #undef NPVP_G_STORE_B

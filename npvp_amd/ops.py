@@ -580,7 +580,7 @@ GEMM_EXCLUSIVE = os.environ.get("NPVP_GEMM_EXCL", "0") == "1"
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
          drop=NO_DROP, alpha=1.0, colsum_a=None, b_pre=None, accumulate=False, rowstats=None, precision=None,
-         replay=False, a_amax=None, b_amax=None, c_amax=None, a_drop=NO_DROP):
+         replay=False, a_amax=None, b_amax=None, c_amax=None, a_drop=NO_DROP, range_flag=None):
     """replay=True: `drop` replays a forward site's mask in backward (not a new site for ops.DropRecorder).
     b_pre = WeightPlanes.get(...) = (planes, weight amax slot) or None; a_amax / b_amax: the operands' amax slots (f16x3; a
     missing slot of A - or of B for a weight gradient - is filled by the stand-alone reduction); c_amax: slot that receives
@@ -627,7 +627,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
                           _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
                           drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, prec, _ptr(colsum_a),
-                          _ptr(planes), int(accumulate), _ptr(rowstats), _ptr(a_amax), _ptr(b_amax), _ptr(c_amax),
+                          _ptr(planes), int(accumulate), _ptr(rowstats), _ptr(a_amax), _ptr(b_amax), _ptr(c_amax), _ptr(range_flag),
                           a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(ws), wsn, _stream()),
           "npvp_gemm_f32")
     if probe:
@@ -710,17 +710,87 @@ def masked_grad(dy2, drop, w):
 DROP_PATH_IN_GEMM_ROWS = int(os.environ.get("NPVP_DROP_PATH_IN_GEMM_ROWS", "32768"))
 
 
+class RangeGuard:
+    """The per-ROW range of the two-term fp16 arithmetic (include/npvp_hip.h, `range_flag`).  Forward / dgrad GEMMs repair a tile
+    whose rows lie 2^18 or more below the operand's bound themselves (a second pass with per-row scales, inside the kernel).  The
+    weight-gradient kernel only DETECTS a feature (a column of dy = a row of dW) that far below dy's bound and raises a device
+    counter; what happens then:
+      strict (NPVP_RANGE_GUARD=strict, RangeGuard.strict = True: tests, audits): linear_wgrad reads the counter right after the
+          launch (a device synchronisation per weight gradient) and re-runs THAT gradient in the six-term bf16 arithmetic, which
+          has fp32's exponent range;
+      default: nothing is read inside the step.  The training step reads the counter where it reads its loss scalars anyway
+          (trainer.predictor_train_step(sync=True) -> 'f16_range_events'); from the first event on, every weight gradient of the
+          process runs as bf16x6 (sticky; RangeGuard.reset() re-arms).  One step's smallest feature rows are then late by one
+          step, never silently wrong for long.
+    NPVP_RANGE_GUARD=off passes no counter (the kernel then skips the column maxima)."""
+    mode = os.environ.get("NPVP_RANGE_GUARD", "on")
+    strict = mode == "strict"
+    fallback = False             # sticky: weight gradients run as bf16x6
+    events = 0                   # total raised so far (host view)
+    _flags = {}
+
+    @classmethod
+    def flag(cls, dev):
+        if cls.mode == "off":
+            return None
+        f = cls._flags.get(dev)
+        if f is None:
+            f = cls._flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            if WgradStream.enabled:
+                f.record_stream(WgradStream.stream(dev))
+        return f
+
+    @classmethod
+    def poll(cls, dev):
+        """read and clear the device counter (synchronises); arms the sticky fallback if it was raised"""
+        f = cls._flags.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
+        if f is None:
+            return 0
+        n = int(f.item())
+        if n:
+            f.zero_()
+            cls.events += n
+            cls.fallback = True
+        return n
+
+    @classmethod
+    def reset(cls):
+        cls.fallback, cls.events = False, 0
+        for f in cls._flags.values():
+            f.zero_()
+
+
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None, a_drop=NO_DROP):
     """dw[N,K] = dy[R,N]^T x[R,K]; with_bias_grad also returns db[N] = column sums of dy, accumulated by the same
     kernel while it stages dy (no separate reduction pass).  into / into_b: ACCUMULATE into these existing
-    gradient slices instead of allocating results (GradSink)."""
+    gradient slices instead of allocating results (GradSink).  Range of the fp16 arithmetic: RangeGuard."""
     R, N = dy.shape
     K = x.shape[1]
     acc = into is not None
     dw = into if acc else torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = (into_b if acc else torch.empty(N, dtype=torch.float32, device=dy.device)) if with_bias_grad else None
-    gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc,
-         precision=WGRAD_PRECISION if GEMM_PRECISION == 4 else None, a_amax=dy_amax, b_amax=x_amax, a_drop=a_drop)
+    prec = WGRAD_PRECISION if GEMM_PRECISION == 4 else None
+    watch = GEMM_PRECISION == 6 and _gemm_kernel_id(0, 0, N, K, R, 6, False) == 6
+    if watch and RangeGuard.fallback and not a_drop.on:
+        prec, watch = 4, False                     # (a launch that carries a row-group mask needs the fp16 kernel: it stays there)
+    if watch and RangeGuard.strict and not a_drop.on:
+        # strict: into a scratch result first, so that a flagged launch leaves the accumulation target untouched
+        flag = RangeGuard.flag(dy.device)
+        tw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        tb = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias_grad else None
+        gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), tw, colsum_a=tb, a_amax=dy_amax, b_amax=x_amax, range_flag=flag)
+        if RangeGuard.poll(dy.device):
+            RangeGuard.fallback = False             # (strict mode repairs launch by launch)
+            gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), tw, colsum_a=tb, precision=4)
+        if acc:
+            dw.add_(tw)
+            if tb is not None:
+                db.add_(tb)
+        else:
+            dw, db = tw, tb
+        return (dw, db) if with_bias_grad else dw
+    gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc, precision=prec, a_amax=dy_amax, b_amax=x_amax,
+         a_drop=a_drop, range_flag=RangeGuard.flag(dy.device) if watch else None)
     return (dw, db) if with_bias_grad else dw
 
 

@@ -252,6 +252,9 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
            "Image_L1": None if img is None else img.detach()}
     if sync:
         out = {k: (None if v is None else float(v)) for k, v in out.items()}
+        # weight-gradient launches that met a feature 2^18 below its tensor's bound in this step (ops.RangeGuard: from the first
+        # event on the process's weight gradients run in the bf16x6 arithmetic); read where the scalars are read anyway
+        out["f16_range_events"] = ops.RangeGuard.poll(dev)
     return out
 
 

@@ -24,30 +24,54 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-ERR_LOG = os.environ.get("NPVP_ERR_LOG")      # optional: append "<tag> <key> <rel-L2>" lines (GPU triage)
+def max_row_rel_err(a, b, floor=1e-6):
+    """Worst relative L2 error of a ROW (a vector along the last axis: a token row of an activation or of its gradient, an
+    output-feature row of a weight gradient) - the whole-tensor rel-L2 is blind to a few small rows that are wrong.  Rows whose
+    reference norm is below `floor` x the largest row norm are not counted (where rows mix - attention, frame norms, residual
+    sums - such a row is below the fp32 resolution of the tensor it was computed from, in the reference's own arithmetic too);
+    floor = 0 counts every non-zero row (pure GEMMs: a row of the product depends on that row of the operand only).
+    Returns 0 for tensors with fewer than two axes."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    if b.dim() < 2 or a.shape != b.shape or b.shape[-1] < 2:
+        return 0.0
+    a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    nb = b.norm(dim=1)
+    keep = nb > max(floor * float(nb.max()), 0.0)
+    keep &= nb > 0
+    if not bool(keep.any()):
+        return 0.0
+    return float(((a - b).norm(dim=1)[keep] / nb[keep]).max())
 
 
-def log_err(tag, key, e):
+ERR_LOG = os.environ.get("NPVP_ERR_LOG")      # optional: append "<tag> <key> <rel-L2> <worst row>" lines (GPU triage)
+
+
+def log_err(tag, key, e, er=None):
     if ERR_LOG:
         with open(ERR_LOG, "a") as f:
-            f.write(f"{tag} {key} {e:.3e}\n")
+            f.write(f"{tag} {key} {e:.3e}" + (f" row {er:.3e}" if er is not None else "") + "\n")
 
 
-def compare(results, golden, tol, skip=(), tag=""):
-    """Every golden array (except meta) must be reproduced within rel-L2 `tol`."""
+def compare(results, golden, tol, skip=(), tag="", row_tol=1e-3):
+    """Every golden array (except meta) must be reproduced within rel-L2 `tol`, and - for arrays stored with their row
+    structure - every row of it within `row_tol` (max_row_rel_err; 1e-3 = north_star's bar)."""
     worst = 0.0
-    errs = {}
+    errs, rerrs = {}, {}
     for key, g in golden.items():
         if key == "meta" or key in skip:
             continue
         assert key in results, f"case does not produce golden key {key}"
         mine = O.golden_view(results[key]) if results[key].numel() != g.size else results[key]
         e = rel_err(mine, g)
+        er = max_row_rel_err(mine, g) if tuple(torch.as_tensor(mine).shape) == tuple(g.shape) else 0.0
         worst = max(worst, e)
         errs[key] = e
-        log_err(tag, key, e)
+        rerrs[key] = er
+        log_err(tag, key, e, er)
     bad = {k: f"{v:.3e}" for k, v in errs.items() if not v < tol}
     assert not bad, f"rel-L2 above {tol:.1e}: {bad}"
+    bad = {k: f"{v:.3e}" for k, v in rerrs.items() if not v < row_tol}
+    assert not bad, f"worst-row rel-L2 above {row_tol:.1e}: {bad}"
     return worst
 
 

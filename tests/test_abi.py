@@ -34,7 +34,7 @@ def test_argument_errors_do_not_need_a_gpu(built):
     from npvp_amd._lib import lib
     L = lib()
     rc = L.npvp_gemm_f32(1, 1, 128, 128, 33, None, 36, None, 36, None, 128, None, 0, None, None, None, 0, 0.0, 0, 1, 1,
-                         None, 0, 1.0, 0, None, None, 0, None, None, None, None, 0.0, 1, 1, 0, None, 0, None)
+                         None, 0, 1.0, 0, None, None, 0, None, None, None, None, None, 0.0, 1, 1, 0, None, 0, None)
     assert rc == -1 and b"multiple of 32" in L.npvp_last_error()
     assert L.npvp_layernorm_fwd(None, None, None, None, None, None, 4, 500, 1e-5, 0, None, None) == -1
     assert L.npvp_attn_fwd(None, 512, None, 512, None, 512, None, 512, 1, 1, 64, 8, 0, 40, 40, 8, 64, 0, 0.0, None, 0, None, None) == -1
