@@ -15,17 +15,21 @@ do not take - fewer than 128 rows, no weight planes - run the three-term bf16 sp
 
 PRIMARY workload (the `value` line) = BASELINE.json configs[2], the largest single-GPU configuration:
 BAIR 64x64 NPVP-D, 64 clips per GPU, To=2, Tp=28 (T=30).  At N > 1 it is WEAK scaling: every rank gets
-its own 64 clips, gradients are all-reduced over RCCL.  SECONDARY workloads (shorter runs, reported under
-`secondary`): at N = 1 every other BASELINE configuration - north_star's "BAIR B=64 T=20" target line (c2p),
-configs[1] (c1), configs[0] (c0), the per-GPU shards of configs[3] / configs[4] (c3s / c4s: 8 clips of
-128x128 Cityscapes / KITTI, the N = 1 denominators of the N = 4 / 8 lines) and the FULL step from pixels
-through the frozen autoencoder on a 64x64 (full64 = c1) and a 128x128 (full128 = the c4 shard) workload;
-at N = 4 / 8 the BASELINE configuration named for that GPU count (c3 / c4, 8 clips per GPU).
+its own 64 clips, gradients are all-reduced over RCCL.  SECONDARY workloads (shorter runs; `secondary` is a compact
+{key: [ms_per_step, frames_per_s]} map, the details go to stderr): at N = 1 every other BASELINE configuration -
+north_star's "BAIR B=64 T=20" target line (c2p), configs[1] (c1), configs[0] (c0), the per-GPU shards of configs[3] /
+configs[4] (c3s / c4s: 8 clips of 128x128 Cityscapes / KITTI), their FULL global batches on one GPU (c3full: 32 clips,
+c4full: 64 clips - the honest denominators of a strong-scaling ratio) and the FULL step from pixels through the frozen
+autoencoder on a 64x64 (full64 = c1) and a 128x128 (full128 = the c4 shard) workload; at N = 2 / 4 / 8 the BASELINE
+data-parallel configuration for that GPU count (c3 on 4, c4 on 8 and - as a rehearsal - on 2; 8 clips per GPU), and in the SAME
+run rank 0 alone times that configuration's global batch and its shard on one GPU, so that `scaling_dp` carries both the
+strong ratio (N GPUs / the whole batch on 1) and the shard efficiency (N GPUs / N x one shard on 1).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the GEMM layout - forward or dgrad -
 with the largest share of the timed region, timed live with HIP event pairs around every launch on the
-stream it is launched on) and, at N=1, `cpu_baseline` (the CPU oracle restatement of the same step on a
-bounded sample, host cores stated).
+stream it is launched on), `roofline_hbm` (the three kernels that lead the HBM-bound half of the step: algorithmic bytes,
+event-pair time in the step, TB/s against 8 TB/s) and, at N=1, `cpu_baseline` (the CPU oracle restatement of the same step
+on a bounded sample, host cores stated).
 """
 import argparse
 import gc
@@ -48,7 +52,11 @@ WORKLOADS = {   # name -> (config file, variant, per-GPU clips, To, Tp)
     "c0": ("config_SMMNIST_VFP_NPVP-S.yaml", "SM-MNIST 64x64 NPVP-S B=4 T=20 (BASELINE configs[0])", 4, 5, 15),
     "c3": ("config_Cityscapes_VFP_NPVP-S.yaml", "Cityscapes 128x128 NPVP-S B=32 T=14 over 4 GPUs (BASELINE configs[3], per-GPU shard)", 8, 2, 12),
     "c4": ("config_KITTI_VFP_NPVP-D.yaml", "KITTI 128x128 NPVP-D B=64 T=20 over 8 GPUs (BASELINE configs[4], per-GPU shard)", 8, 4, 16),
+    # the same two configurations with their WHOLE global batch on one GPU: the denominators of a strong-scaling ratio
+    "c3full": ("config_Cityscapes_VFP_NPVP-S.yaml", "Cityscapes 128x128 NPVP-S B=32 T=14 (BASELINE configs[3]) whole batch on ONE GPU", 32, 2, 12),
+    "c4full": ("config_KITTI_VFP_NPVP-D.yaml", "KITTI 128x128 NPVP-D B=64 T=20 (BASELINE configs[4]) whole batch on ONE GPU", 64, 4, 16),
 }
+HBM_PEAK_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured by a float4 copy)
 MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); fp32-input MFMA: 157.3
 LAYOUTS = {(1, 1): "forward", (1, 0): "dgrad", (0, 0): "wgrad"}
 
@@ -119,25 +127,29 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None):
+def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None):
     """Build the workload's model / optimiser / synthetic batch, run `warmup` untimed and `steps` timed steps
-    (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict"""
+    (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict.  world = 1 inside a multi-rank job =
+    a SOLO run of the calling rank (no collectives, no barrier): the one-GPU denominators of `scaling_dp`."""
     import npvp_amd
     from npvp_amd import dp, ops
     from npvp_amd.trainer import load_config, cosine_warm_restarts_lr
 
     cfg_file, name, B, To, Tp = WORKLOADS[key]
+    if clips is not None:
+        B = clips
     cfg = load_config(os.path.join(ROOT, "configs", cfg_file), B, To, Tp)
     P = cfg["Predictor"]
     torch.manual_seed(cfg["Env"]["rand_seed"])
     model = npvp_amd.build_predictor_from_cfg(npvp_amd.Predictor, P, To, Tp).to(dev)       # dropout/drop-path 0.1 defaults
-    if world > 1:
+    dp_on = world > 1 or (dp.FORCE and dp.active())        # (NPVP_DP_FORCE=1: the data-parallel machinery on a group of one rank)
+    if dp_on:
         dp.broadcast_module(model)
         dp.convert_sync_batchnorm(model)
     model.train()
     log(f"[{key}] model built: {name}, {B} clips/GPU, To={To}, Tp={Tp}, world={world}")
     opt = npvp_amd.FlatAdamW(model, lr=P["predictor_lr"], clip_module=model.transformer, max_grad_norm=P["max_grad_norm"])
-    gsync = dp.GradSync(opt.buf) if world > 1 else None
+    gsync = dp.GradSync(opt.buf) if dp_on else None
     ops.rng.manual_seed(cfg["Env"]["rand_seed"] + rank, dev)
 
     g = torch.Generator().manual_seed(cfg["Env"]["rand_seed"] + rank)
@@ -172,7 +184,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -210,7 +222,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     assert loss == loss, "loss is NaN"
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dp_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
     ms = 1000.0 * dt / steps
@@ -219,14 +231,28 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     log(f"[{key}] {steps} timed steps: {ms:.2f} ms/step (host enqueue {1000.0 * t_host / steps:.2f} ms/step, slowest {1000.0 * host_max:.2f}), "
         f"{frames / (ms * 1e-3):.0f} frames/s; host ms per step: " + " ".join(f"{1000.0 * h:.0f}" for h in host_all))
 
-    roof = None
+    roof, roof_hbm = None, None
+    if probe and not args.graph:
+        # the HBM-bound family, timed in two EXTRA steps after the clock stopped (the event packets fence their neighbours)
+        ops.HbmProbe.armed, ops.HbmProbe.records = True, []
+        for i in range(2):
+            step(warmup + steps + i)
+        fence()
+        ops.HbmProbe.armed = False
+        roof_hbm = []
+        for kname, (n, pms, pby) in sorted(ops.HbmProbe.summary().items(), key=lambda kv: -kv[1][1]):
+            tbs = pby / (pms * 1e-3) / 1e12
+            roof_hbm.append({"kernel": kname, "bound": "hbm", "launches_per_step": n // 2, "algorithmic_bytes_per_launch": round(pby / n),
+                             "avg_launch_us": round(1000.0 * pms / n, 1), "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                             "frac": round(tbs / HBM_PEAK_TBS, 3)})
+        ops.HbmProbe.records = []
     if probe:
         per = ops.GemmProbe.summary()           # {((a_kc,b_kc), kernel id): (launches, ms, flops, bytes)}
-        groups = {}
+        groups = {}            # "<layout>:<kernel id>" -> [launches, average us, algorithmic TFLOP/s]
         for (lay, kid), (n, pms, pfl, pby) in per.items():
-            groups[f"{LAYOUTS[lay]}:{ops.GemmProbe.KERNELS[kid]}"] = {
-                "launches": n, "avg_launch_us": round(1000.0 * pms / n, 2), "achieved_tflops": round(pfl / (pms * 1e-3) / 1e12, 2),
-                "algorithmic_bytes_per_launch": round(pby / n), "total_ms": round(pms, 2)}
+            groups[f"{LAYOUTS[lay]}:{kid}"] = [n, round(1000.0 * pms / n, 1), round(pfl / (pms * 1e-3) / 1e12, 1)]
+            log(f"[{key}] probe {LAYOUTS[lay]}:{ops.GemmProbe.KERNELS[kid]}: {n} launches, {1000.0 * pms / n:.1f} us average, "
+                f"{pfl / (pms * 1e-3) / 1e12:.1f} TF algorithmic, {pby / n / 1e6:.0f} MB algorithmic per launch, {pms:.1f} ms in all")
         # dominant kernel = the one with the largest total time among the kernels of the critical path (forward and dgrad
         # launches: same stream as the step).  The weight-gradient GEMMs run on the low-priority gradient stream UNDER other
         # kernels, so their event-pair durations include time-sharing; they are reported but not used for the fraction.
@@ -241,7 +267,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
             kname = ops.GemmProbe.KERNELS[kid]
             ach = pfl / (pms * 1e-3) / 1e12
             traffic = None
-            tj = os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{key}.json")
+            tj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r_}_hbm_traffic_{key}.json") for r_ in (4, 3)) if os.path.exists(q)), "")
             if os.path.exists(tj) and not full:
                 # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command (separate
                 # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r03_hbm_traffic_<key>.*
@@ -249,34 +275,27 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
                 traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
             f16 = kid in (5, 6, 7)
             mfmas = 1 if kid == 0 else (3 if f16 else 6)
-            desc = {5: " (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into two amax-scaled fp16 terms, "
-                       "scaled fp16 weight planes by LDS-DMA)",
-                    7: " (forward + dgrad launches; the same kernel on 128x128 tiles)",
-                    2: " (forward + dgrad launches; 128x256 tiles, 4 waves, A split on the fly into three bf16 terms, pre-split "
-                       "weight planes by LDS-DMA)"}.get(kid, "")
-            roof = {"bound": "mfma", "kernel": kname + desc,
+            roof = {"bound": "mfma", "kernel": kname + " (forward + dgrad launches)",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "mfma_per_product": mfmas,
                     "mfma_pipe_busy_frac": round(mfmas * ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
-                    "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel": groups,
-                    "probe": "every GEMM launch" if args.probe_all else "forward / dgrad launches of the wide kernels (--probe-all: all)",
-                    "note": "achieved = ALGORITHMIC fp32-equivalent flops (2MNK) / event-pair time over every forward and dgrad "
-                            f"launch of this kernel in the timed region; each product costs {mfmas} matrix instructions "
-                            + ("(v_mfma_f32_32x32x16_f16 on two amax-scaled fp16 terms per operand: fp32-grade)" if f16 else
-                               "(v_mfma_f32_32x32x16_bf16 on three bf16 terms per operand: fp32-grade)" if mfmas == 6 else "(fp32-input MFMA)")
-                            + f", so frac <= 1/{mfmas} of the dense 16-bit MFMA peak by construction and mfma_pipe_busy_frac = "
-                            f"{mfmas} x frac is the share of that peak the matrix pipe delivers (the sustained f16 MFMA rate of "
-                            "this part on non-trivial operands is ~1.5-1.66 PFLOP/s: tools/f16_probe.hip)",
+                    "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel_id": groups,
+                    "note": f"achieved = algorithmic 2MNK flops / event-pair time of every launch; {mfmas} MFMAs per fp32-grade product, "
+                            f"so frac <= 1/{mfmas} by construction",
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
     log(f"[{key}] peak device memory {peak_gb:.1f} GiB")
     torch.cuda.reset_peak_memory_stats(dev)
+    events = ops.RangeGuard.poll(dev)           # weight-gradient launches that met a feature 2^18 below its tensor's bound (0 expected)
     res = {"key": key, "name": name, "B": B, "To": To, "Tp": Tp, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "peak_gb": peak_gb,
-           "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "steps": steps,
-           "warmup": warmup}
+           "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "roof_hbm": roof_hbm, "steps": steps,
+           "warmup": warmup, "range_events": events}
     if gsync is not None:
+        res["dp"] = {"backend": dist.get_backend(), "buckets": len(gsync.buckets), "last_bucket_mb": round((gsync.buckets[0]["hi"] - gsync.buckets[0]["lo"]) * 4 / 2 ** 20, 1),
+                     "allreduces_launched": gsync.launched, "exposed_allreduce_ms_per_step": round(gsync.exposed_ms(), 3)}
+        log(f"[{key}] data parallel: " + json.dumps(res["dp"]))
         gsync.remove()
     del model, opt, gsync, past, fut, out, step
     gc.collect()
@@ -322,50 +341,75 @@ def main():
 
     main_res = run_workload(args.workload, args.steps, args.warmup, args, rank, world, dev, probe=not args.no_probe)
 
-    secondary = {}
+    secondary, detail, scaling_dp = {}, {}, None
     if not args.no_secondary and args.workload == "c2" and not args.graph and args.flavour == "predictor":
-        # (key in the JSON, workload, flavour): every BASELINE configuration the primary line does not cover
-        plan = {1: [("c2p", "c2p", None), ("c1", "c1", None), ("c0", "c0", None), ("c3s", "c3", None), ("c4s", "c4", None),
-                    ("full64", "c1", "full"), ("full128", "c4", "full")],
-                2: [("c4s", "c4", None)], 4: [("c3", "c3", None)], 8: [("c4", "c4", None)]}.get(world, [])
-        for name, k, flav in plan:
-            r = run_workload(k, max(4, args.steps // 2), min(3, args.warmup) or 1, args, rank, world, dev, probe=False, flavour=flav)
-            secondary[name] = {"workload": r["name"] + (" - FULL step from pixels through the frozen autoencoder" if flav == "full" else
-                                                        " - predictor-only step"),
-                               "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"],
-                               "value": round(r["frames_per_s"], 2), "unit": "frames/s", "ms_per_step": round(r["ms"], 3),
-                               "steps": r["steps"], "warmup": r["warmup"],
-                               "whole_step_tflops_per_gpu": round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 2),
-                               "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)}
+        sec_steps, sec_warm = max(4, args.steps // 2), min(3, args.warmup) or 1
+
+        def note(name, r, flav=None, solo=False):
+            secondary[name] = [round(r["ms"], 2), round(r["frames_per_s"], 1)]
+            detail[name] = {"workload": r["name"] + (" - FULL step from pixels through the frozen autoencoder" if flav == "full" else
+                                                     " - predictor-only step") + (" [rank 0 alone]" if solo else ""),
+                            "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"], "frames_per_s": round(r["frames_per_s"], 2),
+                            "ms_per_step": round(r["ms"], 3), "steps": r["steps"], "warmup": r["warmup"],
+                            "whole_step_tflops_per_gpu": round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 2),
+                            "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)}
+            log(f"secondary {name}: " + json.dumps(detail[name]))
+
+        if world == 1:
+            # (key in the JSON, workload, flavour): every BASELINE configuration the primary line does not cover
+            for name, k, flav in [("c2p", "c2p", None), ("c1", "c1", None), ("c0", "c0", None), ("c3s", "c3", None), ("c4s", "c4", None),
+                                  ("c3full", "c3full", None), ("c4full", "c4full", None), ("full64", "c1", "full"), ("full128", "c4", "full")]:
+                note(name, run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False, flavour=flav), flav)
+            # what N GPUs can at best make of these shards: N x shard / whole batch on one GPU (the step is not linear in the clip
+            # count - an 8-clip shard is bound by kernel count)
+            scaling_dp = {"c3_on_4_upper_bound": round(4 * secondary["c3s"][1] / secondary["c3full"][1], 2),
+                          "c4_on_8_upper_bound": round(8 * secondary["c4s"][1] / secondary["c4full"][1], 2),
+                          "note": "N x (8-clip shard on 1 GPU) / (whole global batch on 1 GPU), frames/s: the strong-scaling ratio a free "
+                                  "all-reduce would give; the measured ratio is in the N = 4 / 8 records"}
+        else:
+            # the BASELINE data-parallel configuration for this GPU count on all ranks, then - rank 0 alone, the others waiting at the
+            # barrier below - the same configuration's whole global batch and its 8-clip shard on ONE GPU
+            k = {4: "c3"}.get(world, "c4")
+            rd = run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False)
+            note(k, rd)
+            if rank == 0:
+                rs = run_workload(k, sec_steps, sec_warm, args, 0, 1, dev, probe=False)
+                rf = run_workload(k, sec_steps, sec_warm, args, 0, 1, dev, probe=False, clips=8 * world)
+                note(k + "s@1", rs, solo=True); note(k + "full@1", rf, solo=True)
+                scaling_dp = {"config": f"{k}: {8 * world} clips over {world} GPUs (8 per GPU)",
+                              "dp_frames_per_s": round(rd["frames_per_s"], 1), "whole_batch_on_1_gpu_frames_per_s": round(rf["frames_per_s"], 1),
+                              "shard_on_1_gpu_frames_per_s": round(rs["frames_per_s"], 1),
+                              "strong_ratio": round(rd["frames_per_s"] / rf["frames_per_s"], 3),
+                              "shard_efficiency": round(rd["frames_per_s"] / (world * rs["frames_per_s"]), 3),
+                              "note": "strong_ratio = N GPUs / the whole batch on one GPU; shard_efficiency = N GPUs / (N x one shard on one GPU)"}
+            dist.barrier()
 
     if rank == 0:
         r = main_res
-        wg = "" if ops.WGRAD_PRECISION is None else "; weight-gradient GEMMs two-term (NPVP_WGRAD=bf16x3 opt-in)"
+        wg = "" if ops.WGRAD_PRECISION is None else "; weight gradients two-term bf16 (NPVP_WGRAD=bf16x3 opt-in)"
         res = {"metric": "predictor train frames/sec", "value": round(r["frames_per_s"], 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms"], 3),
-               "higher_is_better": True, "scaling": "weak",
-               "scaling_note": "the primary line is WEAK scaling (64 clips per GPU at every N); the BASELINE multi-GPU configurations "
-                               "(8 clips per GPU) are the c3 / c4 secondaries at N = 4 / 8, with their N = 1 denominators c3s / c4s here",
-               "vs_baseline": None,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"f32": "f32 (fp32-input MFMA)",
-                         "bf16x6": f"f32 (three-term bf16 split on the bf16 MFMA, fp32 accumulate: fp32-grade products{wg})",
-                         "f16x3": "f32 (two-term fp16 split on the f16 MFMA, operands scaled by their amax, fp32 accumulate: fp32-grade "
-                                  "products, 1.8e-7..5e-7 rel-L2 against fp64 on the path's GEMM shapes; GEMMs without weight planes / "
-                                  "under 128 rows: three-term bf16 split)"}[args.gemm],
+                         "bf16x6": f"f32 (three-term bf16 split, 6 MFMAs per product, fp32 accumulate: fp32-grade{wg})",
+                         "f16x3": "f32 (two-term fp16 split of amax-scaled operands, 3 MFMAs per product, fp32 accumulate: fp32-grade; "
+                                  "small GEMMs: three-term bf16 split)"}[args.gemm],
                "data": "synthetic",
                "config": {"workload": f"{r['name']} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
-                                                         else "FULL train step from pixels (frozen AE: MIOpen convolutions with folded BatchNorm + csrc/ae.hip epilogues)")
+                                                         else "FULL train step from pixels (frozen AE)")
                                       + (" [HIP-graph replay]" if args.graph else "") + f", {r['B']} clips/GPU, To={r['To']}, "
                                       f"Tp={r['Tp']}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * r["B"], "frames_per_clip": r["To"] + r["Tp"], "parallelism": f"dp{world}",
                           "algorithmic_tflop_per_step_per_gpu": round(r["flops_step"] / 1e12, 3), "final_loss": round(r["loss"], 6),
-                          "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)},
-               "roofline": r["roof"], "secondary": secondary or None}
+                          "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1),
+                          "f16_range_events": r["range_events"]},
+               "roofline": r["roof"], "roofline_hbm": r["roof_hbm"], "secondary": secondary or None, "scaling_dp": scaling_dp,
+               "dp": r.get("dp")}
         if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")
             res["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

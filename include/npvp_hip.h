@@ -16,6 +16,15 @@
  *   - dropout / drop-path masks are a counter hash of (*seed, salt, element key): `seed` is a
  *     device uint64 (so a captured graph sees a new value per replay), `salt` identifies the call
  *     site; backward entry points replay the forward mask from the same (seed, salt).
+ *
+ * What is deliberately NOT in this ABI (this header is authoritative where it differs from SURVEY 8(b)'s sketch):
+ *   - `npvp_dp_init / npvp_dp_allreduce_async / npvp_dp_wait`: the data-parallel layer stays in torch.distributed
+ *     (backend "nccl" = RCCL over xGMI), npvp_amd/dp.py - bucketed all-reduce of the flat gradient buffer on a side HIP
+ *     stream, SyncBatchNorm on its own communicator.  PyTorch already owns one RCCL communicator set per process; a second
+ *     collective runtime under this library would have to share streams and memory registration with it and would buy
+ *     nothing the Python layer does not already do with three calls (all_reduce(async_op=True), work.wait(), wait_stream).
+ *   - `npvp_<op>_workspace_bytes` exists for the entry points that NEED a workspace (GEMM split-K, LayerNorm / frame-LN /
+ *     fused-middle parameter-gradient partials, colsum, metrics); the others take none.
  */
 #ifndef NPVP_HIP_H
 #define NPVP_HIP_H
@@ -109,6 +118,27 @@ int npvp_split_weights_batched(const void* desc, int count, npvp_stream_t stream
  * deterministic) and the tensor's bound is the maximum of the 32 words.  npvp_amax is the stand-alone producer for a
  * [rows][cols] matrix (row stride ld) that no kernel of this library wrote: slot = max(slot, |x|). */
 int npvp_amax(const float* x, long long rows, long long cols, long long ld, float* slot, npvp_stream_t stream);
+
+/* ---- weight gradients whose split-K reduction rides in the NEXT weight-gradient launch.  dW = dy^T x over 10^3..10^5 token rows
+ * has only a handful of output tiles, so the precision-6 kernel (id 6) splits the reduction over ~512 workgroups and leaves
+ * `splits` partial slabs to sum.  npvp_gemm_f32 sums them with a launch of its own (170 launches per training step of an 8-clip
+ * shard, each an idle tail behind an MFMA-bound kernel).  The chained form defers that sum: it fills `my_job` and returns; the job
+ * is handed as `prev_job` to the next chained launch ON THE SAME STREAM, where extra workgroups of that launch do it (HBM-bound work
+ * beside MFMA-bound work, no launch, same summation order as the stand-alone reduction: bit-identical), or to
+ * npvp_splitk_reduce_job when no launch follows (the end of a backward pass).  The caller keeps `workspace` alive until the job
+ * has been handed on.  dw / db: accumulated into when `accumulate` (GradSink), else overwritten - by the job, not by this launch.
+ * range_flag, adrop_*: as in npvp_gemm_f32. */
+typedef struct npvp_reduce_job {
+  const float* ws; float* out; long long ldc; int M, N, splits, accum; float alpha; int blocks; const float* cs_part; float* cs_out;
+} npvp_reduce_job_t;                                                                 /* 64 bytes, plain data */
+int npvp_wgrad_f16_chainable(int M, int N, int K);                                    /* dW [M][N] over K rows: 1 if the kernel takes it with splits > 1 */
+long long npvp_wgrad_f16_chain_workspace_bytes(int M, int N, int K);
+int npvp_wgrad_f16_chained(int M, int N, int K, const float* dy, long long lda, const float* x, long long ldb, float* dw,
+                           long long ldc, float* db, int accumulate, const float* a_amax, const float* b_amax,
+                           unsigned int* range_flag, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
+                           const unsigned long long* seed, const void* prev_job, void* my_job, void* workspace,
+                           long long ws_bytes, npvp_stream_t stream);
+int npvp_splitk_reduce_job(const void* job, npvp_stream_t stream);
 /* w [N][K] -> the fp16 planes of precision 6: F[2 terms][K/8][N][8 over k], D[2 terms][N/8][K][8 over n] (2*N*K fp16 each,
  * either may be null), scaled by the power of two of w's amax, which is (re)computed into amax_slot (zeroed here first).
  * npvp_split_weights_f16: the same for `count` views in three stream operations; desc is a DEVICE array of records of eight

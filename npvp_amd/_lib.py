@@ -21,6 +21,11 @@ SIGNATURES = {
                               c_p, c_ll, c_f, c_int, c_int, c_int, c_p, c_u, c_f, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p,
                               c_f, c_int, c_int, c_u, c_p, c_ll, c_p]),
     "npvp_amax": (c_int, [c_p, c_ll, c_ll, c_ll, c_p, c_p]),
+    "npvp_wgrad_f16_chainable": (c_int, [c_int, c_int, c_int]),
+    "npvp_wgrad_f16_chain_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
+    "npvp_wgrad_f16_chained": (c_int, [c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p, c_p, c_f, c_int, c_int,
+                                       c_u, c_p, c_p, c_p, c_p, c_ll, c_p]),
+    "npvp_splitk_reduce_job": (c_int, [c_p, c_p]),
     "npvp_split_weight_f16": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p, c_p]),
     "npvp_split_weights_f16": (c_int, [c_p, c_int, c_p, c_ll, c_p]),
     "npvp_frame_stats_finalize": (c_int, [c_p, c_int, c_f, c_p, c_p, c_int, c_f, c_p]),

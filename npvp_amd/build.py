@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        # NPVP_HIPCC_EXTRA: extra flags for one-off measurement builds on the GPU box (e.g. -DNPVP_WIDE_ABL=1); never set
+        # NPVP_HIPCC_EXTRA: extra flags for one-off builds on the GPU box (e.g. -save-temps, -Rpass-analysis=kernel-resource-usage); never set
         # by the product build
         cmd = [hipcc] + FLAGS + os.environ.get("NPVP_HIPCC_EXTRA", "").split() + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

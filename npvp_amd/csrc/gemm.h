@@ -9,6 +9,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// A split-K reduction still to do: out[m][n] (+)= alpha * sum_z ws[z][m][n] (and, with it, cs_out[m] (+)= sum_z cs_part[z][m], the
+// bias gradient's column-sum partials).  Plain data: the host hands it from one weight-gradient launch to the next (gemm_f16.hip).
+struct ReduceJob {
+  const float* ws; float* out; long long ldc; int M, N, splits, accum; float alpha; int blocks; const float* cs_part; float* cs_out;
+};
+
 struct GemmParams {
   const float* A; const float* B; float* C;
   const float* bias;       // [N] or null
@@ -35,7 +41,38 @@ struct GemmParams {
   // c_amax (nullable) receives the bound of the values this launch stores to C (the next GEMM's a_amax)
   const float* a_amax; const float* b_amax; float* c_amax;
   unsigned int* range_flag;   // nullable; fp16 weight-gradient kernel: raised when a column of A lies 2^18 below its bound (see the kernel)
+  ReduceJob prev;             // fp16 weight-gradient kernel: the PREVIOUS launch's split-K reduction, done by prev.blocks extra
+                              // workgroups of this launch (grid.y = splits + extra rows); prev.blocks == 0: none
 };
+
+// the reduction, by `nblocks` blocks of 256 threads of which this is block `bid` (fixed summation order: bit-identical whoever runs it)
+__device__ __forceinline__ void splitk_reduce_body(const ReduceJob& j, int bid, int nblocks, float& cmax) {
+  const long long total4 = (long long)j.M * j.N / 4, cs4 = j.cs_out ? j.M / 4 : 0;
+  for (long long i = (long long)bid * 256 + threadIdx.x; i < total4 + cs4; i += (long long)nblocks * 256) {
+    if (i >= total4) {
+      const long long e = (i - total4) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int zz = 0; zz < j.splits; ++zz) {
+        const float4 v = ld4(j.cs_part + (long long)zz * j.M + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (j.accum) { const float4 o = ld4(j.cs_out + e); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+      st4(j.cs_out + e, s);
+      continue;
+    }
+    const long long e = i * 4;
+    const int m = (int)(e / j.N), n = (int)(e - (long long)m * j.N);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int zz = 0; zz < j.splits; ++zz) {
+      const float4 v = ld4(j.ws + (long long)zz * j.M * j.N + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= j.alpha; s.y *= j.alpha; s.z *= j.alpha; s.w *= j.alpha;
+    if (j.accum) { const float4 o = ld4(j.out + (long long)m * j.ldc + n); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    st4(j.out + (long long)m * j.ldc + n, s);
+    cmax = amax4(cmax, s);
+  }
+}
 
 __device__ __forceinline__ void store_colsum(const GemmParams& p, long long idx, float v) {
   p.colsum[idx] = (p.accum && p.splits == 1) ? p.colsum[idx] + v : v;      // split-K partials are summed (and accumulated) later

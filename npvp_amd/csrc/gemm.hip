@@ -469,31 +469,15 @@ __global__ void split_weights_batched_kernel(const SplitDesc* __restrict__ desc)
 // column-sum partials of the bias gradient (cs_part [splits][M] -> cs_out [M], no alpha), which used to be a launch of its own
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N,
                                      long long ldc, int splits, float alpha, int accum, const float* __restrict__ cs_part,
-                                     float* __restrict__ cs_out) {
-  const long long total4 = (long long)M * N / 4, cs4 = cs_out ? M / 4 : 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4 + cs4; i += (long long)gridDim.x * blockDim.x) {
-    if (i >= total4) {
-      const long long e = (i - total4) * 4;
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int zz = 0; zz < splits; ++zz) {
-        const float4 v = ld4(cs_part + (long long)zz * M + e);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      if (accum) { const float4 o = ld4(cs_out + e); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-      st4(cs_out + e, s);
-      continue;
-    }
-    const long long e = i * 4;
-    const int m = (int)(e / N), n = (int)(e - (long long)m * N);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int zz = 0; zz < splits; ++zz) {
-      const float4 v = ld4(ws + (long long)zz * M * N + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
-    if (accum) { const float4 o = ld4(out + (long long)m * ldc + n); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-    st4(out + (long long)m * ldc + n, s);
-  }
+                                     float* __restrict__ cs_out, float* c_amax) {
+  // c_amax (nullable): the bound of the values stored to `out` - the split launch itself cannot commit it (its tiles are partial
+  // sums), and a consumer that trusted an unraised slot would run at scale 1
+  __shared__ float ared[4];
+  const unsigned int cpeek = amax_peek_block(c_amax);
+  float cmax = 0.f;
+  const ReduceJob j = {ws, out, ldc, M, N, splits, accum, alpha, 0, cs_part, cs_out};
+  splitk_reduce_body(j, blockIdx.x, gridDim.x, cmax);
+  amax_slot_commit_block(c_amax, cmax, ared, cpeek);
 }
 
 static int pick_splits(int M, int N, int K) {
@@ -610,6 +594,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   p.colsum = colsum_a;
   p.rowstats = rowstats;
   p.a_amax = a_amax; p.b_amax = b_amax; p.c_amax = c_amax; p.range_flag = range_flag;
+  p.prev = ReduceJob{};
   NPVP_CHECK_ARG(!rowstats || (precision == 4 && a_kc && b_kc && M % 64 == 0 && N % 128 == 0 && act == 0 && !aux_out && !residual &&
                                drop_p == 0.f && !accumulate),
                  "gemm: rowstats needs the default (bf16x6) forward layout, M % 64 == 0, N % 128 == 0 and a bias-only epilogue");
@@ -647,7 +632,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
           int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
           const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;       // (a float4-aligned bias gradient rides along)
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
-                             sh, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr);
+                             sh, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr, c_amax);
           NPVP_CHECK_LAUNCH();
           if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, sh, M, M, stream, p.accum)) {
             npvp_set_error("gemm: column-sum reduce launch failed");
@@ -707,7 +692,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
-                       splits, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr);
+                       splits, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr, c_amax);
     NPVP_CHECK_LAUNCH();
     if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream, p.accum)) {
       npvp_set_error("gemm: column-sum reduce launch failed");

@@ -21,12 +21,6 @@
 #include "gemm.h"
 #include <cstdlib>
 
-// measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_H_ABL=n on the GPU box; results INVALID): 1 = no C stores, 2 = no A global
-// loads inside the K loop, 4 = no B LDS-DMA inside the K loop, 8 = no A split / ds_write inside the K loop
-#ifndef NPVP_H_ABL
-#define NPVP_H_ABL 0
-#endif
-
 namespace npvp {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   {                                                                                                        \
     const char* st_ = lds + (CUR) * STAGE;                                                                 \
     char* nx_ = lds + (NXT) * STAGE;                                                                       \
-    if (!(NPVP_H_ABL & 4)) NPVP_H_BLOAD(nx_, (KT) + 1)                                                     \
+    NPVP_H_BLOAD(nx_, (KT) + 1)                                                                            \
     f16x8 fb_[2][TN];                                                                                      \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                    \
@@ -193,16 +187,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
       f16x8 fa_[2];                                                                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
         fa_[s_] = *reinterpret_cast<const f16x8*>(st_ + fa_off + s_ * A_PLANE + i_ * 512);                 \
-      if (i_ == 0 && !(NPVP_H_ABL & 8)) { NPVP_H_ASTORE(nx_, R0, 0) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) } \
-      if (i_ == 1 && !(NPVP_H_ABL & 2)) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                 \
+      if (i_ == 0) { NPVP_H_ASTORE(nx_, R0, 0) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) }                      \
+      if (i_ == 1) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                                      \
       /* smallest terms first */                                                                           \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], (FIRST) ? zero16 : acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);       /* every MFMA of the step is issued before the wave parks at the wait */ \
-    if (NPVP_H_ABL & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");  \
-    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");                 \
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");                      \
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
@@ -282,15 +275,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
         for (int j = 0; j < TN; ++j) acc[i][j][g] *= f;
       }
   }
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (NPVP_H_ABL & 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
-    return;
-  }
-#endif
   if constexpr (ROWSTATS) {
     static_assert(!ROWSTATS || (TN % 2 == 0 && TM % 2 == 0), "frame statistics ride on 64 x 64 accumulator blocks");
 #pragma unroll
@@ -332,6 +316,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   constexpr int STAGE = A_BYTES + B_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
+  if ((int)blockIdx.y >= p.splits) {
+    // the extra grid rows: the PREVIOUS weight-gradient launch's split-K reduction (ReduceJob, gemm.h).  That launch is complete
+    // (same stream), its partial slabs are at rest; these workgroups are HBM-bound and run beside this launch's MFMA-bound ones -
+    // no launch of its own, no idle tail.  Same summation order as splitk_reduce_kernel: bit-identical.
+    float cm = 0.f;
+    splitk_reduce_body(p.prev, ((int)blockIdx.y - p.splits) * (int)gridDim.x + (int)blockIdx.x, p.prev.blocks, cm);
+    return;
+  }
   int z, tl;
   {
     const int tiles = gridDim.x;
@@ -511,7 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 int f16_wgrad_splits(int M, int N, int K) {
   if ((K & 15) || M < 64 || N < 128 || K < 4096) return 0;
   const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
-  static const int want = getenv("NPVP_WGRAD_WGS") ? atoi(getenv("NPVP_WGRAD_WGS")) : 512;     // A/B switch (workgroups per launch)
+  const int want = 512;                 // workgroups per launch (256 / 384 / 1024 measured within noise of it: DESIGN.md section 5)
   int s = (want + tiles - 1) / tiles;
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
@@ -521,10 +513,22 @@ int f16_wgrad_splits(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
+// blocks that reduce a [M][N] split-K result inside the next launch: a multiple of that launch's tile count (whole grid rows)
+static int reduce_rows_for(const ReduceJob& j, int tiles) {
+  if (!j.ws) return 0;
+  const long long total4 = (long long)j.M * j.N / 4;
+  long long want = (total4 + 255) / 256;
+  if (want > 256) want = 256;
+  if (want < 1) want = 1;
+  return (int)((want + tiles - 1) / tiles);
+}
+
 bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + 255) / 256;
-  dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+  const int tiles = p.tiles_m * p.tiles_n, rr = reduce_rows_for(p.prev, tiles);
+  p.prev.blocks = rr * tiles;
+  dim3 grid(tiles, splits + rr), block(256);
   hipLaunchKernelGGL((gemm_wgrad_f16_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
   return true;
 }
@@ -547,9 +551,6 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
-  static const int force_g = getenv("NPVP_COLGROUPS") ? atoi(getenv("NPVP_COLGROUPS")) : 0;        // A/B switch
-  if (force_g > 0 && (force_g == 1 || (p.tiles_n % force_g == 0 && p.tiles_m % (8 / force_g) == 0 && (p.tiles_m * p.tiles_n) % 8 == 0)))
-    p.colgroups = force_g;
   dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (v == 1) {
     if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
@@ -658,6 +659,64 @@ extern "C" int npvp_split_weight_f16(const float* w, long long ld, int N, int K,
   hipLaunchKernelGGL(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
   NPVP_CHECK_LAUNCH();
   hipLaunchKernelGGL(split_weights_f16_kernel, dim3(128, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// ---- weight gradients whose split-K reduction rides in the NEXT weight-gradient launch (see include/npvp_hip.h) -------------------
+static_assert(sizeof(ReduceJob) == 64, "npvp_reduce_job_t (include/npvp_hip.h) mirrors this layout");
+
+extern "C" int npvp_wgrad_f16_chainable(int M, int N, int K) {
+  return (M % 4 == 0 && N % 4 == 0 && f16_wgrad_splits(M, N, K) > 1) ? 1 : 0;
+}
+
+extern "C" long long npvp_wgrad_f16_chain_workspace_bytes(int M, int N, int K) {
+  const int s = f16_wgrad_splits(M, N, K);
+  return s > 1 ? ((long long)s * M * N + (long long)s * M) * 4 : 0;
+}
+
+extern "C" int npvp_wgrad_f16_chained(int M, int N, int K, const float* dy, long long lda, const float* x, long long ldb, float* dw,
+                                      long long ldc, float* db, int accumulate, const float* a_amax, const float* b_amax,
+                                      unsigned int* range_flag, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
+                                      const unsigned long long* seed, const void* prev_job, void* my_job, void* workspace,
+                                      long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(npvp_wgrad_f16_chainable(M, N, K), "wgrad_f16_chained: shape not taken (npvp_wgrad_f16_chainable tells)");
+  NPVP_CHECK_ARG(dy && x && dw && a_amax && b_amax && my_job, "wgrad_f16_chained: null operand / amax slot / job");
+  NPVP_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dw % 16) == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0,
+                 "wgrad_f16_chained: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  NPVP_CHECK_ARG(!db || ((uintptr_t)db % 16) == 0, "wgrad_f16_chained: the bias gradient must be 16-byte aligned");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_wgrad_f16_chain_workspace_bytes(M, N, K), "wgrad_f16_chained: workspace too small");
+  NPVP_CHECK_ARG(adrop_p >= 0.f && adrop_p < 0.5f && (adrop_p == 0.f || (seed && adrop_g1 > 0 && adrop_g2 > 0 && adrop_g1 % 16 == 0)),
+                 "wgrad_f16_chained: adrop needs a device seed and groups of a multiple of 16 rows");
+  const int sh = f16_wgrad_splits(M, N, K);
+  GemmParams p = {};
+  p.A = dy; p.B = x; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K / sh; p.alpha = 1.f;
+  p.C = (float*)workspace; p.ldc = N; p.splits = sh; p.colgroups = 1; p.accum = accumulate ? 1 : 0;
+  p.colsum = db ? (float*)workspace + (long long)sh * M * N : nullptr;
+  p.seed = seed;
+  p.drop = make_drop_spec(0.f, 0u, 0, 1, 1);
+  p.adrop = make_drop_spec(adrop_p, adrop_salt, 1, adrop_g1, adrop_g2);
+  p.a_amax = a_amax; p.b_amax = b_amax; p.range_flag = range_flag;
+  if (prev_job) p.prev = *reinterpret_cast<const ReduceJob*>(prev_job);
+  launch_gemm_wgrad_f16(p, sh, stream);
+  NPVP_CHECK_LAUNCH();
+  ReduceJob mine = {(const float*)workspace, dw, ldc, M, N, sh, accumulate ? 1 : 0, 1.f, 0, db ? p.colsum : nullptr, db};
+  *reinterpret_cast<ReduceJob*>(my_job) = mine;
+  return NPVP_OK;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_job_kernel(ReduceJob j) {
+  float cm = 0.f;
+  splitk_reduce_body(j, blockIdx.x, gridDim.x, cm);
+}
+
+extern "C" int npvp_splitk_reduce_job(const void* job, hipStream_t stream) {
+  NPVP_CHECK_ARG(job, "splitk_reduce_job: null job");
+  const ReduceJob j = *reinterpret_cast<const ReduceJob*>(job);
+  NPVP_CHECK_ARG(j.ws && j.out && j.M > 0 && j.N > 0 && j.splits > 0, "splitk_reduce_job: empty job");
+  const long long total4 = (long long)j.M * j.N / 4;
+  int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_job_kernel, dim3(blocks), dim3(256), 0, stream, j);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

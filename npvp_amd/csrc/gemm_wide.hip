@@ -26,12 +26,6 @@
 #include "gemm.h"
 #include <cstdlib>
 
-// measurement builds only (NPVP_HIPCC_EXTRA=-DNPVP_WIDE_ABL=n on the GPU box; results INVALID): 1 = epilogue without its
-// global stores, 2 = no K loop
-#ifndef NPVP_WIDE_ABL
-#define NPVP_WIDE_ABL 0
-#endif
-
 namespace npvp {
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
-  int kt = (NPVP_WIDE_ABL & 2) ? nk : 0;
+  int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
     NPVP_W_STEP(kt, 0, 1)
     NPVP_W_STEP(kt + 1, 1, 0)
@@ -162,15 +156,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
 #undef NPVP_W_ALOAD
 
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (NPVP_WIDE_ABL & 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
-    return;
-  }
-#endif
   float cmax = 0.f;
   float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;      // per-wave transposition scratch (gemm.h)
   if constexpr (ROWSTATS) {

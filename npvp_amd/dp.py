@@ -27,12 +27,23 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+# NPVP_DP_FORCE=1: take the data-parallel code path with ONE rank too - process group, model broadcast, SyncBatchNorm2d, GradSync
+# with its side stream and asynchronous all-reduces.  With backend "nccl" this executes ProcessGroupNCCL / RCCL itself (init, stream
+# semantics of async_op collectives, work.wait() ordering) on a box that has a single GPU (tests/test_dp_gpu.py::test_rccl_one_rank).
+FORCE = os.environ.get("NPVP_DP_FORCE", "0") == "1"
+
+
+def active(group=None):
+    """the data-parallel machinery is on: more than one rank, or one rank with NPVP_DP_FORCE=1"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE)
+
+
 def init_distributed(backend=None):
     """Initialise from the torchrun / torch.distributed.run environment.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("NPVP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -52,7 +63,7 @@ def shard_batch(x, rank, world):
 
 def broadcast_module(module, src=0):
     """parameters and buffers start identical on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -63,31 +74,49 @@ def broadcast_module(module, src=0):
 class GradSync:
     """Bucketed, overlapped all-reduce(mean) of a FlatBuffers gradient buffer."""
 
-    def __init__(self, buf, bucket_bytes=64 << 20, group=None):
+    def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20):
         self.buf, self.group = buf, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on = active(group)                 # (one rank with NPVP_DP_FORCE=1 runs the whole machinery on a group of one)
         from . import ops
-        if self.world > 1 and ops.AuxStream.enabled:
+        if self.on and ops.AuxStream.enabled:
             # a bucket's all-reduce is ordered after the compute stream and the gradient stream only: contributions
             # produced on the auxiliary encoder stream (NPVP_DUAL_ENCODER=1) could land after it
             raise RuntimeError("GradSync: NPVP_DUAL_ENCODER=1 (two-stream encoder passes) is not supported under data parallelism")
         self.cuda = buf.flat_g.is_cuda
         self.side = torch.cuda.Stream() if self.cuda else None
-        # contiguous buckets over the flat buffer, each owning whole parameters
-        cap = max(1, bucket_bytes // 4)
+        # Contiguous buckets over the flat buffer, each owning whole parameters, cut in AUTOGRAD order: the buffer is laid out in
+        # module order (coordinate MLP, encoder, event encoders, decoder last), backward fills it from the END, so the buckets are
+        # cut walking from the end - full `bucket_bytes` ones first - and what is left at the FRONT (the coordinate MLP and the first
+        # encoder layers, whose gradients complete last: every layer's positional tables feed them) is the bucket that is reduced
+        # last.  That one is the only all-reduce nothing can hide behind, so it is kept small (`last_bucket_bytes`).
+        cap, cap_last = max(1, bucket_bytes // 4), max(1, last_bucket_bytes // 4)
+        ends = [buf.offsets[i + 1][0] if i + 1 < len(buf.offsets) else buf.total for i in range(len(buf.offsets))]
+        cuts, hi = [], buf.total                     # bucket boundaries (element offsets), found from the end
+        for i in range(len(buf.params) - 1, -1, -1):
+            lo = buf.offsets[i][0]
+            if hi - lo >= cap and lo > 0:
+                cuts.append(lo); hi = lo
+        if hi > cap_last:                            # the front remainder: split off its head
+            for i in range(len(buf.params)):
+                if ends[i] >= cap_last and ends[i] < hi:
+                    cuts.append(ends[i]); break
+        cuts = sorted(set(cuts))
         self.buckets, self.param_bucket = [], {}
-        start, count, members = 0, 0, 0
-        for i, (p, (off, n)) in enumerate(zip(buf.params, buf.offsets)):
-            end = buf.offsets[i + 1][0] if i + 1 < len(buf.offsets) else buf.total
-            self.param_bucket[id(p)] = len(self.buckets)
-            members += 1
-            if end - start >= cap or i + 1 == len(buf.offsets):
-                self.buckets.append({"lo": start, "hi": end, "n": members, "ready": 0, "work": None})
-                start, members = end, 0
+        bounds = [0] + cuts + [buf.total]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            self.buckets.append({"lo": lo, "hi": hi, "n": 0, "ready": 0, "work": None})
+        bi = 0
+        for p, (off, n) in zip(buf.params, buf.offsets):
+            while off >= self.buckets[bi]["hi"]:
+                bi += 1
+            self.param_bucket[id(p)] = bi
+            self.buckets[bi]["n"] += 1
+        self._exposed = []                           # (event before, event after) the compute stream's wait for the side stream
         self._handles = []
         self.count = {id(p): 0 for p in buf.params}     # contributions seen this step
         self.expected = None                            # learned in the first step
-        if self.world > 1:
+        if self.on:
             for p in buf.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
             from . import ops
@@ -128,7 +157,7 @@ class GradSync:
     def finish(self):
         """Call after backward(): reduce any bucket whose hooks did not all fire (unused parameters), then
         order the compute stream after every reduction."""
-        if self.world == 1:
+        if not self.on:
             return
         if self.expected is None:
             self.expected = dict(self.count)
@@ -170,7 +199,19 @@ class GradSync:
                 b["work"].wait()
             b["work"], b["ready"] = None, 0
         if self.cuda:
+            # what the compute stream waits here is the EXPOSED part of the step's all-reduces (the tail of the last bucket)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             torch.cuda.current_stream().wait_stream(self.side)
+            e1.record()
+            self._exposed.append((e0, e1))
+            del self._exposed[:-64]
+
+    def exposed_ms(self):
+        """average time the compute stream spent waiting for the all-reduce stream in finish() over the recorded steps (call after
+        a device synchronisation; the first step reduces everything in finish() and is left out)"""
+        pairs = self._exposed[1:] if len(self._exposed) > 1 else self._exposed
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs) if pairs else 0.0
 
     def relearn(self):
         """Call before a step whose autograd graph differs from the previous one (e.g. a random-context batch with a
@@ -199,7 +240,7 @@ def syncbn_group():
     latency-critical [sum, sum_sq, n] all-reduces of the forward pass would queue behind 64 MB bucket reductions that are
     still in flight from the previous step's tail / this step's backward."""
     global _SYNCBN_GROUP
-    if _SYNCBN_GROUP is None and dist.is_initialized() and dist.get_world_size() > 1:
+    if _SYNCBN_GROUP is None and active():
         _SYNCBN_GROUP = dist.new_group(ranks=list(range(dist.get_world_size())))
     return _SYNCBN_GROUP
 
@@ -250,7 +291,7 @@ class SyncBatchNorm2d(nn.BatchNorm2d):
     Same parameters / buffers / state-dict keys as nn.BatchNorm2d; works on gloo (CPU) and nccl (RCCL)."""
 
     def forward(self, x):
-        if not (dist.is_initialized() and dist.get_world_size() > 1 and self.training):
+        if not (active() and self.training):
             return super().forward(x)
         if self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)

@@ -21,11 +21,16 @@ def _ptr(t):
 class AmaxSlot:
     """One amax slot (2 KB of device memory: 32 words, 64 bytes apart, see include/npvp_hip.h): the bound of |x| over a tensor
     that feeds a precision-6 GEMM.  Slots are cut from zero-filled chunks (one torch.zeros per 1024 slots); a slot keeps its
-    chunk alive, so a saved-for-backward slot is valid until the node that holds it is freed."""
+    chunk alive, so a saved-for-backward slot is valid until the node that holds it is freed.
+
+    One current chunk per (device, STREAM): the chunk's zero fill is enqueued on the stream that cuts the slots, so it is ordered
+    before every producer's atomic max and every consumer's read on that stream (autograd replays a node on the stream of its
+    forward; streams that consume a tensor produced elsewhere are ordered behind its producer by the caller's wait_stream, which
+    covers the slot too).  A chunk is also protected from allocator reuse on every side stream this module runs (gradient stream,
+    auxiliary stream) and on the device's default stream - its slots may be read there after the cutting stream has moved on."""
     __slots__ = ("ptr", "chunk")
     CHUNK, BYTES, FLOATS = 1024, 2048, 512
-    _cur = None
-    _next = 0
+    _cur = {}                 # (device index, raw stream) -> [chunk, next slot]
 
     def __init__(self, ptr, chunk):
         self.ptr, self.chunk = ptr, chunk
@@ -39,15 +44,28 @@ class AmaxSlot:
         return float(self.chunk.view(-1, self.FLOATS)[i].max())
 
     @classmethod
+    def reset_chunks(cls):
+        """forget the current chunks (a HIP-graph capture cuts its slots from chunks created INSIDE the capture)"""
+        cls._cur = {}
+
+    @classmethod
     def new(cls, dev):
-        ch = cls._cur
-        if ch is None or cls._next >= cls.CHUNK or ch.device != dev:
-            ch = cls._cur = torch.zeros(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev)
-            cls._next = 0
+        key = (dev.index, _stream())             # (one C call; the tensors of this module live on the current device)
+        st = cls._cur.get(key)
+        if st is None or st[1] >= cls.CHUNK:
+            cur = torch.cuda.current_stream(dev)
+            ch = torch.zeros(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev)
+            others = [torch.cuda.default_stream(dev)]
             if WgradStream.enabled:
-                ch.record_stream(WgradStream.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
-        s = cls(ch.data_ptr() + cls.BYTES * cls._next, ch)
-        cls._next += 1
+                others.append(WgradStream.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
+            if AuxStream.enabled or DecoderSplit.enabled:
+                others.append(AuxStream.stream(dev))
+            for o in others:
+                if o.cuda_stream != cur.cuda_stream:
+                    ch.record_stream(o)
+            st = cls._cur[key] = [ch, 0]
+        s = cls(st[0].data_ptr() + cls.BYTES * st[1], st[0])
+        st[1] += 1
         return s
 
 
@@ -409,6 +427,40 @@ class GemmProbe:
         return out
 
 
+class HbmProbe:
+    """bench.py's live probe of the HBM-bound family: when armed, the three kernels that lead the non-GEMM time of a step (the
+    fused MlpDWBN middle backward, the token LayerNorm backward, the frame-LayerNorm backward apply pass) are bracketed by HIP
+    event pairs on the stream they run on, with their ALGORITHMIC bytes (every operand read once, every result
+    written once, fp32).  Armed for a few extra steps AFTER the timed region, so the event packets do not perturb `value`."""
+    armed = False
+    records = []          # (start_event, end_event, kernel name, algorithmic bytes)
+
+    @classmethod
+    def begin(cls):
+        if not cls.armed:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    @classmethod
+    def end(cls, e0, name, nbytes):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        cls.records.append((e0, e1, name, float(nbytes)))
+
+    @classmethod
+    def summary(cls):
+        """{kernel: (launches, total_ms, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
+        out = {}
+        for e0, e1, name, by in cls.records:
+            n, ms, b = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + by)
+        return out
+
+
 class GradSink:
     """Parameter gradients go STRAIGHT into the flat gradient buffer.  When a weight / bias / LayerNorm parameter is a
     FlatBuffers parameter (or a contiguous view into one, e.g. the q|k rows of an in_proj_weight or a 1x1 conv weight
@@ -521,6 +573,7 @@ class WgradStream:
             cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return cls._side[key]
 
+    in_flush = False         # inside flush(): the current stream is the gradient stream (WgradChain defers reductions there)
     _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
     BATCH = max(1, int(os.environ.get("NPVP_WGRAD_BATCH", "3")))
 
@@ -549,8 +602,16 @@ class WgradStream:
         dev, side = cls._pending
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for fn, _, _ in q:
-                fn()
+            cls.in_flush = True
+            try:
+                for fn, _, _ in q:
+                    fn()
+                if GradSink.listener is not None:
+                    # data parallel: the slots reported below must be COMPLETE on this stream when a bucket's all-reduce is
+                    # ordered behind it - a split-K reduction still waiting for its next launch is not
+                    WgradChain.flush()
+            finally:
+                cls.in_flush = False
         for _, keep, slots in q:
             for t in keep:
                 t.record_stream(side)
@@ -570,12 +631,13 @@ class WgradStream:
         if cls._pending is not None:
             cls.flush()
             dev, side = cls._pending
+            with torch.cuda.stream(side):
+                WgradChain.flush()               # the last weight gradient's split-K reduction has no launch to ride in
             torch.cuda.current_stream(dev).wait_stream(side)
             cls._pending = None
 
 
 # --------------------------------------------------------------------------- raw kernel wrappers
-GEMM_EXCLUSIVE = os.environ.get("NPVP_GEMM_EXCL", "0") == "1"
 
 
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
@@ -613,10 +675,6 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
     # the population (and the average duration) is then the same as in a rocprofv3 kernel trace of the same command
-    if GEMM_EXCLUSIVE and planes is not None and WgradStream._pending is not None:
-        WgradStream.flush()
-        # measurement switch: a critical-path GEMM starts only when the gradient stream has drained
-        torch.cuda.current_stream(A.device).wait_stream(WgradStream._pending[1])
     probe = GemmProbe.armed
     if probe:
         kid = _gemm_kernel_id(a_kc, b_kc, M, N, K, prec, planes is not None)
@@ -710,6 +768,57 @@ def masked_grad(dy2, drop, w):
 DROP_PATH_IN_GEMM_ROWS = int(os.environ.get("NPVP_DROP_PATH_IN_GEMM_ROWS", "32768"))
 
 
+class WgradChain:
+    """Split-K reductions of the fp16 weight gradients, handed from launch to launch (include/npvp_hip.h, npvp_wgrad_f16_chained):
+    a weight gradient accumulated in place on the gradient stream leaves its `splits` partial slabs in a workspace and a 64-byte
+    job; the NEXT weight-gradient launch on that stream does the sum with extra workgroups (no launch of its own: 110 of the 170
+    reduction launches of an 8-clip step; HBM-bound work beside MFMA-bound work), WgradStream.join() runs the last one.  Same
+    summation order as the stand-alone reduction, so results are bit-identical.  NPVP_WGRAD_CHAIN=0: one reduction launch each."""
+    enabled = os.environ.get("NPVP_WGRAD_CHAIN", "1") == "1"
+    _pending = {}          # raw stream -> (job bytes, workspace, dw, db): kept alive until the job has been handed on
+    _ok, _wsb = {}, {}
+
+    @classmethod
+    def takes(cls, M, N, K):
+        key = (M, N, K)
+        v = cls._ok.get(key)
+        if v is None:
+            v = cls._ok[key] = bool(lib().npvp_wgrad_f16_chainable(M, N, K))
+            cls._wsb[key] = lib().npvp_wgrad_f16_chain_workspace_bytes(M, N, K)
+        return v
+
+    @classmethod
+    def launch(cls, dy, x, dw, db, dy_amax, x_amax, a_drop, flag):
+        """dw (+)= dy^T x, db (+)= colsum(dy), both ACCUMULATED (GradSink slices), reduction deferred"""
+        R, N = dy.shape
+        K = x.shape[1]
+        st = _stream()
+        ws, wsn = _ws(cls._wsb[(N, K, R)], dy.device)
+        job = ctypes.create_string_buffer(64)
+        prev = cls._pending.pop(st, None)
+        seed = rng.seed_tensor(dy.device) if a_drop.on else None
+        probe = GemmProbe.armed and (GemmProbe.only is None or 6 in GemmProbe.only)
+        if probe:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib().npvp_wgrad_f16_chained(N, K, R, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), _ptr(db), 1,
+                                           _ptr(dy_amax), _ptr(x_amax), _ptr(flag), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt,
+                                           _ptr(seed), ctypes.addressof(prev[0]) if prev is not None else None, ctypes.addressof(job),
+                                           _ptr(ws), wsn, st), "npvp_wgrad_f16_chained")
+        if probe:
+            e1.record()
+            GemmProbe.records.append((e0, e1, 2.0 * N * K * R, 4.0 * (N * R + K * R + N * K), ((0, 0), 6)))
+        cls._pending[st] = (job, ws, dw, db)
+
+    @classmethod
+    def flush(cls):
+        """the pending job of the CURRENT stream, as a launch of its own"""
+        st = _stream()
+        prev = cls._pending.pop(st, None)
+        if prev is not None:
+            check(lib().npvp_splitk_reduce_job(ctypes.addressof(prev[0]), st), "npvp_splitk_reduce_job")
+
+
 class RangeGuard:
     """The per-ROW range of the two-term fp16 arithmetic (include/npvp_hip.h, `range_flag`).  Forward / dgrad GEMMs repair a tile
     whose rows lie 2^18 or more below the operand's bound themselves (a second pass with per-row scales, inside the kernel).  The
@@ -789,8 +898,13 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
         else:
             dw, db = tw, tb
         return (dw, db) if with_bias_grad else dw
+    flag = RangeGuard.flag(dy.device) if watch else None
+    if (watch and acc and prec is None and WgradChain.enabled and WgradStream.in_flush and WgradChain.takes(N, K, R)
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1):
+        WgradChain.launch(dy, x, dw, db, amax_of(dy, dy_amax), amax_of(x, x_amax), a_drop, flag)
+        return (dw, db) if with_bias_grad else dw
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc, precision=prec, a_amax=dy_amax, b_amax=x_amax,
-         a_drop=a_drop, range_flag=RangeGuard.flag(dy.device) if watch else None)
+         a_drop=a_drop, range_flag=flag)
     return (dw, db) if with_bias_grad else dw
 
 
@@ -1564,9 +1678,11 @@ class _MlpDwbn(torch.autograd.Function):
                                          frames, PF, d.p, d.salt, dp.p, dp.salt, T, _ptr(seed), mode, _ptr(slot), _ptr(ws), wsn,
                                          _stream()), "npvp_frameln_act_bwd")
         else:
+            pe = HbmProbe.begin()
             check(L.npvp_frameln_act_bwd_apply(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(psum), nparts,
                                                _ptr(dh), _ptr(dw), _ptr(db), frames, PF, mode, _ptr(slot), _ptr(ws), wsn, _stream()),
                   "npvp_frameln_act_bwd_apply")
+            HbmProbe.end(pe, "npvp::frameln_act_bwd_fused_kernel", 4.0 * 3 * frames * PF)            # reads dout, h; writes dh
         if sk:
             if WgradStream.enabled:
                 WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
@@ -1647,10 +1763,12 @@ class _MlpDwbn(torch.autograd.Function):
         wmode = 2 if sk_dw else 0          # 2: the depthwise gradient partials stay in `ws` for the gradient stream (below)
         if fuse_n2:
             seed = rng.seed_tensor(dev) if d2.on else None
+            pe = HbmProbe.begin()
             check(L.npvp_mlpdw_mid_bwd_n2(_ptr(da2), _ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _ptr(psum2),
                                           hid // 16, d2.p, d2.salt, _ptr(seed), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w),
                                           _ptr(n1b), _ptr(wtb), _ptr(da1), _ptr(dwtb), _ptr(psum), frames, 8, 8, hid, wmode, _ptr(ws), wsn,
                                           _stream()), "npvp_mlpdw_mid_bwd_n2")
+            HbmProbe.end(pe, "npvp::mlpdw_mid_bwd_kernel<1, true>", 4.0 * 4 * frames * 64 * hid)     # reads da2, h2, h1; writes da1
             del da2, psum2
         else:
             check(L.npvp_mlpdw_mid_bwd(_ptr(dh2), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w), _ptr(n1b), _ptr(wtb), _ptr(da1),
@@ -1716,8 +1834,10 @@ def _raw_ln_bwd(dy2, x2, w, b, st, dres, sk):
     dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
     ws, wsn = _ws(L.npvp_layernorm_bwd_workspace_bytes(rows, C), x2.device)
     slot = _new_slot(x2.device)
+    pe = HbmProbe.begin()
     check(L.npvp_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(b), _row(st, 0), _row(st, 1), _ptr(dx), _ptr(dw), _ptr(db), rows, C,
                                0, _ptr(dres), _sink_mode(sk), _ptr(slot), _ptr(ws), wsn, _stream()), "npvp_layernorm_bwd")
+    HbmProbe.end(pe, "npvp::ln_bwd_kernel<2>", 4.0 * (3 + (dres is not None)) * rows * C)            # reads dy, x (+ dres); writes dx
     tag_amax(dx, slot)
     if sk:
         _sunk_ln_reduce(sk, ws, rows, C)

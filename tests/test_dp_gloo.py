@@ -98,3 +98,32 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert got["launched"] >= 6            # every bucket, both steps
     # the tied norm sits in the clip (transformer) range, the unused parameter's gradient stays zero
     assert float(m.unused.grad.abs().max()) == 0.0
+
+
+def test_buckets_are_cut_in_autograd_order_with_a_small_last_one():
+    """The flat buffer is laid out in module order and filled from the END in backward: buckets are cut walking from the end, and
+    the bucket at the FRONT - reduced last, the only all-reduce with nothing left to hide behind - is kept small."""
+    sys.path.insert(0, ROOT)
+    from npvp_amd import dp
+    from npvp_amd.trainer import FlatBuffers
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.first = nn.Linear(8, 8)                                            # completes last in backward
+            self.enc = nn.Sequential(*[nn.Linear(64, 64) for _ in range(6)])
+            self.transformer = nn.Sequential(*[nn.Linear(64, 64) for _ in range(10)])
+    m = Stack()
+    buf = FlatBuffers(m, m.transformer)
+    cap, cap_last = 4 * 3 * 4160, 4 * 4160                                          # three layers per bucket; one layer in the last one
+    gs = dp.GradSync(buf, bucket_bytes=cap, last_bucket_bytes=cap_last)
+    b = gs.buckets
+    assert b[0]["lo"] == 0 and b[-1]["hi"] == buf.total and all(x["hi"] == y["lo"] for x, y in zip(b[:-1], b[1:]))
+    sizes = [x["hi"] - x["lo"] for x in b]
+    assert all(sz >= cap // 4 for sz in sizes[2:]), sizes                           # full buckets from the end
+    assert sizes[0] <= cap_last // 4 + 4160, sizes                                  # the front (last-reduced) bucket is small
+    assert sum(x["n"] for x in b) == len(buf.params)
+    for p, (off, n) in zip(buf.params, buf.offsets):
+        bk = b[gs.param_bucket[id(p)]]
+        assert bk["lo"] <= off and off + n <= bk["hi"]
+    assert gs.param_bucket[id(m.first.weight)] == 0 and gs.param_bucket[id(m.transformer[9].weight)] == len(b) - 1

@@ -44,3 +44,22 @@ def test_bench_two_ranks(request):
     assert r["config"]["global_batch"] == 16 and "c4" not in r["config"]["parallelism"] and r["config"]["parallelism"] == "dp2"
     assert r["roofline"] is not None and r["roofline"]["achieved"] > 0
     assert abs(r["value"] - 2 * 8 * 20 / (r["ms_per_step"] * 1e-3)) < 1e-2 * r["value"]
+
+
+def test_rccl_one_rank(request):
+    """RCCL as far as one GPU allows: bench.py on ONE rank with backend nccl and NPVP_DP_FORCE=1 - ProcessGroupNCCL
+    initialised, the model broadcast, SyncBatchNorm2d converted and reducing on its own communicator, GradSync's buckets reduced by
+    all_reduce(async_op=True) on the side stream while backward runs, work.wait() + finish() before the clip - all on real RCCL.
+    A group of one leaves every value unchanged, so the step must equal the plain one-process step's loss scale and finish."""
+    rc, read = _jobs(request)
+    log = read("rccl1")
+    lines = [l for l in log.splitlines() if l.startswith("{")]
+    assert lines, f"bench.py on one RCCL rank printed no JSON line (rc={rc}):\n{log[-3000:]}"
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["config"]["final_loss"] == r["config"]["final_loss"]
+    d = r["dp"]
+    assert d["backend"] == "nccl" and d["buckets"] >= 6 and d["last_bucket_mb"] <= 16.0
+    # step 1 learns the contribution counts and reduces everything in finish(); from step 2 on every bucket is launched from a hook
+    # (2 warm-up + 3 timed steps + the 2 extra steps of the HBM probe)
+    assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
+    assert d["exposed_allreduce_ms_per_step"] >= 0.0

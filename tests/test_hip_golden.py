@@ -148,6 +148,123 @@ def test_validation_step(impl, variant, layout):
                tag=f"val_step_{variant}[{MODE},{layout}]")
 
 
+def test_bf16x6_mode_stays_in_the_default_session(impl):
+    """the six-term bf16 arithmetic is a selectable mode (bench.py --gemm bf16x6, NPVP_GEMM) and what every shape the
+    fp16 kernels do not take falls back to; its wide kernels (bf16 weight planes, gemm_wide_kernel) must not go untested when
+    NPVP_TEST_ALL_MODES is unset: one whole-predictor case and one training step per default session."""
+    import npvp_amd
+    if MODE != DEFAULT_MODE:
+        pytest.skip("runs once, beside the default mode")
+    npvp_amd.ops.set_gemm_precision("bf16x6")
+    try:
+        GC.compare(GC.case_predictor(impl, DEV, "D"), GC.load("predictor_D"), 1e-4, tag="predictor_D[bf16x6]")
+        mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        res, g = GC.case_train_step(impl, DEV, "S", make_opt=mk), GC.load("train_step_S")
+        GC.compare({k: v for k, v in res.items() if k.endswith("_0")}, {k: v for k, v in g.items() if k.endswith("_0")}, 1e-4,
+                   tag="train_step_S[bf16x6]")
+    finally:
+        npvp_amd.ops.set_gemm_precision(MODE)
+
+
+def test_backward_that_raises_leaves_no_stale_gradient_work(impl):
+    """WgradStream queues closures; a backward pass that raises never runs the engine callback that joins the gradient
+    stream.  FlatAdamW.zero_grad / step join first: the next step's gradients equal those of a fresh run."""
+    from npvp_amd import ops
+    N, To, Tp = 2, 3, 4
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+
+    def grads(poison):
+        m = GC._small_predictor(impl, False, 101, DEV)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        if poison:
+            opt.zero_grad()
+
+            class Boom(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, x):
+                    return x.clone()
+
+                @staticmethod
+                def backward(ctx, g):
+                    raise RuntimeError("boom")
+            # the failing node sits at the INPUT: the whole predictor's backward (weight-gradient closures queued on the way) runs first
+            y = m(Boom.apply(past.clone().requires_grad_()))
+            with pytest.raises(RuntimeError, match="boom"):
+                (y * y).sum().backward()
+            assert ops.WgradStream._pending is not None, "expected an open gradient-stream join after the failed backward"
+        opt.zero_grad()
+        (m(past) - fut).abs().mean().backward()
+        ops.WgradStream.join()
+        torch.cuda.synchronize()
+        return opt.flat_g.clone()
+
+    a, b = grads(False), grads(True)
+    assert GC.rel_err(b, a) < 1e-6, "stale gradient-stream work leaked into the step after a failed backward"
+
+
+def test_chained_split_k_reductions_are_bit_identical(impl):
+    """ops.WgradChain: a weight gradient's split-K reduction done by extra workgroups of the NEXT weight-gradient launch (or by
+    npvp_splitk_reduce_job at the end of backward) sums the same slabs in the same order as the stand-alone reduction launch:
+    the whole flat gradient of a step must be bit-identical with the chain on and off (4 096 decoder token rows: the fp16
+    weight-gradient kernel with split-K; dropout on, so the row-group masks ride in the chained launches too)."""
+    from npvp_amd import ops
+    if MODE != "f16x3":
+        pytest.skip("the chain belongs to the fp16 weight-gradient kernel")
+    N, To, Tp = 8, 2, 8
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+    old = ops.WgradChain.enabled
+    flat, launches = {}, {}
+    try:
+        for on in (True, False):
+            ops.WgradChain.enabled = on
+            m = GC._small_predictor(impl, False, 101, DEV, To=To, Tp=Tp, dropout=0.1, drop_path=0.1)
+            m.train()
+            opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+            ops.rng.manual_seed(777, torch.device(DEV))
+            ops.rng.begin_step(torch.device(DEV))
+            opt.zero_grad()
+            (m(past) - fut).abs().mean().backward()
+            ops.WgradStream.join()
+            torch.cuda.synchronize()
+            assert not ops.WgradChain._pending, "a deferred reduction was left behind after the join"
+            flat[on] = opt.flat_g.clone()
+        assert float(flat[True].abs().max()) > 0
+        assert torch.equal(flat[True], flat[False]), f"chained vs stand-alone reductions differ: {GC.rel_err(flat[True], flat[False]):.3e}"
+    finally:
+        ops.WgradChain.enabled = old
+
+
+@pytest.mark.parametrize("which", ["dual_encoder", "decoder_split"])
+def test_stream_experiments_keep_the_amax_slots_ordered(impl, which):
+    """the opt-in stream experiments (NPVP_DUAL_ENCODER: the two NPVP-S encoder passes on two streams, forward and
+    backward; NPVP_DECODER_SPLIT: the decoder's half-batches on two streams) cut fp16 amax slots inside their auxiliary-stream
+    regions.  A slot chunk is now per (device, stream) - zero-filled on the stream that cuts from it - so a step with either
+    switch on must still meet the reference's training-step vectors (a slot that read 0 would flush 1e-8-sized gradients)."""
+    from npvp_amd import ops
+    if MODE != "f16x3":
+        pytest.skip("amax slots belong to the f16x3 arithmetic")
+    old = (ops.AuxStream.enabled, ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows)
+    try:
+        if which == "dual_encoder":
+            ops.AuxStream.enabled = True
+        else:
+            ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows = True, 1
+        ops.AmaxSlot.reset_chunks()
+        mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        res = GC.case_train_step(impl, DEV, "S", make_opt=mk)
+        g = GC.load("train_step_S")
+        GC.compare({k: v for k, v in res.items() if k.endswith("_0")}, {k: v for k, v in g.items() if k.endswith("_0")}, TOL,
+                   tag=f"train_step_S[{which}]")
+        GC.compare({k: v for k, v in res.items() if k.endswith("_1")}, {k: v for k, v in g.items() if k.endswith("_1")}, max(3e-3, TOL))
+    finally:
+        ops.AuxStream.enabled, ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows = old
+        ops.AmaxSlot.reset_chunks()
+        torch.cuda.synchronize()
+
+
 def test_grad_sink_matches_autograd_accumulation(impl):
     """ops.GradSink (backward kernels accumulate parameter gradients straight into the flat gradient buffer) against
     the plain autograd route (temporaries + AccumulateGrad adds): same flat gradient, tied LayerNorm and the twice-used

@@ -3,6 +3,7 @@ tests/conftest.py before the test process touches the GPU; this wrapper itself n
   1. tools/dp_check.py        - 2 ranks on one card (gloo on device tensors): the real data-parallel step == one process
   2. bench.py --gpus 2        - the N > 1 branch of the benchmark itself (rank-strided model build, GradSync, SyncBatchNorm,
                                 MAX-over-ranks timing, the JSON line) on the BASELINE multi-GPU shard workload (c4: 8 clips)
+  3. bench.py --gpus 1 on RCCL - one rank, backend nccl, NPVP_DP_FORCE=1: the data-parallel path on real RCCL (see below)
 Each job's output goes to <log>.<name>; the wrapper's exit code is the first failure's."""
 import os, subprocess, sys
 
@@ -13,10 +14,17 @@ run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per
 jobs = [("dp_check", run + ["--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]),
         ("bench2", run + ["--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "3",
                           "--warmup", "1", "--no-secondary"])]
+# 3. RCCL itself, as far as one GPU allows: ONE rank, backend nccl, NPVP_DP_FORCE=1 = the whole data-parallel code path on a group
+#    of one (ProcessGroupNCCL init, model broadcast, SyncBatchNorm2d's all-reduces on their own communicator, GradSync's bucket
+#    all_reduce(async_op=True) on the side stream + work.wait() + finish()) inside the benchmark's own step
+run1 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+jobs.append(("rccl1", run1 + ["--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
+                              "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
+envs = {"rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1")}
 rc = 0
 for name, cmd in jobs:
     with open(f"{log}.{name}", "w") as f:
-        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, env=envs.get(name, env), cwd=ROOT)
     if r.returncode != 0 and rc == 0:
         rc = r.returncode
 sys.exit(rc)
