@@ -58,18 +58,19 @@ __device__ __forceinline__ bool block_any(bool pred, int* flags, int wave) {
   return __builtin_amdgcn_readfirstlane(any) != 0;
 }
 
-template <int TM, int TN, int WM, int WN, bool ROWSTATS>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(GemmParams p) {
+template <int TM, int TN, int WM, int WN, bool ROWSTATS, int MINB = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams p) {
   constexpr int NW = WM * WN, THREADS = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int APASS = BM / (THREADS / 4);
-  static_assert(APASS == 2 && BN % 64 == 0, "A staging is written for two row passes");
+  static_assert((APASS == 1 || APASS == 2) && BN % 64 == 0, "A staging: a thread stages one or two rows of the tile");
   constexpr int KGS_A = BM * 16 + 64, A_PLANE = 2 * KGS_A, A_BYTES = 2 * A_PLANE;
   constexpr int KGS_B = BN * 16, B_PLANE = 2 * KGS_B, B_BYTES = 2 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int CPS = BN / 64;                       // 1 KB glds chunks per (term, k-group) slab
   constexpr int NCHUNK = 4 * CPS, CPW = (NCHUNK + NW - 1) / NW;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  constexpr int EPI_BYTES = (4 + NW * EPI_FLOATS + BM) * 4;          // the epilogue's scratch lives in the idle stages
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
 
   int tile_m, tile_n;
   tile_of_block_unsplit(p, tile_m, tile_n);
@@ -120,11 +121,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   // in front of every barrier.  VMEM issue order per step: 4 (CPW) LDS-DMA pieces of B tile kt+1, then 2 loads of A tile
   // kt+3; "vmcnt(2)" at the step's end therefore waits for everything but those 2 loads - B kt+1 (one step of latency
   // budget) and A kt+2 (a step and a half) have landed, and the registers consumed in the next step are valid.
-  f32x4 ea0, ea1, eb0, eb1;
+  f32x4 ea0, ea1 = {0.f, 0.f, 0.f, 0.f}, eb0, eb1 = {0.f, 0.f, 0.f, 0.f};
 #define NPVP_H_ALOAD(R0, R1, KT)                                                                           \
   { const char* ab_ = a_base + ((long long)min((KT), nk - 1) << 6);                                        \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R0) : "v"(a_off0), "s"(ab_) : "memory");          \
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R1) : "v"(a_off1), "s"(ab_) : "memory"); }
+    if constexpr (APASS == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R1) : "v"(a_off1), "s"(ab_) : "memory"); }
+  // everything but the APASS loads just issued has landed
+#define NPVP_H_WAIT_BUT_NEWEST(...)                                                                        \
+  { if constexpr (APASS == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : __VA_ARGS__ :: "memory");     \
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" : __VA_ARGS__ :: "memory"); }
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
   { if (ROWOFF) rm1 = fmaxf(fmaxf(rm1, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));  \
     else rm0 = fmaxf(fmaxf(rm0, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));         \
@@ -162,10 +167,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   NPVP_H_ALOAD(ea0, ea1, 0)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1) :: "memory");
   NPVP_H_ASTORE(lds, ea0, 0)
-  NPVP_H_ASTORE(lds, ea1, (BM / 2) * 16)
+  if constexpr (APASS == 2) NPVP_H_ASTORE(lds, ea1, (BM / 2) * 16)
   NPVP_H_ALOAD(ea0, ea1, 1)
   NPVP_H_ALOAD(eb0, eb1, 2)
-  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(ea0), "+v"(ea1) :: "memory");
+  NPVP_H_WAIT_BUT_NEWEST("+v"(ea0), "+v"(ea1))
   __builtin_amdgcn_s_barrier();
 
   // one K-step: MFMAs of tile KT on stage CUR; B tile KT+1 is DMA'd into NXT; A tile KT+1 (register set R, loaded two
@@ -187,15 +192,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
       f16x8 fa_[2];                                                                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
         fa_[s_] = *reinterpret_cast<const f16x8*>(st_ + fa_off + s_ * A_PLANE + i_ * 512);                 \
-      if (i_ == 0) { NPVP_H_ASTORE(nx_, R0, 0) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) }                      \
-      if (i_ == 1) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                                      \
+      if (i_ == 0) { NPVP_H_ASTORE(nx_, R0, 0) if constexpr (APASS == 2) NPVP_H_ASTORE(nx_, R1, (BM / 2) * 16) } \
+      if (i_ == TM - 1) { NPVP_H_ALOAD(R0, R1, (KT) + 3) }                                                 \
       /* smallest terms first */                                                                           \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[1], fb_[0][j_], (FIRST) ? zero16 : acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[1][j_], acc[i_][j_], 0, 0, 0); \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);       /* every MFMA of the step is issued before the wave parks at the wait */ \
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(RN0), "+v"(RN1) :: "memory");                      \
+    NPVP_H_WAIT_BUT_NEWEST("+v"(RN0), "+v"(RN1))                                                           \
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
 #undef NPVP_H_BLOAD
 #undef NPVP_H_ASTORE
 #undef NPVP_H_ALOAD
+#undef NPVP_H_WAIT_BUT_NEWEST
 
   // Back to the operands' own scale: C = acc * (1/sa) * (1/sb) * alpha + bias.  The two scales are powers of two, so their product
   // times alpha is exact and ONE fused multiply-add per element (the epilogue's own alpha * acc + bias) rounds exactly like
@@ -261,10 +267,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_f16_kernel(G
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
   float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;      // per-wave transposition scratch (the stages are idle:
-  static_assert(2 * STAGE >= (4 + NW * EPI_FLOATS + BM) * 4, "scratch");    // the K loop ended on a barrier); 4 floats: amax commit
+  // the K loop ended on a barrier); 4 floats: amax commit
   if (rescued) {                                                            // (workgroup-uniform) rows back to the tensor's scale
     float* rowfac = reinterpret_cast<float*>(lds) + 4 + NW * EPI_FLOATS;
-    if (quad == 0) { rowfac[rl] = rf0; rowfac[rl + BM / 2] = rf1; }
+    if (quad == 0) { rowfac[rl] = rf0; if (APASS == 2) rowfac[rl + BM / 2] = rf1; }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -534,11 +540,15 @@ bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream) {
 }
 
 // forward / dgrad with scaled fp16 planes: 1 = 128 x 256 tiles, 2 = 128 x 128 tiles (outputs that 128 x 256 tiles do not
-// fill the chip with), 0 = shape not taken (the caller falls back to the three-term bf16 kernels WITHOUT planes)
+// fill the chip with), 3 = 128 x 64 tiles (outputs of at most 128 tiles of 128 x 128), 0 = shape not taken (the caller falls back to the three-term bf16 kernels WITHOUT planes)
 int gemm_f16_variant(int M, int N, int K) {
   if ((K & 15) || (N & 7) || M < 128) return 0;
   const int tw = ((M + 127) / 128) * ((N + 255) / 256);
   if (N % 128 != 0 || tw >= 512) return 1;
+  // up to 128 tiles of 128 x 128 (the encoder of an 8-clip shard: 1 024 .. 2 048 token rows) half the chip would idle: 128 x 64
+  // tiles double the workgroups (R = 2 048: forward 18.8 -> 15.4 us at N = K = 512, 58 -> 49 us at K = 2 048; from 256 tiles on the
+  // narrow tile loses - the A staging per MFMA doubles - profiles/r04_gemm_bench_narrow.txt)
+  if (N % 64 == 0 && ((M + 127) / 128) * (N / 128) <= 128) return 3;
   return 2;
 }
 
@@ -547,7 +557,7 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
   if (p.adrop.thresh && (p.adrop.mode != 1 || !p.seed)) return false;
   const int v = gemm_f16_variant(p.M, p.N, p.K);
   if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return false;
-  const int bn = v == 1 ? 256 : 128;
+  const int bn = v == 1 ? 256 : (v == 3 ? 64 : 128);
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
@@ -555,7 +565,10 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
   if (v == 1) {
     if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+  } else if (v == 3 && !p.rowstats) {
+    hipLaunchKernelGGL((gemm_f16_kernel<2, 1, 2, 2, false>), grid, block, 0, stream, p);
   } else {
+    if (v == 3) { p.tiles_n = (p.N + 127) / 128; grid = dim3(p.tiles_m * p.tiles_n); p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n); }
     if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
   }

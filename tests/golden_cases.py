@@ -53,9 +53,13 @@ def log_err(tag, key, e, er=None):
             f.write(f"{tag} {key} {e:.3e}" + (f" row {er:.3e}" if er is not None else "") + "\n")
 
 
-def compare(results, golden, tol, skip=(), tag="", row_tol=1e-3):
+def compare(results, golden, tol, skip=(), tag="", row_tol=None):
     """Every golden array (except meta) must be reproduced within rel-L2 `tol`, and - for arrays stored with their row
-    structure - every row of it within `row_tol` (max_row_rel_err; 1e-3 = north_star's bar)."""
+    structure - every ROW of it within `row_tol` (max_row_rel_err).  north_star's bar is 1e-3; the default here is 2e-5 wherever
+    the whole-tensor bound is the usual 1e-4 (measured on the GPU, every mode: <= 7.6e-6, the exact fp32-MFMA mode included - that
+    much is the oracle's own fp32 rounding against the reference), 10 x tol for cases with a looser whole-tensor bound."""
+    if row_tol is None:
+        row_tol = 2e-5 if tol <= 1e-4 else 10 * tol
     worst = 0.0
     errs, rerrs = {}, {}
     for key, g in golden.items():

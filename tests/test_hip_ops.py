@@ -22,7 +22,8 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-ROW_TOL = 1e-3       # north_star's bar, per ROW (token row of an activation / gradient, output-feature row of a weight gradient)
+ROW_TOL = 1e-4       # per ROW (token row of an activation / gradient, output-feature row of a weight gradient); north_star's bar is
+                     # 1e-3, measured worst over every op test and fp32-grade mode: 7e-6 (bf16x3: 1.1e-5)
 
 
 def close(a, b, tol=TOL, what="", row_tol=None, row_floor=1e-6):
