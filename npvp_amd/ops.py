@@ -1589,7 +1589,7 @@ def dwconv3x3(a, wtb, frames, H, W, want_stats=False):
     return _DwConv.apply(a, wtb, frames, H, W, bool(want_stats))
 
 
-MID_BWD_FENCE = os.environ.get("NPVP_MID_BWD_FENCE", "1") == "1"
+MID_BWD_FENCE = os.environ.get("NPVP_MID_BWD_FENCE", "0") == "1"
 
 
 class _MlpDwbn(torch.autograd.Function):
@@ -1752,10 +1752,10 @@ class _MlpDwbn(torch.autograd.Function):
         dwtb = torch.empty(10, hid, dtype=torch.float32, device=dev)
         psum = torch.empty(frames * (hid // 256) * 2, dtype=torch.float32, device=dev)
         ws, wsn = _ws(L.npvp_mlpdw_mid_bwd_workspace_bytes(frames, hid), dev)
-        # Second line of defence: mlpdw_mid_bwd_kernel's packed-FMA build was not bitwise reproducible
-        # while a weight-gradient GEMM of the gradient stream shared the CUs.  The kernel now accumulates with scalar
-        # v_fmac_f32 and is reproducible without this wait (soak runs in DESIGN.md); the wait costs less than run-to-run
-        # noise, so it stays on by default (NPVP_MID_BWD_FENCE=0 removes it).
+        # NPVP_MID_BWD_FENCE=1 (off by default since round 4): a wait for the gradient stream in front of this kernel.  Round 2's
+        # packed-FMA build of mlpdw_mid_bwd_kernel was not bitwise reproducible while a weight-gradient GEMM shared the CUs; the
+        # kernel has accumulated with scalar v_fmac_f32 since, 28 soak runs without the wait give one digest per batch size
+        # (profiles/r04_determinism_soak.txt) and the wait costs 2.4 ms of a c2 step.
         if MID_BWD_FENCE and WgradStream._pending is not None:
             WgradStream.flush()
             torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
