@@ -13,7 +13,7 @@ def load(path, counter):
         n = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", name))
         full = n if len(n) < 100 else n[:97] + "..."
         base = re.sub(r"<.*$", "", n)
-        m = re.match(r"(npvp::gemm_(?:wide|f16)_kernel<\d+, \d+, \d+, \d+), \w+>", n)
+        m = re.match(r"(npvp::gemm_(?:wide|f16)_kernel<\d+, \d+, \d+, \d+), .*>", n)
         if m:               # the tile instantiations of the wide kernel are different kernels to bench.py (npvp_gemm_kernel_id 2 / 4)
             base = m.group(1) + ">"
         for k in (full, "POOL:" + base):
