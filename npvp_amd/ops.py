@@ -574,14 +574,17 @@ class WgradStream:
         return cls._side[key]
 
     in_flush = False         # inside flush(): the current stream is the gradient stream (WgradChain defers reductions there)
+    _held, _held_bytes = [], 0
+    HOLD_BYTES = int(os.environ.get("NPVP_WGRAD_HOLD_MB", "2048")) << 20
     _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
-    BATCH = max(1, int(os.environ.get("NPVP_WGRAD_BATCH", "3")))
+    BATCH = max(1, int(os.environ.get("NPVP_WGRAD_BATCH", "16")))
 
     @classmethod
     def run(cls, fn, *keep_alive, wrote=None, urgent=False):
         """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors are protected
         from allocator reuse until the side stream has consumed them; `wrote` = gradient slots to report to the GradSink
-        listener once fn is enqueued.  Calls are QUEUED and handed to the side stream BATCH at a time (and when the backward
+        listener once fn is enqueued.  Calls are QUEUED and handed to the side stream BATCH at a time (16 since round 4: on host-bound
+        shards 3 -> 16 measured 0 .. -4.7 ms per step depending on the box's CPU, c1 -1 ms; and when the backward
         pass ends): one event record / wait and one stream switch per batch instead of per call - 300 of them were 8 ms of an
         8-clip step's 42 ms of host time (c3 shard 48.5 -> 43 ms).  `urgent` hands the queue over at once: large GEMMs, whose
         early start is worth more than the host time (c2: 257 vs 260 ms).  The inputs of fn are never written again on the main stream (they are already read
@@ -614,7 +617,16 @@ class WgradStream:
                 cls.in_flush = False
         for _, keep, slots in q:
             for t in keep:
-                t.record_stream(side)
+                # the gradient stream reads t after the caller may have dropped it: either HOLD a reference until the join (after
+                # which the compute stream is ordered behind everything the gradient stream did - freeing is then safe without
+                # any allocator bookkeeping) or, past a byte budget (the large workloads: tens of GB of dy per backward pass),
+                # record the stream on the block (an event per block when it is freed: 500 of them were ~1 ms of a shard's step)
+                nb = t.numel() * 4
+                if cls._held_bytes + nb <= cls.HOLD_BYTES:
+                    cls._held.append(t)
+                    cls._held_bytes += nb
+                else:
+                    t.record_stream(side)
             if slots is not None:
                 GradSink.wrote(*slots)          # (on the caller's stream: the listener orders its collective after both streams)
 
@@ -635,6 +647,7 @@ class WgradStream:
                 WgradChain.flush()               # the last weight gradient's split-K reduction has no launch to ride in
             torch.cuda.current_stream(dev).wait_stream(side)
             cls._pending = None
+            cls._held, cls._held_bytes = [], 0
 
 
 # --------------------------------------------------------------------------- raw kernel wrappers

@@ -484,10 +484,12 @@ _LARGER_ORACLE = {}
 
 
 @pytest.mark.parametrize("variant,N,To,Tp,seed0", [("S", 2, 5, 15, 11), ("D", 2, 2, 18, 91), ("D", 1, 2, 28, 91), ("S", 1, 2, 12, 11),
-                                                   ("D", 2, 4, 16, 91), ("S", 1, 10, 10, 11)])
+                                                   ("D", 2, 4, 16, 91), ("S", 1, 10, 10, 11), ("D", 8, 4, 16, 91)])
 def test_against_oracle_larger(impl, variant, N, To, Tp, seed0):
     """Full depth (4+8), every BASELINE config's clip shape - c0 (S, 5+15), c2' (D, 2+18), c2 (D, 2+28), c3 (S, 2+12),
-    c4 (D, 4+16), c1 (S, 10+10): HIP vs oracle on the same seeded inputs, forward (train mode, dropout 0) and gradients."""
+    c4 (D, 4+16), c1 (S, 10+10) - and (round 4) the WHOLE per-GPU shard of the 8-GPU configuration c4 (8 clips of 4 + 16 at full
+    depth: 8 192 decoder token rows, i.e. the shapes and kernel variants the data-parallel benchmark line runs): HIP vs oracle on
+    the same seeded inputs, forward (train mode, dropout 0) and gradients."""
     import oracle
     stochastic = variant == "S"
     h = torch.linspace(0, 7, 8)
