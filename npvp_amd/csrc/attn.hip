@@ -42,33 +42,50 @@ struct AttnParams {
   float* o_amax; float* dq_amax; float* dk_amax; float* dv_amax;     // nullable amax slots of the outputs (common.h)
 };
 
-__device__ __forceinline__ long long attn_row(const AttnParams& p, long long g, int m, int Tn) {
+// The token rows of one attention group, resolved ONCE per wave.  (Until round 4 every row of every tile load and store divided by
+// the window / frame geometry again - 64-bit scalar and 32-bit vector division sequences, 200+ per wave: the T = 28 backward
+// executed ~15 000 scalar instructions around its 320 MFMAs and its time followed them, not the bytes.)
+//   mode 1 (temporal):  a = sample, b = pixel:            row(m) = (a * Tn + m) * P + b
+//   mode 0 (windows):   a = first row of the window:      row(m) = a + (m / ws) * W + m % ws
+// m / ws for the few dozen rows of a window is taken as (int)((m + 0.5) / ws) in fp32: (m + 0.5) / ws is never closer than
+// 1 / (2 ws) to an integer, far above the rounding of the product.  Row indices fit 32 bits (attn_setup checks).
+struct AttnRows { int mode, a, b, P, W, ws; float inv_ws; };
+__device__ __forceinline__ AttnRows attn_rows(const AttnParams& p, unsigned int g) {
+  AttnRows r;
+  r.mode = p.mode; r.P = p.P; r.W = p.W; r.ws = p.ws; r.b = 0; r.inv_ws = 0.f;
   if (p.mode == 0) {
-    const long long f = g / p.nwin;
-    const int win = (int)(g - f * p.nwin);
-    const int qh = win / p.nww, qw = win - qh * p.nww;
-    const int ph = m / p.ws, pw = m - ph * p.ws;
-    return f * p.P + (long long)(qh * p.ws + ph) * p.W + qw * p.ws + pw;
+    const unsigned int f = g / (unsigned int)p.nwin, win = g - f * (unsigned int)p.nwin;
+    const unsigned int qh = win / (unsigned int)p.nww, qw = win - qh * (unsigned int)p.nww;
+    r.a = (int)(f * (unsigned int)p.P + qh * (unsigned int)(p.ws * p.W) + qw * (unsigned int)p.ws);
+    r.inv_ws = 1.f / (float)p.ws;
+  } else {
+    const unsigned int n = g / (unsigned int)p.P;
+    r.a = (int)n; r.b = (int)(g - n * (unsigned int)p.P);
   }
-  const long long n = g / p.P;
-  const int px = (int)(g - n * p.P);
-  return (n * Tn + m) * p.P + px;
+  return r;
+}
+__device__ __forceinline__ long long attn_row(const AttnRows& r, int m, int Tn) {
+  if (r.mode == 0) {
+    const int ph = (int)(((float)m + 0.5f) * r.inv_ws);
+    return r.a + ph * (r.W - r.ws) + m;
+  }
+  return (r.a * Tn + m) * r.P + r.b;
 }
 
-__device__ __forceinline__ void load_tile(float* dst, const float* src, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ void load_tile(float* dst, const float* src, long long ld, const AttnParams& p, const AttnRows& g,
                                           int nrows, int Tn, int head, int lane) {
   for (int idx = lane; idx < nrows * 16; idx += 64) {
     const int r = idx >> 4, c4 = (idx & 15) * 4;
-    st4(dst + r * LDT + c4, ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + c4));
+    st4(dst + r * LDT + c4, ld4(src + attn_row(g, r, Tn) * ld + head * HD + c4));
   }
 }
-__device__ __forceinline__ float store_tile(const float* src, float* dst, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ float store_tile(const float* src, float* dst, long long ld, const AttnParams& p, const AttnRows& g,
                                             int nrows, int Tn, int head, int lane) {
   float am = 0.f;
   for (int idx = lane; idx < nrows * 16; idx += 64) {
     const int r = idx >> 4, c4 = (idx & 15) * 4;
     const float4 v = ld4(src + r * LDT + c4);
-    st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + c4, v);
+    st4(dst + attn_row(g, r, Tn) * ld + head * HD + c4, v);
     am = amax4(am, v);
   }
   return am;
@@ -106,8 +123,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   long long wid = (long long)blockIdx.x * p.wpb + wave;
   const bool active = wid < p.total;
   if (!active) wid = p.total - 1;          // keep every wave in step for the barriers; stores are skipped
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   float* Qs = smem + (long long)wave * p.per_wave_floats;
   float* Ks = Qs + L * LDT;
@@ -190,8 +207,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   long long wid = (long long)blockIdx.x * p.wpb + wave;
   const bool active = wid < p.total;
   if (!active) wid = p.total - 1;
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   float* Qs = smem + (long long)wave * p.per_wave_floats;
   float* Ks = Qs + L * LDT;
@@ -331,33 +348,33 @@ struct AttnTileG { float4 v[4]; };
 
 // blk = 16-row block of the sequence (sequences up to 32 = two blocks); rows past the end are clamped (finite data,
 // their contributions are masked or never stored)
-__device__ __forceinline__ void attn_load_r(AttnTileR& t, const float* src, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ void attn_load_r(AttnTileR& t, const float* src, long long ld, const AttnParams& p, const AttnRows& g,
                                             int nrows, int Tn, int head, int n, int c, int blk) {
   const int r = min(16 * blk + n, nrows - 1);
-  const float* q = src + attn_row(p, g, r, Tn) * ld + head * HD + 16 * c;
+  const float* q = src + attn_row(g, r, Tn) * ld + head * HD + 16 * c;
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
     const float4 x = ld4(q + 4 * s4);
     t.v[4 * s4 + 0] = x.x; t.v[4 * s4 + 1] = x.y; t.v[4 * s4 + 2] = x.z; t.v[4 * s4 + 3] = x.w;
   }
 }
-__device__ __forceinline__ void attn_load_g(AttnTileG& t, const float* src, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ void attn_load_g(AttnTileG& t, const float* src, long long ld, const AttnParams& p, const AttnRows& g,
                                             int nrows, int Tn, int head, int n, int c, int blk) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = min(16 * blk + 4 * c + i, nrows - 1);
-    t.v[i] = ld4(src + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n);
+    t.v[i] = ld4(src + attn_row(g, r, Tn) * ld + head * HD + 4 * n);
   }
 }
 // D rows 16 blk + 4c+i, columns d = 4n + b: one float4 per row
-__device__ __forceinline__ void attn_store_d(const f32x4_t (&acc)[4], float* dst, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ void attn_store_d(const f32x4_t (&acc)[4], float* dst, long long ld, const AttnParams& p, const AttnRows& g,
                                              int nrows, int Tn, int head, int n, int c, int blk, float& am) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 16 * blk + 4 * c + i;
     if (r < nrows) {
       const float4 v = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-      st4(dst + attn_row(p, g, r, Tn) * ld + head * HD + 4 * n, v);
+      st4(dst + attn_row(g, r, Tn) * ld + head * HD + 4 * n, v);
       am = amax4(am, v);
     }
   }
@@ -391,8 +408,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= p.total) return;                      // waves are independent: no barriers in this kernel
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
@@ -455,8 +472,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
   const int lane = threadIdx.x & 63, n = lane & 15, c = lane >> 4;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= p.total) return;
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
@@ -574,12 +591,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnParams p) {
 // bank-conflict free); V is only ever needed as "R" tiles and stays in registers.  No barrier: the wave is alone in its
 // workgroup and LDS operations of one wave execute in order.  22.8 KB of LDS at T = 28 -> 7 waves per CU.
 template <int NIT>
-__device__ __forceinline__ void attn_stage_load(float4 (&r)[NIT], const float* src, long long ld, const AttnParams& p, long long g,
+__device__ __forceinline__ void attn_stage_load(float4 (&r)[NIT], const float* src, long long ld, const AttnParams& p, const AttnRows& g,
                                                 int nrows, int Tn, int head, int lane) {
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = 4 * it + (lane >> 4);
-    if (row < nrows) r[it] = ld4(src + attn_row(p, g, row, Tn) * ld + head * HD + (lane & 15) * 4);
+    if (row < nrows) r[it] = ld4(src + attn_row(g, row, Tn) * ld + head * HD + (lane & 15) * 4);
   }
 }
 template <int NIT>
@@ -608,8 +625,8 @@ __global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x, n = lane & 15, c = lane >> 4;
   const long long wid = blockIdx.x;
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
@@ -744,8 +761,8 @@ __global__ __launch_bounds__(64, 2) void attn_bwd_staged1_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x, n = lane & 15, c = lane >> 4;
   const long long wid = blockIdx.x;
-  const int head = (int)(wid % p.heads);
-  const long long g = wid / p.heads;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
   const int L = p.L, S = p.S;
   const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
   const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
@@ -871,6 +888,9 @@ static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int fram
   p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   p.salt = salt; p.seed = seed;
   p.total = groups * heads;
+  // the kernels resolve (group, head) and token rows in 32-bit arithmetic (AttnRows)
+  const long long rows = mode == 0 ? (long long)frames_or_N * P : (long long)frames_or_N * P * (Tq > Tk ? Tq : Tk);
+  if (p.total >= (1ll << 31) || rows >= (1ll << 31)) { npvp_set_error("attn: too many token rows / (group, head) pairs for one launch"); return NPVP_ERR_ARG; }
   int pw = (p.L + 2 * p.S) * LDT + p.L * LDP;
   if (bwd) pw += p.L * LDT + p.L * LDP;
   pw = (pw + 3) & ~3;

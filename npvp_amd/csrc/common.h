@@ -213,9 +213,26 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 //           per sample g1 = T*P, g2 = N; the enc-dec site drops whole time-steps (:239): g1 = P, g2 = T)
 struct DropSpec {
   unsigned int thresh; float inv_keep; unsigned int salt; int mode; int g1; int g2;
+  unsigned int m1, m2; int s1, s2;      // magic multipliers for row / g1 and (row / g1) / g2 (rows < 2^31), see div_magic
 };
+// n / d for n < 2^31 as (n * m) >> s with m = ceil(2^s / d), s = 31 + ceil(log2 d): exact (m d - 2^s < d <= 2^(s-31), so the
+// excess n (m d - 2^s) / (d 2^s) stays below 1 / d).  The group of a token row used to be two 64-bit divisions per call - ~250
+// vector instructions per row in a GEMM epilogue whose whole K loop has 2 800.
+__host__ __device__ __forceinline__ void div_magic(unsigned int d, unsigned int& m, int& s) {
+  int l = 0;
+  while (l < 31 && (1u << l) < d) ++l;
+  s = 31 + l;
+  m = (unsigned int)(((1ull << s) + d - 1ull) / d);
+}
+__device__ __forceinline__ unsigned int div_by_magic(unsigned int n, unsigned int m, int s) {
+  return (unsigned int)(((unsigned long long)n * m) >> s);
+}
+__device__ __forceinline__ unsigned int drop_group(const DropSpec& d, long long row) {
+  const unsigned int q1 = div_by_magic((unsigned int)row, d.m1, d.s1);
+  return q1 - div_by_magic(q1, d.m2, d.s2) * (unsigned int)d.g2;
+}
 __device__ __forceinline__ float drop_spec_scale(const DropSpec& d, uint64_t seed, long long row, int col, int ncols) {
-  const uint64_t key = d.mode == 0 ? (uint64_t)row * (uint64_t)ncols + (uint64_t)col : (uint64_t)((row / d.g1) % d.g2);
+  const uint64_t key = d.mode == 0 ? (uint64_t)row * (uint64_t)ncols + (uint64_t)col : (uint64_t)drop_group(d, row);
   return rng_u32(seed, d.salt, key) >= d.thresh ? d.inv_keep : 0.f;
 }
 inline DropSpec make_drop_spec(float p, unsigned int salt, int mode, int g1, int g2) {
@@ -223,6 +240,8 @@ inline DropSpec make_drop_spec(float p, unsigned int salt, int mode, int g1, int
   d.thresh = p > 0.f ? drop_threshold(p) : 0u;
   d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   d.salt = salt; d.mode = mode; d.g1 = g1 > 0 ? g1 : 1; d.g2 = g2 > 0 ? g2 : 1;
+  div_magic((unsigned int)d.g1, d.m1, d.s1);
+  div_magic((unsigned int)d.g2, d.m2, d.s2);
   return d;
 }
 

@@ -1,6 +1,7 @@
 // Shared by the GEMM translation units (gemm.hip: fp32-MFMA triage kernel + 128x128 split kernel + C entry point;
 // gemm_wide.hip: 256-row-tile split kernels for the large forward / dgrad / wgrad shapes).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace npvp {
@@ -107,9 +108,32 @@ __device__ __forceinline__ float4 f4_mad(const float4& a, float s, const float4&
 }
 __device__ __forceinline__ void f4_add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
+// f(integral_constant<int, I>) for I = 0 .. N-1, unrolled by construction.  The epilogues index the accumulator tiles acc[i][j]
+// with these: a `#pragma unroll` loop the optimizer declines ("unrolled size is too large": three epilogue variants per tile)
+// turns acc[i][j] into a dynamically indexed array - 128 accumulator registers through scratch memory, 1.6x the launch time.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// the keep-scales of a row-group (DropPath) mask for the four rows a lane owns in every 32 x 32 sub-tile of one 32-row block:
+// taken once per row block, not once per sub-tile and element
+__device__ __forceinline__ float4 epilogue_row_scales(const GemmParams& p, unsigned long long seed, int row0, int lane) {
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (p.drop.thresh && p.drop.mode != 0) {
+    const int r = row0 + (lane >> 3);
+    sc.x = drop_spec_scale(p.drop, seed, r, 0, 1); sc.y = drop_spec_scale(p.drop, seed, r + 8, 0, 1);
+    sc.z = drop_spec_scale(p.drop, seed, r + 16, 0, 1); sc.w = drop_spec_scale(p.drop, seed, r + 24, 0, 1);
+  }
+  return sc;
+}
+
 template <bool CHECK>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float4 (&v)[4], int row0, int col0, int lane, int z,
-                                              unsigned long long seed, float& cmax) {
+                                              unsigned long long seed, float& cmax, float4 rowsc, float alpha) {
   const int rb = row0 + (lane >> 3), col = col0 + 4 * (lane & 7);
   if (CHECK && col >= p.N) return;                 // (N % 4 == 0: a quad is inside or outside)
 #define NPVP_ROW(k) (rb + 8 * (k))
@@ -123,7 +147,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float4 (&v)[4
   }
   const float4 bv = p.bias ? ld4(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = f4_mad(v[k], p.alpha, bv);
+  for (int k = 0; k < 4; ++k) v[k] = f4_mad(v[k], alpha, bv);
   if (p.aux_out) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (NPVP_INB(k)) st4(p.aux_out + NPVP_ROW(k) * ld + col, v[k]);
@@ -152,11 +176,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float4 (&v)[4
     }
   }
   if (p.drop.thresh) {
+    if (p.drop.mode == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long long row = NPVP_ROW(k);
-      v[k].x *= drop_spec_scale(p.drop, seed, row, col + 0, p.N); v[k].y *= drop_spec_scale(p.drop, seed, row, col + 1, p.N);
-      v[k].z *= drop_spec_scale(p.drop, seed, row, col + 2, p.N); v[k].w *= drop_spec_scale(p.drop, seed, row, col + 3, p.N);
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long key = (unsigned long long)NPVP_ROW(k) * (unsigned long long)p.N + (unsigned long long)col;
+        v[k].x *= drop_scale(seed, p.drop.salt, key + 0, p.drop.thresh, p.drop.inv_keep);
+        v[k].y *= drop_scale(seed, p.drop.salt, key + 1, p.drop.thresh, p.drop.inv_keep);
+        v[k].z *= drop_scale(seed, p.drop.salt, key + 2, p.drop.thresh, p.drop.inv_keep);
+        v[k].w *= drop_scale(seed, p.drop.salt, key + 3, p.drop.thresh, p.drop.inv_keep);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float f = k == 0 ? rowsc.x : k == 1 ? rowsc.y : k == 2 ? rowsc.z : rowsc.w;
+        v[k].x *= f; v[k].y *= f; v[k].z *= f; v[k].w *= f;
+      }
     }
   }
   if (p.residual) {
@@ -178,14 +212,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float4 (&v)[4
 }
 
 // the bias-only epilogue of a tile inside the matrix (the launches with frame statistics): nothing but C = v alpha + bias
-__device__ __forceinline__ void epilogue_rows_bias(const GemmParams& p, float4 (&v)[4], int row0, int col0, int lane, float& cmax) {
+__device__ __forceinline__ void epilogue_rows_bias(const GemmParams& p, float4 (&v)[4], int row0, int col0, int lane, float& cmax, float alpha) {
   const int col = col0 + 4 * (lane & 7);
   float* cp = p.C + (long long)(row0 + (lane >> 3)) * p.ldc + col;
   const long long ld8 = 8 * p.ldc;
   const float4 bv = p.bias ? ld4(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float4 x = f4_mad(v[k], p.alpha, bv);
+    const float4 x = f4_mad(v[k], alpha, bv);
     st4(cp + k * ld8, x);
     if (p.c_amax) cmax = amax4(cmax, x);
   }
@@ -193,7 +227,7 @@ __device__ __forceinline__ void epilogue_rows_bias(const GemmParams& p, float4 (
 
 // scr = THIS WAVE's EPI_FLOATS floats of LDS
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int lane, float* scr, int z,
-                                              unsigned long long seed, float& cmax) {
+                                              unsigned long long seed, float& cmax, float4 rowsc, float alpha) {
   if (row0 >= p.M || col0 >= p.N) return;          // (wave-uniform: a tile entirely outside the matrix)
   float4 v[4];
   epi_transpose(acc, scr, lane, v);
@@ -202,9 +236,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
   // loop instead of the general one (whose address arithmetic for the options it does not use cost ~100 us of a
   // [114 688 x 2048]-output launch)
   const bool simple = p.splits == 1 && !p.aux_out && p.act == 0 && !p.drop.thresh && !p.residual && !p.accum;
-  if (simple && inside) epilogue_rows_bias(p, v, row0, col0, lane, cmax);
-  else if (inside) epilogue_rows<false>(p, v, row0, col0, lane, z, seed, cmax);
-  else epilogue_rows<true>(p, v, row0, col0, lane, z, seed, cmax);
+  if (simple && inside) epilogue_rows_bias(p, v, row0, col0, lane, cmax, alpha);
+  else if (inside) epilogue_rows<false>(p, v, row0, col0, lane, z, seed, cmax, rowsc, alpha);
+  else epilogue_rows<true>(p, v, row0, col0, lane, z, seed, cmax, rowsc, alpha);
 }
 
 // Epilogue of the forward GEMMs that feed a frame LayerNorm (MlpDWBN fc1 -> norm1, fc2 -> norm3): C = acc*alpha + bias,
@@ -216,7 +250,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
 // the matrix or outside.  The stores go through the same transposed path as every other epilogue.
 __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, const f32x16& a00, const f32x16& a01,
                                                         const f32x16& a10, const f32x16& a11, int row0, int col0, int lane,
-                                                        float* scr, float& cmax) {
+                                                        float* scr, float& cmax, float alpha) {
   if (row0 >= p.M || col0 >= p.N) return;
   const int r = lane & 31;
   float shift = 0.f, s1 = 0.f, s2 = 0.f;
@@ -231,7 +265,7 @@ __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, con
       const float bv = p.bias ? p.bias[col0 + tn * 32 + r] : 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const float v = acc[g] * p.alpha + bv;
+        const float v = acc[g] * alpha + bv;
         if (tm == 0 && tn == 0 && g == 0) shift = v;
         const float d = v - shift;
         s1 += d; s2 += d * d;
@@ -246,7 +280,7 @@ __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, con
       const f32x16& acc = tm == 0 ? (tn == 0 ? a00 : a01) : (tn == 0 ? a10 : a11);
       float4 v[4];
       epi_transpose(acc, scr, lane, v);
-      epilogue_rows_bias(p, v, row0 + tm * 32, col0 + tn * 32, lane, cmax);
+      epilogue_rows_bias(p, v, row0 + tm * 32, col0 + tn * 32, lane, cmax, alpha);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

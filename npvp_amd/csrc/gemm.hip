@@ -93,10 +93,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16&
   const int row0 = m0 + wm * 64, col0 = n0 + wn * 64, lane = threadIdx.x & 63;
   float* scr = lds + (threadIdx.x >> 6) * EPI_FLOATS;
   float cmax = 0.f;
-  epilogue_tile(p, acc00, row0, col0, lane, scr, z, seed, cmax);
-  epilogue_tile(p, acc01, row0, col0 + 32, lane, scr, z, seed, cmax);
-  epilogue_tile(p, acc10, row0 + 32, col0, lane, scr, z, seed, cmax);
-  epilogue_tile(p, acc11, row0 + 32, col0 + 32, lane, scr, z, seed, cmax);
+  float4 rowsc = epilogue_row_scales(p, seed, row0, lane);
+  epilogue_tile(p, acc00, row0, col0, lane, scr, z, seed, cmax, rowsc, p.alpha);
+  epilogue_tile(p, acc01, row0, col0 + 32, lane, scr, z, seed, cmax, rowsc, p.alpha);
+  rowsc = epilogue_row_scales(p, seed, row0 + 32, lane);
+  epilogue_tile(p, acc10, row0 + 32, col0, lane, scr, z, seed, cmax, rowsc, p.alpha);
+  epilogue_tile(p, acc11, row0 + 32, col0 + 32, lane, scr, z, seed, cmax, rowsc, p.alpha);
   if (p.splits == 1) amax_slot_commit(p.c_amax, cmax, 0u);        // (small shapes only: no peek)
 }
 
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_split_db_kernel(GemmPara
   float* scr0 = reinterpret_cast<float*>(lds);
   if constexpr (ROWSTATS) {
     float cmax = 0.f;
-    epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, lane, scr0 + wave * EPI_FLOATS, cmax);
+    epilogue_rowstats_block(p, acc00, acc01, acc10, acc11, m0 + wm * 64, n0 + wn * 64, lane, scr0 + wave * EPI_FLOATS, cmax, p.alpha);
     amax_slot_commit(p.c_amax, cmax, 0u);
   } else gemm_epilogue(p, acc00, acc01, acc10, acc11, m0, n0, wm, wn, scr0, z);
 }

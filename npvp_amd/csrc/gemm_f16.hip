@@ -249,11 +249,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   // accumulators are scaled in two exact steps, so that neither product of scales can under- or overflow.  Folding saves 32 VALU
   // per 32 x 32 tile (the scalings were a third of the epilogue's instructions).
   const float ia = pow2_recip(sa), ib = pow2_recip(amax_scale(amax_slot_read(p.b_amax)));
-  GemmParams q = p;
+  float alpha = p.alpha;                 // (handed to the epilogue beside p: a modified COPY of the parameter block lives in scratch)
   {
     const float f = ia * ib, af = p.alpha * f, mag = fabsf(af);
     const bool fold = f >= 1.17549435e-38f && f <= 3.0e38f && ((mag >= 1.17549435e-38f && mag <= 3.0e38f) || p.alpha == 0.f);
-    if (fold) q.alpha = af;
+    if (fold) alpha = af;
     else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -287,13 +287,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
     for (int i = 0; i < TM; i += 2)
 #pragma unroll
       for (int j = 0; j < TN; j += 2)
-        epilogue_rowstats_block(q, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax);
+        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax, alpha);
   } else {
-    const unsigned long long seed = (q.seed && q.drop.thresh) ? *q.seed : 0ull;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) epilogue_tile(q, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax);
+    const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
+    static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
+      const float4 rowsc = epilogue_row_scales(p, seed, row_base + i * 32, lane);
+      static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
+        epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax, rowsc, alpha);
+      });
+    });
   }
   amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
@@ -499,10 +501,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   const unsigned long long seed = 0ull;
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, z, seed, cmax);
+  const float4 no_rowsc = make_float4(1.f, 1.f, 1.f, 1.f);         // (a weight gradient's epilogue carries no mask)
+  static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
+    static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
+      epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, z, seed, cmax, no_rowsc, p.alpha);
+    });
+  });
 }
 
 // split count of the fp16 weight-gradient kernel: ~512 workgroups, >= 16 K-steps per split; 0 = shape not taken

@@ -164,13 +164,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wide_kernel(
     for (int i = 0; i < TM; i += 2)
 #pragma unroll
       for (int j = 0; j < TN; j += 2)
-        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax);
+        epilogue_rowstats_block(p, acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], row_base + i * 32, col_base + j * 32, lane, scr, cmax, p.alpha);
   } else {
     const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax);
+    static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
+      const float4 rowsc = epilogue_row_scales(p, seed, row_base + i * 32, lane);
+      static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
+        epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax, rowsc, p.alpha);
+      });
+    });
   }
   amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
@@ -329,10 +331,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_wide_k
   const unsigned long long seed = 0ull;
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, z, seed, cmax);
+  const float4 no_rowsc = make_float4(1.f, 1.f, 1.f, 1.f);         // (a weight gradient's epilogue carries no mask)
+  static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
+    static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
+      epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, z, seed, cmax, no_rowsc, p.alpha);
+    });
+  });
 }
 
 // split count of the wide weight-gradient kernel: ~512 workgroups (2 per CU), >= 16 K-steps per split

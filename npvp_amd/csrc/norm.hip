@@ -582,7 +582,7 @@ struct FlnParams {
 __device__ __forceinline__ float fln_scale(const FlnParams& p, unsigned long long seed, long long f, long long gidx) {
   float sc = 1.f;
   if (p.drop_thresh) sc *= drop_scale(seed, p.salt, (unsigned long long)gidx, p.drop_thresh, p.drop_inv_keep);
-  if (p.dp_thresh) sc *= drop_scale(seed, p.dp_salt, (unsigned long long)(f / p.frames_per_sample), p.dp_thresh, p.dp_inv_keep);
+  if (p.dp_thresh) sc *= drop_scale(seed, p.dp_salt, (unsigned long long)((unsigned int)f / (unsigned int)p.frames_per_sample), p.dp_thresh, p.dp_inv_keep);
   return sc;
 }
 

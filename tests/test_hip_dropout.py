@@ -151,3 +151,34 @@ def test_enc_dec_drop_path_is_constant_over_samples_and_pixels():
     w = torch.eye(C, device=DEV)
     z = ops.linear_fwd(torch.ones(N * T2 * P, C, device=DEV), w, None, drop=d).view(N, T2, P, C)
     assert torch.equal(z != 0, y != 0), "GEMM-epilogue drop-path must replay the same per-time-step mask"
+
+
+@pytest.mark.parametrize("g1,g2", [(1, 77), (7, 13), (64, 5), (448, 3), (1792, 64), (100, 1), (3, 1000)])
+def test_row_group_keys_follow_the_integer_division(g1, g2):
+    """A DropPath site keys its mask by (row / g1) % g2.  The kernels take that quotient by a multiply-shift with host-side magic
+    numbers (csrc/common.h div_magic: two 64-bit divisions per row were most of a GEMM epilogue's instructions); here every row's
+    decision - through npvp_drop_apply and through the epilogue of every GEMM generation - must be the decision of its group in
+    the plain integer arithmetic."""
+    import numpy as np
+    from npvp_amd import ops
+    dev = torch.device(DEV)
+    ops.rng.manual_seed(977, dev)
+    R = 5000 if g1 * g2 < 5000 else 8192
+    d = ops.Drop(0.3, 1, g1, g2)
+    per_group = ops.DropRecorder.mask((d, "group", g2), dev).cpu().numpy()          # decision of group g = row g at g1 = 1
+    assert 0 < (per_group == 0).sum() < g2 or g2 < 8
+    want = per_group[(np.arange(R) // g1) % g2]
+    got = ops.drop_apply(torch.ones(R, 4, device=DEV), d)[:, 0].cpu().numpy()
+    assert np.array_equal(got, want), "npvp_drop_apply"
+    x = torch.randn(R, 512, device=DEV)
+    w = torch.randn(512, 512, device=DEV) * 0.05
+    res = torch.randn(R, 512, device=DEV)
+    for mode in ("f16x3", "bf16x6", "f32"):
+        ops.set_gemm_precision(mode)
+        try:
+            plain = ops.linear_fwd(x, w, None)
+            y = ops.linear_fwd(x, w, None, residual=res, drop=d)
+        finally:
+            ops.set_gemm_precision("f16x3")
+        ref = plain * torch.from_numpy(want).to(DEV)[:, None] + res
+        assert GC.rel_err(y, ref) < 1e-6, f"{mode}: masked epilogue differs from mask x plain output"

@@ -133,8 +133,15 @@ def test_full_step_from_pixels(impl, layout):
     """layout = encoder_channels_last: the frozen encoder runs NHWC and hands the predictor its canonical layout directly"""
     mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
     dl = impl.to_device_layout if layout == "encoder_channels_last" else None
-    GC.compare(GC.case_full_step(impl, impl, DEV, make_opt=mk, device_layout=dl), GC.load("train_step_full_S"), TOL,
+    res, gold = GC.case_full_step(impl, impl, DEV, make_opt=mk, device_layout=dl), GC.load("train_step_full_S")
+    # losses: forward only.  grad_norm and the updated weights hang on the frozen decoder's INPUT GRADIENT, which torch / MIOpen
+    # computes: a few ReLU units within rounding noise of 0 flip with MIOpen's algorithm choice from run to run (see
+    # test_frozen_autoencoder) - the same process repeating this case gives grad_norm 4.2e-5, 9.4e-5 or 1.2e-4 off the vector
+    # (tools/f32_repeat.py; the predictor-only step repeats bit for bit, tools/f32_trace.py), so those keys get that bound
+    via_decoder = ("grad_norm", "w_dec_lin1", "w_evt_fc1")
+    GC.compare({k: v for k, v in res.items() if k not in via_decoder}, {k: v for k, v in gold.items() if k not in via_decoder}, TOL,
                tag=f"full_step[{MODE},{layout}]")
+    GC.compare({k: res[k] for k in via_decoder}, {k: gold[k] for k in via_decoder}, 1e-3, tag=f"full_step.grads[{MODE},{layout}]")
 
 
 @pytest.mark.parametrize("layout", ["nchw", "encoder_channels_last"])
