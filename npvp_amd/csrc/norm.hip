@@ -579,11 +579,16 @@ struct FlnParams {
   int per_frame; long long total4;
 };
 
-__device__ __forceinline__ float fln_scale(const FlnParams& p, unsigned long long seed, long long f, long long gidx) {
-  float sc = 1.f;
-  if (p.drop_thresh) sc *= drop_scale(seed, p.salt, (unsigned long long)gidx, p.drop_thresh, p.drop_inv_keep);
-  if (p.dp_thresh) sc *= drop_scale(seed, p.dp_salt, (unsigned long long)((unsigned int)f / (unsigned int)p.frames_per_sample), p.dp_thresh, p.dp_inv_keep);
-  return sc;
+// keep-scale of an element = (its frame's DropPath decision) x (its own dropout decision).  The frame's factor is taken ONCE per
+// frame (fln_frame_scale) and handed to the per-element function: evaluated per element it was a scalar division and a hash
+// per element - in the forward-with-partials kernel more scalar instructions than the kernel had vector ones.
+__device__ __forceinline__ float fln_frame_scale(const FlnParams& p, unsigned long long seed, long long f) {
+  if (!p.dp_thresh) return 1.f;
+  return drop_scale(seed, p.dp_salt, (unsigned long long)((unsigned int)f / (unsigned int)p.frames_per_sample), p.dp_thresh, p.dp_inv_keep);
+}
+__device__ __forceinline__ float fln_scale(const FlnParams& p, unsigned long long seed, float frame_scale, long long gidx) {
+  if (!p.drop_thresh) return frame_scale;
+  return drop_scale(seed, p.salt, (unsigned long long)gidx, p.drop_thresh, p.drop_inv_keep) * frame_scale;
 }
 
 __global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out, float* __restrict__ amax) {
@@ -596,13 +601,14 @@ __global__ void frameln_act_fwd_kernel(FlnParams p, float* __restrict__ out, flo
     const long long f = i / pf4;
     const int e = (int)(i - f * pf4) * 4;
     const float mu = p.mean[f], rs = p.rstd[f];
+    const float fsc = fln_frame_scale(p, seed, f);
     const float4 v = ld4(p.h + f * p.per_frame + e), ww = ld4(p.w + e), bb = ld4(p.b + e);
     const long long g0 = f * p.per_frame + e;
     float4 o;
-    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, f, g0 + 0);
-    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, f, g0 + 1);
-    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, f, g0 + 2);
-    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, f, g0 + 3);
+    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, fsc, g0 + 0);
+    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, fsc, g0 + 1);
+    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, fsc, g0 + 2);
+    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, fsc, g0 + 3);
     if (p.res) { const float4 r = ld4(p.res + g0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     st4(out + g0, o);
     am = amax4(am, o);
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(256) void frameln_act_fwd_parts_kernel(FlnParams p,
   float mu, rs;
   frame_stats_merge(part, f, J, nb, eps, mu, rs);
   if (e0 == 0 && threadIdx.x == 0) { mean_out[f] = mu; rstd_out[f] = rs; }
+  const float fsc = fln_frame_scale(p, seed, f);
   float am = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -633,10 +640,10 @@ __global__ __launch_bounds__(256) void frameln_act_fwd_parts_kernel(FlnParams p,
     const long long g0 = f * p.per_frame + e;
     const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e);
     float4 o;
-    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, f, g0 + 0);
-    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, f, g0 + 1);
-    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, f, g0 + 2);
-    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, f, g0 + 3);
+    o.x = gelu_f((v.x - mu) * rs * ww.x + bb.x) * fln_scale(p, seed, fsc, g0 + 0);
+    o.y = gelu_f((v.y - mu) * rs * ww.y + bb.y) * fln_scale(p, seed, fsc, g0 + 1);
+    o.z = gelu_f((v.z - mu) * rs * ww.z + bb.z) * fln_scale(p, seed, fsc, g0 + 2);
+    o.w = gelu_f((v.w - mu) * rs * ww.w + bb.w) * fln_scale(p, seed, fsc, g0 + 3);
     if (p.res) { const float4 r = ld4(p.res + g0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     st4(out + g0, o);
     am = amax4(am, o);
@@ -655,16 +662,17 @@ __global__ __launch_bounds__(512) void frameln_act_bwd_stats_kernel(FlnParams p,
   const long long f = blockIdx.x;
   const unsigned long long seed = (p.seed && (p.drop_thresh || p.dp_thresh)) ? *p.seed : 0ull;
   const float mu = p.mean[f], rs = p.rstd[f];
+  const float fsc = fln_frame_scale(p, seed, f);
   float s1 = 0.f, s2 = 0.f;
   const int span = p.per_frame / FLN_PARTS, e0 = blockIdx.y * span, e1 = blockIdx.y == FLN_PARTS - 1 ? p.per_frame : e0 + span;
   for (int e = e0 + threadIdx.x * 4; e < e1; e += 512 * 4) {
     const long long g0 = f * p.per_frame + e;
     const float4 v = ld4(p.h + g0), ww = ld4(p.w + e), bb = ld4(p.b + e), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
-    const float gx = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x) * ww.x;
-    const float gy = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y) * ww.y;
-    const float gz = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z) * ww.z;
-    const float gw = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w) * ww.w;
+    const float gx = d.x * fln_scale(p, seed, fsc, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x) * ww.x;
+    const float gy = d.y * fln_scale(p, seed, fsc, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y) * ww.y;
+    const float gz = d.z * fln_scale(p, seed, fsc, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z) * ww.z;
+    const float gw = d.w * fln_scale(p, seed, fsc, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w) * ww.w;
     s1 += gx + gy + gz + gw;
     s2 += gx * hx + gy * hy + gz * hz + gw * hw;
   }
@@ -693,15 +701,16 @@ __global__ void frameln_act_bwd_fused_kernel(FlnParams p, const float* __restric
   for (long long f = f0; f < f1; ++f) {
     const long long g0 = f * p.per_frame + e;
     const float mu = p.mean[f], rs = p.rstd[f];
+    const float fsc = fln_frame_scale(p, seed, f);
     float a1 = 0.f, a2 = 0.f;              // s1 = mean(g), s2 = mean(g*hhat) from the FLN_PARTS partial sums, fixed order
     for (int j = 0; j < nparts; ++j) { a1 += psum[(f * nparts + j) * 2]; a2 += psum[(f * nparts + j) * 2 + 1]; }
     a1 /= p.per_frame; a2 /= p.per_frame;
     const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
-    const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
-    const float dy_ = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
-    const float dz_ = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
-    const float dw_ = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
+    const float dx_ = d.x * fln_scale(p, seed, fsc, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
+    const float dy_ = d.y * fln_scale(p, seed, fsc, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
+    const float dz_ = d.z * fln_scale(p, seed, fsc, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
+    const float dw_ = d.w * fln_scale(p, seed, fsc, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
     aw.x += dx_ * hx; aw.y += dy_ * hy; aw.z += dz_ * hz; aw.w += dw_ * hw;
     ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
     float4 o;
@@ -735,12 +744,13 @@ __global__ __launch_bounds__(256) void frameln_act_bwd_pgrad_kernel(FlnParams p,
   for (long long f = f0; f < f1; ++f) {
     const long long g0 = f * p.per_frame + e;
     const float mu = p.mean[f], rs = p.rstd[f];
+    const float fsc = fln_frame_scale(p, seed, f);
     const float4 v = ld4(p.h + g0), d = ld4(dout + g0);
     const float hx = (v.x - mu) * rs, hy = (v.y - mu) * rs, hz = (v.z - mu) * rs, hw = (v.w - mu) * rs;
-    const float dx_ = d.x * fln_scale(p, seed, f, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
-    const float dy_ = d.y * fln_scale(p, seed, f, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
-    const float dz_ = d.z * fln_scale(p, seed, f, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
-    const float dw_ = d.w * fln_scale(p, seed, f, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
+    const float dx_ = d.x * fln_scale(p, seed, fsc, g0 + 0) * gelu_grad_f(hx * ww.x + bb.x);
+    const float dy_ = d.y * fln_scale(p, seed, fsc, g0 + 1) * gelu_grad_f(hy * ww.y + bb.y);
+    const float dz_ = d.z * fln_scale(p, seed, fsc, g0 + 2) * gelu_grad_f(hz * ww.z + bb.z);
+    const float dw_ = d.w * fln_scale(p, seed, fsc, g0 + 3) * gelu_grad_f(hw * ww.w + bb.w);
     aw.x += dx_ * hx; aw.y += dy_ * hy; aw.z += dz_ * hz; aw.w += dw_ * hw;
     ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
     const float gx = dx_ * ww.x, gy = dy_ * ww.y, gz = dz_ * ww.z, gw = dw_ * ww.w;

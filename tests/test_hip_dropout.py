@@ -182,3 +182,36 @@ def test_row_group_keys_follow_the_integer_division(g1, g2):
             ops.set_gemm_precision("f16x3")
         ref = plain * torch.from_numpy(want).to(DEV)[:, None] + res
         assert GC.rel_err(y, ref) < 1e-6, f"{mode}: masked epilogue differs from mask x plain output"
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_mask_statistics(p):
+    """The counter hash behind every mask (csrc/common.h rng_u32: two keyed finalizer rounds per element): keep rate, independence
+    between sites (salts) and steps (seeds), and no lagged structure along a row or down a column of the [R, 512] / [R, 2048]
+    tensors it masks - each within 4.5 sigma of what independent Bernoulli draws give over 2^22 elements."""
+    import numpy as np
+    from npvp_amd import ops
+    dev = torch.device(DEV)
+    n = 1 << 22
+    sig = 1.0 / np.sqrt(n)
+    masks = []
+    for seed in (4242, 4243, 99991):
+        ops.rng.manual_seed(seed, dev)
+        for _ in range(3):
+            d = ops.Drop(p, 0)                                  # a new site: the next salt
+            m = ops.DropRecorder.mask((d, "elem", n), dev)
+            masks.append((m != 0).double().cpu().numpy())
+    for m in masks:
+        assert abs(m.mean() - (1 - p)) < 4.5 * np.sqrt(p * (1 - p)) * sig, f"keep rate {m.mean():.5f} at p = {p}"
+    z = [(m - m.mean()) / m.std() for m in masks]
+    for i in range(len(z)):
+        for j in range(i + 1, len(z)):
+            assert abs((z[i] * z[j]).mean()) < 4.5 * sig, f"masks {i} and {j} are correlated: {(z[i] * z[j]).mean():.2e}"
+    for lag in (1, 2, 3, 4, 8, 64, 512, 2048, 4096, 2048 * 64):
+        for k in (0, 4, 8):
+            r = (z[k][:-lag] * z[k][lag:]).mean()
+            assert abs(r) < 4.5 * sig, f"lag {lag}: autocorrelation {r:.2e}"
+    # counts per row of a [8192, 512] view and per column: binomial variance
+    a = masks[0].reshape(8192, 512)
+    assert 0.9 < a.sum(1).var() / (512 * p * (1 - p)) < 1.1
+    assert 0.75 < a.sum(0).var() / (8192 * p * (1 - p)) < 1.25
