@@ -18,7 +18,7 @@ echo "[2] kernel trace"
 rocprofv3 --kernel-trace -d "$OUT/kt" -o c2 -- $BENCH > "$OUT/bench_c2_profiled.json" 2> "$OUT/kt.err"
 python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2.csv" > /dev/null
 python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2_by_grid.csv" --by-grid > /dev/null
-python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt/*.db | head -1) 3 "$OUT/streams_c2.md" > /dev/null
+python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt/*.db | head -1) 2 "$OUT/streams_c2.md" > /dev/null
 rm -rf "$OUT/kt"
 
 echo "[3] FETCH_SIZE pass"
