@@ -103,11 +103,34 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `python npvp_amd/build.py`). "
                 "npvp_amd has no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH, mode=os.RTLD_NOW)        # resolve every symbol now: a broken build fails here
+        bound = _Bound()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        _lib = L
+            setattr(bound, name, fn)
+        bound._cdll = L
+        # The same entry points through C-API wrappers (npvp_amd/_npvp_fast.so, generated by build.py from SIGNATURES): ctypes spends
+        # ~0.25 us per argument on its prototype machinery - 7 - 8 ms of a host-bound 8-clip step.  Same functions of the same
+        # library, same arguments, same return values; NPVP_FASTCALL=0 keeps ctypes (A/B runs), and so does a missing module.
+        bound._fast = 0
+        if os.environ.get("NPVP_FASTCALL", "1") == "1":
+            try:
+                from . import _npvp_fast as F
+            except ImportError as e:
+                import warnings
+                warnings.warn(f"npvp_amd._npvp_fast is not built ({e}): every call goes through ctypes (same kernels, more host time)")
+            else:
+                for name in SIGNATURES:
+                    f = getattr(F, name, None)
+                    if f is not None:
+                        setattr(bound, name, f)
+                        bound._fast += 1
+        _lib = bound
     return _lib
+
+
+class _Bound:
+    """the bound entry points of libnpvp_hip.so as plain attributes (C-API wrapper where there is one, ctypes function otherwise)"""
 
 
 def check(rc, what):

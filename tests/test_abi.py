@@ -41,6 +41,34 @@ def test_argument_errors_do_not_need_a_gpu(built):
     assert L.npvp_gemm_workspace_bytes(2048, 512, 20480) > 0 and L.npvp_gemm_workspace_bytes(20480, 512, 512) == 0
 
 
+def test_c_api_wrappers_cover_the_abi_and_agree_with_ctypes(built):
+    """npvp_amd/_npvp_fast (generated from _lib.SIGNATURES, built next to the library) wraps every entry point that returns an
+    int / long long; on the host-side argument checks it returns what the ctypes binding returns, it takes ints, None and ctypes
+    pointer objects for pointers, and it raises TypeError on a wrong argument count or type."""
+    import ctypes
+    from npvp_amd import _lib
+    from npvp_amd import _npvp_fast as F
+    L = _lib.lib()
+    raw = L._cdll
+    missing = [n for n in _lib.SIGNATURES if not hasattr(F, n)]
+    assert missing == ["npvp_last_error", "npvp_stream_create_low_priority"], missing       # (char* / pointer returns stay with ctypes)
+    assert L._fast == len(_lib.SIGNATURES) - 2 and L.npvp_gemm_f32 is F.npvp_gemm_f32
+    calls = [("npvp_gemm_f32", (1, 1, 128, 128, 33, None, 36, None, 36, None, 128, None, 0, None, None, None, 0, 0.0, 0, 1, 1, None, 0,
+                                1.0, 0, None, None, 0, None, None, None, None, None, 0.0, 1, 1, 0, None, 0, None)),
+             ("npvp_layernorm_fwd", (None, None, None, None, None, None, 4, 500, 1e-5, 0, None, None)),
+             ("npvp_layernorm_fwd", (ctypes.c_void_p(0), None, None, None, None, None, 4, 500, 1e-5, 0, None, ctypes.c_void_p(0))),
+             ("npvp_gemm_workspace_bytes", (2048, 512, 20480)), ("npvp_gemm_kernel_id", (1, 1, 114688, 512, 512, 6, 1)),
+             ("npvp_gemm_kernel_id", (True, 1, 8192, 512, 512, 6, 0))]
+    for name, args in calls:
+        assert getattr(F, name)(*args) == getattr(raw, name)(*args), name
+    with pytest.raises(TypeError):
+        F.npvp_gemm_kernel_id(1, 1, 512)
+    with pytest.raises(TypeError):
+        F.npvp_gemm_kernel_id(1, 1, "512", 512, 512, 6, 1)
+    with pytest.raises((TypeError, AttributeError)):
+        F.npvp_layernorm_fwd("x", None, None, None, None, None, 4, 500, 1e-5, 0, None, None)
+
+
 def test_no_cpu_fallback():
     import npvp_amd
     with pytest.raises(RuntimeError, match="no CPU fallback"):
