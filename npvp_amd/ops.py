@@ -661,8 +661,11 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     missing slot of A - or of B for a weight gradient - is filled by the stand-alone reduction); c_amax: slot that receives
     the bound of the values stored to `out`.  a_drop: a row-group (DropPath) mask on the rows of A - fp16 kernels only, see
     `masked_grad`."""
-    _chk(A, B, out, bias, aux_in, aux_out, residual, colsum_a)
-    L = lib()
+    # (this wrapper runs for a third of a step's launches: the optional arguments are tested in line instead of through _ptr / _chk,
+    # ~3 us of its ~9 us of interpreter time)
+    for t in (A, B, out, bias, aux_in, aux_out, residual, colsum_a):
+        if t is not None and not (t.is_cuda and t.dtype is torch.float32):
+            _chk(t)
     prec = GEMM_PRECISION if precision is None else precision
     planes = None
     if b_pre is not None:
@@ -683,7 +686,8 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     ws, wsn = (None, 0)
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
-    seed = rng.seed_tensor(A.device) if (drop.on or a_drop.on) else None
+    masked = drop.p > 0.0 or a_drop.p > 0.0
+    seed = rng.seed_tensor(A.device) if masked else None
     if DropRecorder.sites is not None and not replay:
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
@@ -695,12 +699,18 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.npvp_gemm_f32(a_kc, b_kc, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(out), out.stride(0), _ptr(bias), act,
-                          _ptr(aux_in), _ptr(aux_out), _ptr(residual), residual.stride(0) if residual is not None else 0,
-                          drop.p, drop.mode, drop.g1, drop.g2, _ptr(seed), drop.salt, alpha, prec, _ptr(colsum_a),
-                          _ptr(planes), int(accumulate), _ptr(rowstats), _ptr(a_amax), _ptr(b_amax), _ptr(c_amax), _ptr(range_flag),
-                          a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(ws), wsn, _stream()),
-          "npvp_gemm_f32")
+    rc = lib().npvp_gemm_f32(
+        a_kc, b_kc, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), out.stride(0),
+        None if bias is None else bias.data_ptr(), act, None if aux_in is None else aux_in.data_ptr(),
+        None if aux_out is None else aux_out.data_ptr(), None if residual is None else residual.data_ptr(),
+        0 if residual is None else residual.stride(0), drop.p, drop.mode, drop.g1, drop.g2,
+        None if seed is None else seed.data_ptr(), drop.salt, alpha, prec, None if colsum_a is None else colsum_a.data_ptr(),
+        None if planes is None else planes.data_ptr(), 1 if accumulate else 0, None if rowstats is None else rowstats.data_ptr(),
+        None if a_amax is None else a_amax.data_ptr(), None if b_amax is None else b_amax.data_ptr(),
+        None if c_amax is None else c_amax.data_ptr(), None if range_flag is None else range_flag.data_ptr(),
+        a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, None if ws is None else ws.data_ptr(), wsn, _stream())
+    if rc:
+        check(rc, "npvp_gemm_f32")
     if probe:
         e1.record()
         GemmProbe.records.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), ((a_kc, b_kc), kid)))
