@@ -58,7 +58,11 @@ __device__ __forceinline__ bool block_any(bool pred, int* flags, int wave) {
   return __builtin_amdgcn_readfirstlane(any) != 0;
 }
 
-template <int TM, int TN, int WM, int WN, bool ROWSTATS, int MINB = 2>
+// NST = LDS stages.  2: B tile kt+1 is DMA'd during step kt and must have landed at the step's end - fine when a step is long (the
+// 128 x 256 tile: 24 MFMAs per wave and step, two workgroups per CU).  3 (the small tiles, round 4): B tile kt+2 is DMA'd during
+// step kt, i.e. it has two steps to arrive: with 6 - 12 MFMAs per wave and step and one or two workgroups per CU a step was as
+// long as the L2 -> LDS latency of its B pieces (0.42 us per K-step, three quarters of a shard-sized GEMM's loop).
+template <int TM, int TN, int WM, int WN, bool ROWSTATS, int MINB = 2, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams p) {
   constexpr int NW = WM * WN, THREADS = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   constexpr int CPS = BN / 64;                       // 1 KB glds chunks per (term, k-group) slab
   constexpr int NCHUNK = 4 * CPS, CPW = (NCHUNK + NW - 1) / NW;
   constexpr int EPI_BYTES = (4 + NW * EPI_FLOATS + BM) * 4;          // the epilogue's scratch lives in the idle stages
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES];
 
   int tile_m, tile_n;
   tile_of_block_unsplit(p, tile_m, tile_n);
@@ -130,6 +135,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
 #define NPVP_H_WAIT_BUT_NEWEST(...)                                                                        \
   { if constexpr (APASS == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : __VA_ARGS__ :: "memory");     \
     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" : __VA_ARGS__ :: "memory"); }
+  // three stages: everything but what THIS step issued has landed - its CPW LDS-DMA pieces (B tile kt+2) and its APASS loads
+  // (A tile kt+3); vector-memory operations complete in issue order, so B tile kt+1 and A tile kt+2 (issued a step ago) are in
+  // (two tied register operands: the count is %2)
+#define NPVP_H_WAIT_BUT_THIS_STEP(...)                                                                     \
+  asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)" : __VA_ARGS__ : "n"(CPW + APASS) : "memory");
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
   { if (ROWOFF) rm1 = fmaxf(fmaxf(rm1, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));  \
     else rm0 = fmaxf(fmaxf(rm0, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));         \
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1) :: "memory");
   NPVP_H_ASTORE(lds, ea0, 0)
   if constexpr (APASS == 2) NPVP_H_ASTORE(lds, ea1, (BM / 2) * 16)
+  if constexpr (NST == 3) NPVP_H_BLOAD(lds + STAGE, 1)      // (three stages: B tile 1 leaves here, step kt DMAs tile kt + 2)
   NPVP_H_ALOAD(ea0, ea1, 1)
   NPVP_H_ALOAD(eb0, eb1, 2)
   NPVP_H_WAIT_BUT_NEWEST("+v"(ea0), "+v"(ea1))
@@ -176,14 +187,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   // one K-step: MFMAs of tile KT on stage CUR; B tile KT+1 is DMA'd into NXT; A tile KT+1 (register set R, loaded two
   // steps ago) is split and written to NXT, then R is reloaded with A tile KT+3.  RN = the set the NEXT step consumes: the
   // step's closing wait is tied to it so that nothing that reads it can be scheduled above the wait.
-#define NPVP_H_STEP(KT, CUR, NXT, R0, R1, RN0, RN1) NPVP_H_STEP_(KT, CUR, NXT, R0, R1, RN0, RN1, false)
+#define NPVP_H_STEP(KT, CUR, NXT, R0, R1, RN0, RN1) NPVP_H_STEP_(KT, CUR, NXT, NXT, R0, R1, RN0, RN1, false)
+  // three stages: B2 = the stage that receives B tile KT+2
+#define NPVP_H_STEP3(KT, CUR, NXT, B2, R0, R1, RN0, RN1) NPVP_H_STEP_(KT, CUR, NXT, B2, R0, R1, RN0, RN1, false)
   // FIRST: the step's first MFMA per accumulator takes the constant 0 as its C operand (the accumulators are never zeroed: 128
   // v_mov less per wave and tile)
-#define NPVP_H_STEP_(KT, CUR, NXT, R0, R1, RN0, RN1, FIRST)                                                \
+#define NPVP_H_STEP_(KT, CUR, NXT, B2, R0, R1, RN0, RN1, FIRST)                                            \
   {                                                                                                        \
     const char* st_ = lds + (CUR) * STAGE;                                                                 \
     char* nx_ = lds + (NXT) * STAGE;                                                                       \
-    NPVP_H_BLOAD(nx_, (KT) + 1)                                                                            \
+    NPVP_H_BLOAD(lds + (B2) * STAGE, (KT) + (NST - 1))                                                     \
     f16x8 fb_[2][TN];                                                                                      \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                       \
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                    \
@@ -200,21 +213,45 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
       _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[0], fb_[0][j_], acc[i_][j_], 0, 0, 0); \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);       /* every MFMA of the step is issued before the wave parks at the wait */ \
-    NPVP_H_WAIT_BUT_NEWEST("+v"(RN0), "+v"(RN1))                                                           \
+    if constexpr (NST == 3) { NPVP_H_WAIT_BUT_THIS_STEP("+v"(RN0), "+v"(RN1)) }                            \
+    else { NPVP_H_WAIT_BUT_NEWEST("+v"(RN0), "+v"(RN1)) }                                                  \
     __builtin_amdgcn_s_barrier();                                                                          \
   }
 
-  NPVP_H_STEP_(0, 0, 1, ea0, ea1, eb0, eb1, true)
+  if constexpr (NST == 2) {
+  NPVP_H_STEP_(0, 0, 1, 1, ea0, ea1, eb0, eb1, true)
   int kt = 1;
   for (; kt + 1 < nk; kt += 2) {
     NPVP_H_STEP(kt, 1, 0, eb0, eb1, ea0, ea1)
     NPVP_H_STEP(kt + 1, 0, 1, ea0, ea1, eb0, eb1)
   }
   if (kt < nk) NPVP_H_STEP(kt, 1, 0, eb0, eb1, ea0, ea1)
+  } else {
+  // step s: MFMAs on stage s % 3, A tile s+1 -> stage (s+1) % 3, B tile s+2 -> stage (s+2) % 3 (the stage step s-1 multiplied
+  // from: every wave has passed that step's closing barrier); register sets alternate as above: period 6
+  NPVP_H_STEP_(0, 0, 1, 2, ea0, ea1, eb0, eb1, true)
+  int kt = 1;
+  for (; kt + 5 < nk; kt += 6) {
+    NPVP_H_STEP3(kt, 1, 2, 0, eb0, eb1, ea0, ea1)
+    NPVP_H_STEP3(kt + 1, 2, 0, 1, ea0, ea1, eb0, eb1)
+    NPVP_H_STEP3(kt + 2, 0, 1, 2, eb0, eb1, ea0, ea1)
+    NPVP_H_STEP3(kt + 3, 1, 2, 0, ea0, ea1, eb0, eb1)
+    NPVP_H_STEP3(kt + 4, 2, 0, 1, eb0, eb1, ea0, ea1)
+    NPVP_H_STEP3(kt + 5, 0, 1, 2, ea0, ea1, eb0, eb1)
+  }
+  if (kt < nk) NPVP_H_STEP3(kt, 1, 2, 0, eb0, eb1, ea0, ea1)
+  if (kt + 1 < nk) NPVP_H_STEP3(kt + 1, 2, 0, 1, ea0, ea1, eb0, eb1)
+  if (kt + 2 < nk) NPVP_H_STEP3(kt + 2, 0, 1, 2, eb0, eb1, ea0, ea1)
+  if (kt + 3 < nk) NPVP_H_STEP3(kt + 3, 1, 2, 0, ea0, ea1, eb0, eb1)
+  if (kt + 4 < nk) NPVP_H_STEP3(kt + 4, 2, 0, 1, eb0, eb1, ea0, ea1)
+  }
   // (the clamped loads past the last tile.  Both register sets are TIED to the wait: the last two steps' loads are never read,
   //  and a dead asm output may be given a register that the code between the load and this wait uses for something else -
   //  the load then lands in it.  Seen as intermittent wrong tiles once the row guard changed the register allocation.)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1), "+v"(eb0), "+v"(eb1) :: "memory");
+  // (three stages: the last step's clamped B pieces were still in flight at its closing barrier - every wave's must be in before
+  //  any wave turns the stages into the epilogue's scratch or a second pass rewrites stage 0)
+  if constexpr (NST == 3) __builtin_amdgcn_s_barrier();
   };
   run_tile();
   {
@@ -237,6 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
     }
   }
 #undef NPVP_H_STEP
+#undef NPVP_H_STEP3
+#undef NPVP_H_WAIT_BUT_THIS_STEP
 #undef NPVP_H_STEP_
 #undef NPVP_H_BLOAD
 #undef NPVP_H_ASTORE
@@ -570,11 +609,11 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
     if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
   } else if (v == 3 && !p.rowstats) {
-    hipLaunchKernelGGL((gemm_f16_kernel<2, 1, 2, 2, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<2, 1, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
   } else {
     if (v == 3) { p.tiles_n = (p.N + 127) / 128; grid = dim3(p.tiles_m * p.tiles_n); p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n); }
-    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
+    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, true, 2, 3>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
   }
   return true;
 }
