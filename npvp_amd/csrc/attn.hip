@@ -12,17 +12,15 @@
 // work: one wavefront per (group, head); the shipped kernels run every 16x16 product on
 // v_mfma_f32_16x16x4_f32 (exact fp32) with operands taken straight from global memory
 // (attn_*_mfma_kernel) or, for the backward of 17..32 query rows, from tiles staged once in LDS
-// (attn_bwd_staged_kernel); softmax in registers, attention dropout replayed in backward from a counter
-// hash.  The first-generation LDS kernels (attn_fwd_kernel / attn_bwd_kernel) stay reachable through
-// NPVP_ATTN_LDS for A/B runs.  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
+// (attn_bwd_staged1_kernel); softmax in registers, attention dropout replayed in backward from a counter
+// hash.  (The first-generation LDS kernels and the two-orientation staged backward are in the history of this
+// file: removed in round 4.)  Algorithmic bytes: 4*C*4 B per token fwd (q,k,v read + o write).
 #include "common.h"
-#include <cstdlib>
 
 namespace npvp {
 
 constexpr int HD = 64;      // head dim
 constexpr int LDT = 68;     // LDS row stride of a [rows][64] tile (16-B aligned, bank-skewed)
-constexpr int LDP = 33;     // LDS row stride of the [L][S] probability tile
 
 struct AttnParams {
   const float* q; const float* k; const float* v; const float* go;   // go = dO (bwd only)
@@ -38,7 +36,6 @@ struct AttnParams {
   unsigned int drop_thresh; float drop_inv_keep; unsigned int salt;
   const unsigned long long* seed;
   long long total;                // groups * heads
-  int wpb, per_wave_floats;
   float* o_amax; float* dq_amax; float* dk_amax; float* dv_amax;     // nullable amax slots of the outputs (common.h)
 };
 
@@ -70,259 +67,6 @@ __device__ __forceinline__ long long attn_row(const AttnRows& r, int m, int Tn) 
     return r.a + ph * (r.W - r.ws) + m;
   }
   return (r.a * Tn + m) * r.P + r.b;
-}
-
-__device__ __forceinline__ void load_tile(float* dst, const float* src, long long ld, const AttnParams& p, const AttnRows& g,
-                                          int nrows, int Tn, int head, int lane) {
-  for (int idx = lane; idx < nrows * 16; idx += 64) {
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    st4(dst + r * LDT + c4, ld4(src + attn_row(g, r, Tn) * ld + head * HD + c4));
-  }
-}
-__device__ __forceinline__ float store_tile(const float* src, float* dst, long long ld, const AttnParams& p, const AttnRows& g,
-                                            int nrows, int Tn, int head, int lane) {
-  float am = 0.f;
-  for (int idx = lane; idx < nrows * 16; idx += 64) {
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    const float4 v = ld4(src + r * LDT + c4);
-    st4(dst + attn_row(g, r, Tn) * ld + head * HD + c4, v);
-    am = amax4(am, v);
-  }
-  return am;
-}
-
-__device__ __forceinline__ float dot64(const float4* a, const float* b) {
-  float s = 0.f;
-#pragma unroll
-  for (int c4 = 0; c4 < 16; ++c4) {
-    const float4 t = ld4(b + c4 * 4);
-    s += a[c4].x * t.x + a[c4].y * t.y + a[c4].z * t.z + a[c4].w * t.w;
-  }
-  return s;
-}
-
-template <int PARTS>
-__device__ __forceinline__ float parts_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  if (PARTS == 4) v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return v;
-}
-template <int PARTS>
-__device__ __forceinline__ float parts_sum(float v) {
-  v += __shfl_xor(v, 32, 64);
-  if (PARTS == 4) v += __shfl_xor(v, 16, 64);
-  return v;
-}
-
-// PARTS = 4: rows on lanes 0..15 (L,S <= 16), 4 lanes share a row; PARTS = 2: rows on lanes 0..31.
-template <int PARTS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LP = 64 / PARTS, CW = 64 / PARTS, JPL = 32 / PARTS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long wid = (long long)blockIdx.x * p.wpb + wave;
-  const bool active = wid < p.total;
-  if (!active) wid = p.total - 1;          // keep every wave in step for the barriers; stores are skipped
-  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
-  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
-  const int L = p.L, S = p.S;
-  float* Qs = smem + (long long)wave * p.per_wave_floats;
-  float* Ks = Qs + L * LDT;
-  float* Vs = Ks + S * LDT;
-  float* Ps = Vs + S * LDT;
-  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
-
-  load_tile(Qs, p.q, p.ld_q, p, g, L, Tq, head, lane);
-  load_tile(Ks, p.k, p.ld_k, p, g, S, Tk, head, lane);
-  load_tile(Vs, p.v, p.ld_v, p, g, S, Tk, head, lane);
-  __syncthreads();
-
-  const int i = lane % LP, part = lane / LP;
-  const int ic = i < L ? i : L - 1;
-  float4 qv[16];
-#pragma unroll
-  for (int c4 = 0; c4 < 16; ++c4) qv[c4] = ld4(Qs + ic * LDT + c4 * 4);
-
-  float sc[JPL];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    const int j = part + jj * PARTS;
-    float s = -INFINITY;
-    if (j < S) {
-      s = dot64(qv, Ks + j * LDT) * p.scale;
-      if (p.mask_mode == 1 && j == S - 1 && ic < L - 1) s = -INFINITY;
-    }
-    sc[jj] = s;
-    mx = fmaxf(mx, s);
-  }
-  mx = parts_max<PARTS>(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    sc[jj] = (sc[jj] == -INFINITY) ? 0.f : __expf(sc[jj] - mx);
-    sum += sc[jj];
-  }
-  sum = parts_sum<PARTS>(sum);
-  const float inv = 1.f / sum;
-  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    const int j = part + jj * PARTS;
-    if (j < S && i < L) {
-      float pr = sc[jj] * inv;
-      if (p.drop_thresh)
-        pr *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + i) * S + j, p.drop_thresh, p.drop_inv_keep);
-      Ps[i * LDP + j] = pr;
-    }
-  }
-  __syncthreads();
-
-  float4 acc[CW / 4];
-#pragma unroll
-  for (int c4 = 0; c4 < CW / 4; ++c4) acc[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = 0; j < S; ++j) {
-    const float pj = Ps[ic * LDP + j];
-    const float* vr = Vs + j * LDT + part * CW;
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) {
-      const float4 t = ld4(vr + c4 * 4);
-      acc[c4].x += pj * t.x; acc[c4].y += pj * t.y; acc[c4].z += pj * t.z; acc[c4].w += pj * t.w;
-    }
-  }
-  // stage O in the Q tile (every lane has its q row in registers since the first barrier)
-  if (i < L) {
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) st4(Qs + i * LDT + part * CW + c4 * 4, acc[c4]);
-  }
-  __syncthreads();
-  if (active) amax_slot_commit(p.o_amax, store_tile(Qs, p.o, p.ld_o, p, g, L, Tq, head, lane), 0u);
-}
-
-template <int PARTS>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LP = 64 / PARTS, CW = 64 / PARTS, JPL = 32 / PARTS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long wid = (long long)blockIdx.x * p.wpb + wave;
-  const bool active = wid < p.total;
-  if (!active) wid = p.total - 1;
-  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
-  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
-  const int L = p.L, S = p.S;
-  float* Qs = smem + (long long)wave * p.per_wave_floats;
-  float* Ks = Qs + L * LDT;
-  float* Vs = Ks + S * LDT;
-  float* Gs = Vs + S * LDT;          // dO
-  float* Ps = Gs + L * LDT;          // dropped probabilities (what multiplied V in forward)
-  float* Ds = Ps + L * LDP;          // dS * scale
-  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
-
-  load_tile(Qs, p.q, p.ld_q, p, g, L, Tq, head, lane);
-  load_tile(Ks, p.k, p.ld_k, p, g, S, Tk, head, lane);
-  load_tile(Vs, p.v, p.ld_v, p, g, S, Tk, head, lane);
-  load_tile(Gs, p.go, p.ld_o, p, g, L, Tq, head, lane);
-  __syncthreads();
-
-  const int i = lane % LP, part = lane / LP;
-  const int ic = i < L ? i : L - 1;
-  float sc[JPL], dp[JPL];
-  {
-    float4 qv[16], gv[16];
-#pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) { qv[c4] = ld4(Qs + ic * LDT + c4 * 4); gv[c4] = ld4(Gs + ic * LDT + c4 * 4); }
-#pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) {
-      const int j = part + jj * PARTS;
-      float s = -INFINITY, d = 0.f;
-      if (j < S) {
-        s = dot64(qv, Ks + j * LDT) * p.scale;
-        if (p.mask_mode == 1 && j == S - 1 && ic < L - 1) s = -INFINITY;
-        d = dot64(gv, Vs + j * LDT);
-      }
-      sc[jj] = s; dp[jj] = d;
-    }
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) mx = fmaxf(mx, sc[jj]);
-  mx = parts_max<PARTS>(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    sc[jj] = (sc[jj] == -INFINITY) ? 0.f : __expf(sc[jj] - mx);
-    sum += sc[jj];
-  }
-  sum = parts_sum<PARTS>(sum);
-  const float inv = 1.f / sum;
-  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
-  float rs = 0.f;            // sum_j dP_ij * p_ij
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    const int j = part + jj * PARTS;
-    const float pr = sc[jj] * inv;
-    float m = 1.f;
-    if (p.drop_thresh && j < S)
-      m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + ic) * S + j, p.drop_thresh, p.drop_inv_keep);
-    dp[jj] *= m;             // dP = dP_dropped * mask_scale
-    sc[jj] = pr;
-    rs += dp[jj] * pr;
-    if (j < S && i < L) Ps[i * LDP + j] = pr * m;
-  }
-  rs = parts_sum<PARTS>(rs);
-#pragma unroll
-  for (int jj = 0; jj < JPL; ++jj) {
-    const int j = part + jj * PARTS;
-    if (j < S && i < L) Ds[i * LDP + j] = sc[jj] * (dp[jj] - rs) * p.scale;
-  }
-  __syncthreads();
-
-  float4 aq[CW / 4], ak[CW / 4], av[CW / 4];
-#pragma unroll
-  for (int c4 = 0; c4 < CW / 4; ++c4) {
-    aq[c4] = make_float4(0.f, 0.f, 0.f, 0.f); ak[c4] = aq[c4]; av[c4] = aq[c4];
-  }
-  // dQ[i] = sum_j dS[i][j] K[j]
-  for (int j = 0; j < S; ++j) {
-    const float d = Ds[ic * LDP + j];
-    const float* kr = Ks + j * LDT + part * CW;
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) {
-      const float4 t = ld4(kr + c4 * 4);
-      aq[c4].x += d * t.x; aq[c4].y += d * t.y; aq[c4].z += d * t.z; aq[c4].w += d * t.w;
-    }
-  }
-  // dK[j] = sum_i dS[i][j] Q[i];  dV[j] = sum_i Pd[i][j] dO[i]   (this lane's row index is a key index here)
-  const int jc = i < S ? i : S - 1;
-  for (int ii = 0; ii < L; ++ii) {
-    const float d = Ds[ii * LDP + jc], pd = Ps[ii * LDP + jc];
-    const float* qr = Qs + ii * LDT + part * CW;
-    const float* gr = Gs + ii * LDT + part * CW;
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) {
-      const float4 t = ld4(qr + c4 * 4), u = ld4(gr + c4 * 4);
-      ak[c4].x += d * t.x; ak[c4].y += d * t.y; ak[c4].z += d * t.z; ak[c4].w += d * t.w;
-      av[c4].x += pd * u.x; av[c4].y += pd * u.y; av[c4].z += pd * u.z; av[c4].w += pd * u.w;
-    }
-  }
-  __syncthreads();           // all reads of Qs/Ks/Vs/Gs are done: reuse them as output staging
-  if (i < L) {
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) st4(Qs + i * LDT + part * CW + c4 * 4, aq[c4]);
-  }
-  if (i < S) {
-#pragma unroll
-    for (int c4 = 0; c4 < CW / 4; ++c4) {
-      st4(Ks + i * LDT + part * CW + c4 * 4, ak[c4]);
-      st4(Vs + i * LDT + part * CW + c4 * 4, av[c4]);
-    }
-  }
-  __syncthreads();
-  if (active) {
-    amax_slot_commit(p.dq_amax, store_tile(Qs, p.dq, p.ld_dq, p, g, L, Tq, head, lane), 0u);
-    amax_slot_commit(p.dk_amax, store_tile(Ks, p.dk, p.ld_dk, p, g, S, Tk, head, lane), 0u);
-    amax_slot_commit(p.dv_amax, store_tile(Vs, p.dv, p.ld_dv, p, g, S, Tk, head, lane), 0u);
-  }
 }
 
 // =====================================================================================================
@@ -620,136 +364,9 @@ __device__ __forceinline__ void attn_lds_g(AttnTileG& t, const float* xs, int nr
   for (int i = 0; i < 4; ++i) t.v[i] = ld4(xs + min(16 * blk + 4 * c + i, nrows - 1) * LDT + 4 * n);
 }
 
-template <int NQ, int NK>
-__global__ __launch_bounds__(64) void attn_bwd_staged_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x, n = lane & 15, c = lane >> 4;
-  const long long wid = blockIdx.x;
-  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
-  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
-  const int L = p.L, S = p.S;
-  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
-  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
-  float* Qs = smem;
-  float* Gs = Qs + L * LDT;
-  float* Ks = Gs + L * LDT;
-  AttnTileR vr[NK];
-  {
-    float4 sq[4 * NQ], sg[4 * NQ], sk[4 * NK];
-    attn_stage_load<4 * NK>(sk, p.k, p.ld_k, p, g, S, Tk, head, lane);
-    attn_stage_load<4 * NQ>(sq, p.q, p.ld_q, p, g, L, Tq, head, lane);
-    attn_stage_load<4 * NQ>(sg, p.go, p.ld_o, p, g, L, Tq, head, lane);
-#pragma unroll
-    for (int kb = 0; kb < NK; ++kb) attn_load_r(vr[kb], p.v, p.ld_v, p, g, S, Tk, head, n, c, kb);
-    __builtin_amdgcn_sched_barrier(0);      // every global load of this wave is in flight before the first wait
-    attn_stage_store<4 * NK>(Ks, sk, S, lane);
-    attn_stage_store<4 * NQ>(Qs, sq, L, lane);
-    attn_stage_store<4 * NQ>(Gs, sg, L, lane);
-  }
-  __syncthreads();                          // one wave per workgroup: orders the LDS writes before the reads below
-  // ---- orientation A per query block: softmax statistics of query 16qb+n (kept for phase B), dQ
-  float mxs[NQ], invs[NQ], rss[NQ], am_q = 0.f, am_k = 0.f, am_v = 0.f;
-  const unsigned int pk_q = amax_peek_wave(p.dq_amax), pk_k = amax_peek_wave(p.dk_amax), pk_v = amax_peek_wave(p.dv_amax);
-#pragma unroll
-  for (int qb = 0; qb < NQ; ++qb) {
-    AttnTileR qr, gr;
-    attn_lds_r(qr, Qs, L, n, c, qb);
-    attn_lds_r(gr, Gs, L, n, c, qb);
-    const int q = 16 * qb + n, qn = min(q, L - 1);
-    float sc[NK][4], dp[NK][4], mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NK; ++kb) {
-      AttnTileR kr;
-      attn_lds_r(kr, Ks, S, n, c, kb);
-      const f32x4_t sa = attn_mm_d(kr, qr), da = attn_mm_d(vr[kb], gr);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * kb + 4 * c + i;
-        float s = sa[i] * p.scale;
-        if (j >= S || (p.mask_mode == 1 && j == S - 1 && q < L - 1)) s = -INFINITY;
-        sc[kb][i] = s; dp[kb][i] = da[i]; mx = fmaxf(mx, s);
-      }
-    }
-    mx = quad_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NK; ++kb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { sc[kb][i] = (sc[kb][i] == -INFINITY) ? 0.f : __expf(sc[kb][i] - mx); sum += sc[kb][i]; }
-    sum = quad_sum(sum);
-    const float inv = 1.f / sum;
-    float rs = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NK; ++kb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * kb + 4 * c + i;
-        float m = 1.f;
-        if (p.drop_thresh && j < S)
-          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + qn) * S + j, p.drop_thresh, p.drop_inv_keep);
-        sc[kb][i] *= inv;
-        dp[kb][i] *= m;
-        rs += dp[kb][i] * sc[kb][i];
-      }
-    rs = quad_sum(rs);
-    mxs[qb] = mx; invs[qb] = inv; rss[qb] = rs;
-    f32x4_t dq[4];
-    attn_zero(dq);
-#pragma unroll
-    for (int kb = 0; kb < NK; ++kb) {
-      float ds[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ds[i] = sc[kb][i] * (dp[kb][i] - rs) * p.scale;
-      AttnTileG kg;
-      attn_lds_g(kg, Ks, S, n, c, kb);
-      attn_mm_rows(dq, ds, kg);                                  // dQ[q][d] += sum_j dS[q][j] K[j][d]
-    }
-    attn_store_d(dq, p.dq, p.ld_dq, p, g, L, Tq, head, n, c, qb, am_q);
-  }
-  // ---- orientation B per key block: register i <-> (query 16qb + 4c+i, key 16kb + n): dK, dV
-#pragma unroll
-  for (int kb = 0; kb < NK; ++kb) {
-    f32x4_t dv[4], dk[4];
-    attn_zero(dv); attn_zero(dk);
-    const int key = 16 * kb + n;
-    AttnTileR kr;
-    attn_lds_r(kr, Ks, S, n, c, kb);
-#pragma unroll
-    for (int qb = 0; qb < NQ; ++qb) {
-      AttnTileR qr, gr;
-      attn_lds_r(qr, Qs, L, n, c, qb);
-      attn_lds_r(gr, Gs, L, n, c, qb);
-      const f32x4_t sb = attn_mm_d(qr, kr), db = attn_mm_d(gr, vr[kb]);
-      float pd[4], ds[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ql = 4 * c + i, q = 16 * qb + ql;             // statistics of query q live in lane ql of block qb
-        const float mxq = __shfl(mxs[qb], ql, 64), invq = __shfl(invs[qb], ql, 64), rsq = __shfl(rss[qb], ql, 64);
-        const bool dead = key >= S || q >= L || (p.mask_mode == 1 && key == S - 1 && q < L - 1);
-        const float pr = dead ? 0.f : __expf(sb[i] * p.scale - mxq) * invq;
-        float m = 1.f;
-        if (p.drop_thresh && !dead)
-          m = drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + key, p.drop_thresh, p.drop_inv_keep);
-        pd[i] = pr * m;
-        ds[i] = pr * (db[i] * m - rsq) * p.scale;
-      }
-      AttnTileG gg, qg;
-      attn_lds_g(gg, Gs, L, n, c, qb);
-      attn_lds_g(qg, Qs, L, n, c, qb);
-      attn_mm_rows(dv, pd, gg);                                  // dV[j][d] += sum_q Pd[q][j] dO[q][d]
-      attn_mm_rows(dk, ds, qg);                                  // dK[j][d] += sum_q dS[q][j] Q[q][d]
-    }
-    attn_store_d(dv, p.dv, p.ld_dv, p, g, S, Tk, head, n, c, kb, am_v);
-    attn_store_d(dk, p.dk, p.ld_dk, p, g, S, Tk, head, n, c, kb, am_k);
-  }
-  amax_slot_commit(p.dq_amax, am_q, pk_q);
-  amax_slot_commit(p.dk_amax, am_k, pk_k);
-  amax_slot_commit(p.dv_amax, am_v, pk_v);
-}
-
-// ---- the same backward with ONE score orientation.  attn_bwd_staged_kernel evaluates S = Q K^T and dP = dO V^T twice - once
-// with queries on lanes (softmax statistics, dQ), once with keys on lanes (dK, dV) - because the row-reducing products
-// P^T dO and dS^T Q want P / dS with the QUERY index in registers.  Here they are evaluated once, in the query-on-lanes
+// ---- ONE score orientation.  The row-reducing products P^T dO and dS^T Q want P / dS with the QUERY index in registers, the
+// softmax statistics and dQ want queries on lanes: the first staged kernel (round 2, removed in round 4) therefore evaluated
+// S = Q K^T and dP = dO V^T twice.  Here they are evaluated once, in the query-on-lanes
 // orientation, and the two 16 x 16 blocks a (query block, key block) pair produces - P (dropout mask applied) and dS - are
 // transposed through a 2 x 16 x 20-float LDS scratch (1 ds_write_b128 + 4 ds_read_b32 per lane and matrix).  448 -> 320
 // MFMAs per wave, and the softmax exponentials and the dropout hash - half of the staged kernel's VALU work - are evaluated
@@ -891,14 +508,7 @@ static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int fram
   // the kernels resolve (group, head) and token rows in 32-bit arithmetic (AttnRows)
   const long long rows = mode == 0 ? (long long)frames_or_N * P : (long long)frames_or_N * P * (Tq > Tk ? Tq : Tk);
   if (p.total >= (1ll << 31) || rows >= (1ll << 31)) { npvp_set_error("attn: too many token rows / (group, head) pairs for one launch"); return NPVP_ERR_ARG; }
-  int pw = (p.L + 2 * p.S) * LDT + p.L * LDP;
-  if (bwd) pw += p.L * LDT + p.L * LDP;
-  pw = (pw + 3) & ~3;
-  p.per_wave_floats = pw;
-  int wpb = (64 * 1024) / (pw * 4);
-  if (wpb > 4) wpb = 4;
-  if (wpb < 1) { npvp_set_error("attn: LDS budget exceeded"); return NPVP_ERR_ARG; }
-  p.wpb = wpb;
+  (void)bwd;
   return NPVP_OK;
 }
 
@@ -918,19 +528,12 @@ extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, lon
   NPVP_CHECK_ARG(dim0 > 0, "attn: empty batch");
   NPVP_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0, "attn: row strides must be multiples of 4");
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o;
-  const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
-  const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
-  const int L = p.L > p.S ? p.L : p.S;
-  static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;       // keep the LDS kernels reachable for A/B runs
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
-  if (!use_lds) {
-    if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
-    else if (nq == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
-    else if (nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
-  } else if (L <= 16) hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+  else if (nq == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+  else if (nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
+  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -949,31 +552,16 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
                      ld_dv % 4 == 0, "attn_bwd: row strides must be multiples of 4");
   p.q = q; p.k = k; p.v = v; p.go = go; p.dq = dq; p.dk = dk; p.dv = dv;
   p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o; p.ld_dq = ld_dq; p.ld_dk = ld_dk; p.ld_dv = ld_dv;
-  const unsigned blocks = (unsigned)((p.total + p.wpb - 1) / p.wpb);
-  const size_t lds = (size_t)p.wpb * p.per_wave_floats * 4;
-  const int L = p.L > p.S ? p.L : p.S;
-  static const bool use_lds = getenv("NPVP_ATTN_LDS") != nullptr;
-  static const bool staged = getenv("NPVP_ATTN_BWD_UNSTAGED") == nullptr;   // A/B switch for the measurement in DESIGN.md
-  static const bool two_orient = getenv("NPVP_ATTN_BWD_TWO_ORIENT") != nullptr;   // A/B: the staged kernel with both score orientations
-  const size_t staged_lds = (size_t)(2 * p.L + p.S) * LDT * sizeof(float);
-  const size_t staged1_lds = staged_lds + 2 * 16 * LDX * sizeof(float);
-  NPVP_CHECK_ARG(p.total < (1ll << 31), "attn_bwd: too many (group, head) pairs for one launch");
+  const size_t staged1_lds = (size_t)(2 * p.L + p.S) * LDT * sizeof(float) + 2 * 16 * LDX * sizeof(float);
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
-  if (!use_lds) {
-    if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
-    else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
-    else if (!staged && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
-    else if (!staged) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
-    // measured at the c2 size (tools/attn_bench.py, one / two orientations): T = 28: 718 / 734 us, 28 x 2: 254 / 295 us, but
-    // T = 18: 678 / 580 us (a second query block with 2 live rows pays the full transposition and the dV / dK products):
-    // the one-orientation kernel takes one key block, or query sequences that fill most of the second block
-    else if ((two_orient || (nk == 2 && p.L < 25)) && nk == 1) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
-    else if (two_orient || (nk == 2 && p.L < 25)) hipLaunchKernelGGL((attn_bwd_staged_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged_lds, stream, p);
-    else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
-    else hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
-  } else if (L <= 16) hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3(blocks), dim3(64 * p.wpb), lds, stream, p);
+  // up to 16 query rows: operands straight from global memory; 17 .. 32: Q / dO / K staged once in LDS, one score orientation
+  // (tools/attn_bench.py at the c2 size: T = 28 478 us, 28 x 2 205 us, T = 18 293 us - the two-orientation kernel that used to
+  // take 17 .. 24 rows needed 382 us there once the address arithmetic was out of the way, and is gone)
+  if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+  else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+  else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
+  else hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -890,8 +890,7 @@ extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* b
                                 float* mean, float* rstd, int N, int T, int per_frame, float eps, float* amax, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse: bad shape");
   const int frames = N * T;
-  static const int one_pass = !(getenv("NPVP_POSFUSE_ONE_PASS") && atoi(getenv("NPVP_POSFUSE_ONE_PASS")) == 0);      // A/B switch
-  if (one_pass && per_frame == 32768) {          // 8 x 8 x 512: the frame lives in the block's registers
+  if (per_frame == 32768) {          // 8 x 8 x 512: the frame lives in the block's registers
     hipLaunchKernelGGL((posfuse_fwd_frame_kernel<8>), dim3(frames), dim3(1024), 0, stream, x, add, beta, gamma, y, mean, rstd, T,
                        eps, amax);
     NPVP_CHECK_LAUNCH();
@@ -923,8 +922,7 @@ extern "C" int npvp_ln_posfuse_fwd(const float* x, const float* lw, const float*
 // 1 when npvp_posfuse_bwd computes d beta / d gamma inside its apply pass (the batch loop in the thread): enough (t, e) work to
 // fill the device, or so few samples that the launches saved matter more
 extern "C" int npvp_posfuse_bwd_fused(int N, int T, int per_frame) {
-  static const int off = getenv("NPVP_POSFUSE_FUSED") && atoi(getenv("NPVP_POSFUSE_FUSED")) == 0;      // A/B switch
-  if (off || per_frame % 1024 != 0) return 0;
+  if (per_frame % 1024 != 0) return 0;
   const long long blocks = (long long)T * (per_frame / 1024);
   return (blocks >= 128 || N <= 16) ? 1 : 0;
 }
@@ -1013,11 +1011,8 @@ extern "C" int npvp_frameln_act_fwd_parts(const float* h, const float* part, int
 
 // frame chunks (grid.y) of the one-pass backward: 32 x 128 = 4096 workgroups.  With 8 (1024 workgroups, each walking 224 frames
 // at c2) the kernel was as fast stand-alone (921 vs 923 us for statistics + apply) but lost CU slots to the co-resident
-// weight-gradient GEMM: c2 step 342.7 -> 338.3 ms (three A/B pairs on one box; 64 chunks: 338.1).  NPVP_FLN_CHUNKS overrides.
-static int fln_chunks(int frames) {
-  static const int want = getenv("NPVP_FLN_CHUNKS") ? atoi(getenv("NPVP_FLN_CHUNKS")) : 32;
-  return frames < want ? frames : want;
-}
+// weight-gradient GEMM: c2 step 342.7 -> 338.3 ms (three A/B pairs on one box; 64 chunks: 338.1).
+static int fln_chunks(int frames) { return frames < 32 ? frames : 32; }
 
 extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
   return ((long long)frames * 2 * FLN_PARTS + (long long)fln_chunks(frames) * 2 * per_frame) * 4;

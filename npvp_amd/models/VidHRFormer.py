@@ -7,7 +7,6 @@ tensor); the reference's permute/reshape/rearrange round trips (ref :34,50,94,11
 are epilogues of the GEMM / frame-LN kernels, never separate passes.
 """
 import copy
-import os
 
 import torch
 import torch.nn as nn
@@ -228,8 +227,7 @@ def _stock_fuser(pos_fuser):
     """the sub-layer nodes call the positional-fuse kernels directly: only for the stock PosFeatFuser('layer') (an 'instance'
     fuser or a user's own module goes through the per-kernel autograd path below)"""
     from .submodules import PosFeatFuser
-    return (type(pos_fuser) is PosFeatFuser and pos_fuser.norm_type == 'layer'
-            and os.environ.get("NPVP_SUBLAYER_NODES", "1") == "1")
+    return type(pos_fuser) is PosFeatFuser and pos_fuser.norm_type == 'layer'
 
 
 def _get_clones(module, N):

@@ -252,8 +252,8 @@ class WeightPlanes:
     table keyed by device address alone: a freed weight's address is reused by the next model's weights.  The key holds the
     view's device address too: re-pointing `p.data` (FlatBuffers does) makes a NEW entry, and entries whose storage is no longer
     the owner's are dropped.
-    NPVP_PRESPLIT=0 disables it (every GEMM then splits both operands on the fly, bf16x6 128 x 128 kernel only)."""
-    enabled = os.environ.get("NPVP_PRESPLIT", "1") == "1"
+    `enabled = False` (tests) makes every GEMM split both operands on the fly (bf16x6 128 x 128 kernel only)."""
+    enabled = True
     _owners = []            # weak references to tensors that carry a `_npvp_planes` store
     _tables = None          # [(fmt, device table, amax table or None, [entries])] - rebuilt when `_dirty`
     _dirty = True
@@ -470,7 +470,7 @@ class GradSink:
     a 160 ms c1 step).  The flat buffer is zeroed once per step by FlatBuffers.zero_grad(), so every contribution is a
     plain accumulate.  `listener(param)` is called after each contribution (npvp_amd.dp.GradSync counts them to know
     when a bucket is complete)."""
-    enabled = os.environ.get("NPVP_GRAD_SINK", "1") == "1"
+    enabled = True
     listener = None
 
     @classmethod
@@ -564,20 +564,19 @@ class WgradStream:
         key = (dev.type, dev.index)
         if key not in cls._side:
             st = None
-            if os.environ.get("NPVP_WGRAD_PRIORITY", "low") == "low":
-                # lowest device priority (torch only offers normal / high): critical-path kernels are dispatched first
-                with torch.cuda.device(dev):
-                    h = lib().npvp_stream_create_low_priority(None, None)
-                if h:
-                    st = torch.cuda.ExternalStream(h, device=dev)
+            # lowest device priority (torch only offers normal / high): critical-path kernels are dispatched first
+            with torch.cuda.device(dev):
+                h = lib().npvp_stream_create_low_priority(None, None)
+            if h:
+                st = torch.cuda.ExternalStream(h, device=dev)
             cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return cls._side[key]
 
     in_flush = False         # inside flush(): the current stream is the gradient stream (WgradChain defers reductions there)
     _held, _held_bytes = [], 0
-    HOLD_BYTES = int(os.environ.get("NPVP_WGRAD_HOLD_MB", "2048")) << 20
+    HOLD_BYTES = 2048 << 20
     _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
-    BATCH = max(1, int(os.environ.get("NPVP_WGRAD_BATCH", "16")))
+    BATCH = 16
 
     @classmethod
     def run(cls, fn, *keep_alive, wrote=None, urgent=False):
@@ -796,8 +795,8 @@ class WgradChain:
     a weight gradient accumulated in place on the gradient stream leaves its `splits` partial slabs in a workspace and a 64-byte
     job; the NEXT weight-gradient launch on that stream does the sum with extra workgroups (no launch of its own: 110 of the 170
     reduction launches of an 8-clip step; HBM-bound work beside MFMA-bound work), WgradStream.join() runs the last one.  Same
-    summation order as the stand-alone reduction, so results are bit-identical.  NPVP_WGRAD_CHAIN=0: one reduction launch each."""
-    enabled = os.environ.get("NPVP_WGRAD_CHAIN", "1") == "1"
+    summation order as the stand-alone reduction, so results are bit-identical.  `enabled = False`: one reduction launch each."""
+    enabled = True
     _pending = {}          # raw stream -> (job bytes, workspace, dw, db): kept alive until the job has been handed on
     _ok, _wsb = {}, {}
 
@@ -1878,7 +1877,7 @@ def _raw_posfuse_fwd(x, add, beta, gamma, N, T):
     return tag_amax(y, slot), st
 
 
-LN_POSFUSE_ONE_KERNEL = os.environ.get("NPVP_LN_POSFUSE", "1") == "1"          # A/B switch
+LN_POSFUSE_ONE_KERNEL = True          # (False: the two-kernel route, kept for the op tests)
 
 
 def _raw_ln_posfuse_fwd(x2, lw, lb, eps, add, beta, gamma, N, T):

@@ -1,6 +1,6 @@
 """Attention cores at the c2 size (BAIR B=64: 64 clips x 64 pixels x 8 heads), forward and backward, against their
 ALGORITHMIC bytes (q, k, v [, dO] read once, o [dq, dk, dv] written once, fp32) - SURVEY 8(d).
-Usage: python tools/attn_bench.py [--clips 64]        (NPVP_ATTN_BWD_UNSTAGED=1 for the register-only backward)"""
+Usage: python tools/attn_bench.py [--clips 64]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """PosFeatFuser backward at a workload's decoder size: the fused apply (batch loop in the thread, d beta / d gamma in registers)
-against the apply + two reductions (NPVP_POSFUSE_FUSED=0).  python tools/posfuse_bench.py [N] [T]"""
+against the apply + two reductions (the library's route for shapes npvp_posfuse_bwd_fused declines).  python tools/posfuse_bench.py [N] [T]"""
 import os
 import sys
 import torch
