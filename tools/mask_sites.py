@@ -1,6 +1,6 @@
 """Which GEMM launches of a training step carry a dropout / DropPath mask in their epilogue (or on the rows of A), and which sites
 mask a gradient copy (npvp_drop_apply): counts per (kind, shape) over ONE step of a BASELINE workload.
-Usage: python tools/mask_sites.py [c2|c4s|...] [clips]"""
+Usage: python tools/mask_sites.py [c2|c4|... a bench.py workload key] [clips]"""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
