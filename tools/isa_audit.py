@@ -19,7 +19,9 @@ files = args or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def demangle(names):
-    out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+    if not names:
+        return []
+    out = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.split("\n")
     return [re.sub(r"\(.*", "", o) for o in out]
 
 
