@@ -69,6 +69,47 @@ def test_c_api_wrappers_cover_the_abi_and_agree_with_ctypes(built):
         F.npvp_layernorm_fwd("x", None, None, None, None, None, 4, 500, 1e-5, 0, None, None)
 
 
+def test_row_group_magic_division_is_exact(tmp_path):
+    """csrc/common.h div_magic: the multiply-shift the kernels use for (row / g1) % g2 of a DropPath site - host-compiled from the
+    header itself and compared with `/` for every numerator class that matters (dense low range, multiples of d and their
+    predecessors, the top of the 31-bit range, random pairs)."""
+    import subprocess
+    src = tmp_path / "div_magic_check.hip"
+    src.write_text(r'''#include "common.h"
+#include <cstdio>
+#include <cstdlib>
+int main() {
+  unsigned ds[] = {1, 2, 3, 5, 7, 13, 16, 28, 64, 100, 448, 1792, 1793, 4096, 65535, 65536, 65537, 114688, 1000003, 1u << 30, (1u << 30) + 1, 0x7fffffffu};
+  for (unsigned d : ds) {
+    unsigned m; int s;
+    npvp::div_magic(d, m, s);
+    for (unsigned long long n = 0; n < (1ull << 31); n += (n < 70000 ? 1 : 9973))
+      if ((unsigned)((n * m) >> s) != (unsigned)(n / d)) { printf("BAD d=%u n=%llu\n", d, n); return 1; }
+    for (unsigned long long k = 1; k < 3000; ++k)
+      for (int o = -1; o <= 0; ++o) { unsigned long long x = k * d + o; if (x < (1ull << 31) && (unsigned)((x * m) >> s) != (unsigned)(x / d)) { printf("BAD d=%u n=%llu\n", d, x); return 1; } }
+    unsigned long long x = (1ull << 31) - 1;
+    if ((unsigned)((x * m) >> s) != (unsigned)(x / d)) { printf("BAD top d=%u\n", d); return 1; }
+  }
+  srand(1);
+  for (int t = 0; t < 300000; ++t) {
+    unsigned d = (unsigned)(rand() % 2000000) + 1, m; int s;
+    npvp::div_magic(d, m, s);
+    unsigned long long n = (((unsigned long long)rand() << 16) ^ rand()) & 0x7fffffff;
+    if ((unsigned)((n * m) >> s) != (unsigned)(n / d)) { printf("BAD rnd d=%u n=%llu\n", d, n); return 1; }
+  }
+  printf("ok\n");
+  return 0;
+}
+''')
+    exe = tmp_path / "div_magic_check"
+    csrc = os.path.join(ROOT, "npvp_amd", "csrc")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{csrc}", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_no_cpu_fallback():
     import npvp_amd
     with pytest.raises(RuntimeError, match="no CPU fallback"):
