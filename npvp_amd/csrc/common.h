@@ -181,13 +181,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // Counter-based RNG for dropout masks: stateless, so backward replays the mask of
 // forward from (seed, salt, element index).  `seed` lives in device memory so that
 // a captured HIP graph sees a fresh value on every replay.
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bu;
   h ^= h >> 13; h *= 0xc2b2ae35u;
   h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t salt, uint64_t idx) {
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t salt, uint64_t idx) {
   // Two keys from (seed, salt) - wave-uniform values: the compiler keeps them on the scalar unit and hoists them out of loops -
   // then TWO finalizer rounds per element with a key entering before each (until round 4: three rounds, six 32-bit multiplies
   // per element - quarter-rate instructions; in the fused MlpDWBN backward, which is VALU bound, the mask was a third of the

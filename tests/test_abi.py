@@ -110,6 +110,63 @@ int main() {
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_mask_hash_statistics_on_the_host(tmp_path):
+    """csrc/common.h rng_u32 (two keyed finalizer rounds per element), host-compiled from the header: on sequential and strided
+    counters (row stride 512 / 2048, column walks) the top, middle and low byte are uniform (chi-square per degree of freedom
+    within 0.75 .. 1.3), keep rates at p = 0.1 / 0.5 sit within 4.5 sigma, masks of different sites (salts) and steps (seeds) and
+    lagged copies of one mask are uncorrelated within 4.5 sigma.  (tests/test_hip_dropout.py::test_mask_statistics repeats the
+    mask part through the kernels.)"""
+    import subprocess
+    import numpy as np
+    src = tmp_path / "hash_dump.hip"
+    src.write_text(r'''#include "common.h"
+#include <cstdio>
+#include <cstdlib>
+// usage: prog seed salt stride offset count  -> count raw 32-bit hashes of idx = offset + i * stride on stdout
+int main(int argc, char** argv) {
+  const unsigned long long seed = strtoull(argv[1], nullptr, 0), stride = strtoull(argv[3], nullptr, 0), off = strtoull(argv[4], nullptr, 0);
+  const unsigned int salt = (unsigned int)strtoul(argv[2], nullptr, 0);
+  const long n = atol(argv[5]);
+  unsigned int* buf = (unsigned int*)malloc(n * 4);
+  for (long i = 0; i < n; ++i) buf[i] = npvp::rng_u32(seed, salt, off + (unsigned long long)i * stride);
+  fwrite(buf, 4, n, stdout);
+  return 0;
+}
+''')
+    exe = tmp_path / "hash_dump"
+    csrc = os.path.join(ROOT, "npvp_amd", "csrc")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{csrc}", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n = 1 << 21
+
+    def hashes(seed, salt, stride=1, off=0):
+        out = subprocess.run([str(exe), str(seed), str(salt), str(stride), str(off), str(n)], capture_output=True, timeout=120)
+        assert out.returncode == 0
+        return np.frombuffer(out.stdout, dtype=np.uint32)
+
+    seed0 = 0x1E3779B97F4A7C15
+    for stride, off in [(1, 0), (512, 3), (2048, 5), (4, 1), (114688, 0)]:
+        for k in range(2):
+            h = hashes(seed0 + k * 0x632BE5AB, 3 + k, stride, off)
+            for shift in (24, 12, 0):
+                c = np.bincount((h >> shift) & 255, minlength=256)
+                chi = float(((c - n / 256.0) ** 2 / (n / 256.0)).sum() / 255.0)
+                assert 0.75 < chi < 1.3, f"stride {stride}, byte at bit {shift}: chi-square / dof {chi:.2f}"
+    sig = 1.0 / np.sqrt(n)
+    for p in (0.1, 0.5):
+        thr = int(p * 4294967296.0)
+        masks = [(hashes(seed0 + k * 0x632BE5AB, s) >= thr).astype(np.float64) for k in range(3) for s in (1, 2, 50)]
+        for m in masks:
+            assert abs(m.mean() - (1 - p)) < 4.5 * np.sqrt(p * (1 - p)) * sig
+        z = [(m - m.mean()) / m.std() for m in masks]
+        for i in range(len(z)):
+            for j in range(i + 1, len(z)):
+                assert abs((z[i] * z[j]).mean()) < 4.5 * sig, f"p={p}: masks {i}, {j} correlate"
+        for lag in (1, 2, 3, 4, 8, 64, 512, 2048, 4096):
+            assert abs((z[0][:-lag] * z[0][lag:]).mean()) < 4.5 * sig, f"p={p}: lag {lag}"
+
+
 def test_no_cpu_fallback():
     import npvp_amd
     with pytest.raises(RuntimeError, match="no CPU fallback"):
