@@ -167,6 +167,17 @@ int main(int argc, char** argv) {
             assert abs((z[0][:-lag] * z[0][lag:]).mean()) < 4.5 * sig, f"p={p}: lag {lag}"
 
 
+def test_window_row_quotient_in_fp32_is_exact():
+    """csrc/attn.hip attn_row takes m / ws for the rows of a local window as (int)((m + 0.5f) * (1.f / ws)) - restated here in numpy
+    float32: exact for every window side up to 32 and every row index a window of that side can have (and far beyond)."""
+    import numpy as np
+    m = np.arange(0, 4096, dtype=np.int64)
+    for ws in range(1, 33):
+        inv = np.float32(1.0) / np.float32(ws)
+        q = ((m.astype(np.float32) + np.float32(0.5)) * inv).astype(np.int64)
+        assert np.array_equal(q, m // ws), f"ws = {ws}: first mismatch at m = {int(m[q != m // ws][0])}"
+
+
 def test_no_cpu_fallback():
     import npvp_amd
     with pytest.raises(RuntimeError, match="no CPU fallback"):
