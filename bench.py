@@ -86,6 +86,23 @@ def host_cores():
     return max(1, min(cores, 16))
 
 
+def host_cpu():
+    """(model name, cores this process may run on): the host-bound secondaries depend on it (c0 / c3s / c4s differ by 25 % from box to box)"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return model, cores
+
+
 def cpu_baseline_one(cfg_file, To, Tp, clips, steps, cores):
     import oracle
     from npvp_amd.trainer import load_config
@@ -127,10 +144,13 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None):
+def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None, mode="eager"):
     """Build the workload's model / optimiser / synthetic batch, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict.  world = 1 inside a multi-rank job =
-    a SOLO run of the calling rank (no collectives, no barrier): the one-GPU denominators of `scaling_dp`."""
+    a SOLO run of the calling rank (no collectives, no barrier): the one-GPU denominators of `scaling_dp`.
+    mode: "eager" (two streams, host enqueues every launch), "graph" (the step captured single-stream into ONE HIP graph and replayed:
+    no host in the loop) or "auto" = whichever of the two is faster in a short timed trial after the warm-up - only tried when the eager
+    step is plausibly host bound (host enqueue time >= 60 % of the step), single process, predictor flavour.  The record says which."""
     import npvp_amd
     from npvp_amd import dp, ops
     from npvp_amd.trainer import load_config, cosine_warm_restarts_lr
@@ -174,13 +194,53 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
         return npvp_amd.predictor_train_step(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"],
                                              sync=False, grad_sync=gsync)
 
-    if args.graph:
-        assert world == 1 and not full, "--graph: single process, predictor-only flavour"
-        probe = False
+    eager_step = step
+    lr_at = lambda i: cosine_warm_restarts_lr(P["predictor_lr"], P["scheduler_eta_min"], P["scheduler_T0"], i / iters_per_epoch)
+
+    def graphed():
         opt.set_lr(P["predictor_lr"])
-        gstep = npvp_amd.GraphedTrainStep(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"])
-        log(f"[{key}] step captured into a HIP graph")
-        step = lambda i: gstep(lr=cosine_warm_restarts_lr(P["predictor_lr"], P["scheduler_eta_min"], P["scheduler_T0"], i / iters_per_epoch))
+        two = os.environ.get("NPVP_GRAPH_STREAMS", "1") == "2"      # experiment: the gradient stream inside the capture
+        gs = npvp_amd.GraphedTrainStep(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"], single_stream=not two)
+        log(f"[{key}] step captured into a HIP graph ({'two streams' if two else 'single stream'}, {gs.launches} library launches)")
+        return gs, (lambda i: gs(lr=lr_at(i)))
+
+    def trial(fn, n=4):
+        """-> (ms per step, fastest host enqueue ms) over n steps after one untimed step"""
+        fn(0)
+        torch.cuda.synchronize()
+        t0, hmin = time.perf_counter(), 1e9
+        for i in range(n):
+            ti = time.perf_counter()
+            fn(1 + i)
+            hmin = min(hmin, time.perf_counter() - ti)
+        torch.cuda.synchronize()
+        return 1000.0 * (time.perf_counter() - t0) / n, 1000.0 * hmin
+
+    if args.graph:
+        mode = "graph"
+    used, trial_ms = "eager", None
+    if mode in ("graph", "auto") and (dp_on or full):
+        assert mode == "auto", "--graph: single process, predictor-only flavour"
+        mode = "eager"
+    if mode == "graph":
+        probe = False
+        gstep, step = graphed()
+        used = "graph"
+    elif mode == "auto":
+        for i in range(warmup):
+            eager_step(i)
+        e_ms, e_host = trial(eager_step)
+        trial_ms = {"eager": round(e_ms, 2), "eager_host": round(e_host, 2)}
+        if e_host >= 0.6 * e_ms:
+            gstep, gfn = graphed()
+            g_ms, _ = trial(gfn)
+            trial_ms["graph"] = round(g_ms, 2)
+            if g_ms < e_ms:
+                step, used, probe = gfn, "graph", False
+            else:
+                del gstep, gfn
+                gc.collect()
+        log(f"[{key}] mode trial: {trial_ms} -> {used}")
 
     def fence():
         torch.cuda.synchronize()
@@ -202,8 +262,9 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     if probe:
         # forward / dgrad kernels of either arithmetic (ids 2, 4, 5, 7: the candidates for the dominant kernel); --probe-all also
         # brackets the weight-gradient and small-shape launches (their event pairs cost the step ~1 %)
-        ops.GemmProbe.arm(None if args.probe_all else {2, 4, 5, 7})
+        ops.GemmProbe.arm(None if args.probe_all else {2, 4, 5, 7, 8})
     fence()
+    L0 = npvp_amd._lib.lib().npvp_launch_count()
     t0 = time.perf_counter()
     host_max, host_min, host_all = 0.0, 1e9, []
     for i in range(steps):
@@ -215,6 +276,9 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     # GPU); the others also contain the time the launch queue makes the host wait for the GPU once it is a few thousand
     # launches ahead, i.e. they converge to the GPU's step time and say nothing about the host.
     t_host = host_min * steps
+    launches = (npvp_amd._lib.lib().npvp_launch_count() - L0) / steps       # (library launches; a replayed graph enqueues none: taken from its capture)
+    if used == "graph":
+        launches = gstep.launches
     fence()
     dt = time.perf_counter() - t0
     ops.GemmProbe.disarm()
@@ -232,7 +296,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
         f"{frames / (ms * 1e-3):.0f} frames/s; host ms per step: " + " ".join(f"{1000.0 * h:.0f}" for h in host_all))
 
     roof, roof_hbm = None, None
-    if probe and not args.graph:
+    if probe and used == "eager":
         # the HBM-bound family, timed in two EXTRA steps after the clock stopped (the event packets fence their neighbours)
         ops.HbmProbe.armed, ops.HbmProbe.records = True, []
         for i in range(2):
@@ -273,7 +337,7 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
                 # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r03_hbm_traffic_<key>.*
                 ent = json.load(open(tj)).get("pooled", {}).get(kname)
                 traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
-            f16 = kid in (5, 6, 7)
+            f16 = kid in (5, 6, 7, 8)
             mfmas = 1 if kid == 0 else (3 if f16 else 6)
             roof = {"bound": "mfma", "kernel": kname + " (forward + dgrad launches)",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -284,6 +348,15 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
                     "note": f"achieved = algorithmic 2MNK flops / event-pair time of every launch; {mfmas} MFMAs per fp32-grade product, "
                             f"so frac <= 1/{mfmas} by construction",
                     "whole_step_tflops": round(flops_step / (ms * 1e-3) / 1e12, 2)}
+            # BASELINE's "MFMA util %" as a MEASURED step-level number: sum of SQ_VALU_MFMA_BUSY_CYCLES over every dispatch of the timed
+            # steps / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8), from a committed rocprofv3 --pmc pass over this very command
+            # (tools/profile_r05.sh, tools/rocpd_mfma_util.py; counter passes cannot run inside the timed process - like `traffic`)
+            for tag, wk in (("mfma_util_step", key), ("mfma_util_step_c2p", "c2p")):
+                uj = os.path.join(ROOT, "profiles", f"r05_mfma_util_{wk}.json")
+                if os.path.exists(uj) and not full and (tag == "mfma_util_step" or key == "c2"):
+                    u = json.load(open(uj))
+                    roof[tag] = {"value": u["mfma_util_step"], "vs_unprofiled_step": u.get("util_vs_unprofiled_step"),
+                                 "clock_ghz": u["effective_clock_ghz"], "source": f"profiles/r05_mfma_util_{wk}.md"}
 
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
     log(f"[{key}] peak device memory {peak_gb:.1f} GiB")
@@ -291,13 +364,14 @@ def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None
     events = ops.RangeGuard.poll(dev)           # weight-gradient launches that met a feature 2^18 below its tensor's bound (0 expected)
     res = {"key": key, "name": name, "B": B, "To": To, "Tp": Tp, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "peak_gb": peak_gb,
            "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "roof_hbm": roof_hbm, "steps": steps,
-           "warmup": warmup, "range_events": events}
+           "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms}
     if gsync is not None:
         res["dp"] = {"backend": dist.get_backend(), "buckets": len(gsync.buckets), "last_bucket_mb": round((gsync.buckets[0]["hi"] - gsync.buckets[0]["lo"]) * 4 / 2 ** 20, 1),
                      "allreduces_launched": gsync.launched, "exposed_allreduce_ms_per_step": round(gsync.exposed_ms(), 3)}
         log(f"[{key}] data parallel: " + json.dumps(res["dp"]))
         gsync.remove()
-    del model, opt, gsync, past, fut, out, step
+    del model, opt, gsync, past, fut, out, step, eager_step
+    gstep = gfn = None
     gc.collect()
     # The cache goes back to the driver: with c2's ~100 GB of cached blocks in the allocator the host-bound 8-clip workloads that
     # follow ran 10 % slower (every torch.empty walks a long free list).  The multi-second stalls this once caused inside a LATER
@@ -323,6 +397,8 @@ def main():
                          "flavour, pixels -> frozen encoder -> predictor -> frozen decoder -> image L1 (AE = stock PyTorch-ROCm)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (N=1, predictor flavour; no per-kernel probe: roofline null)")
+    ap.add_argument("--mode", default="eager", choices=["eager", "graph", "auto"],
+                    help="primary workload: eager (default; the roofline probes need it), graph, or auto = the faster of the two in a short trial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--probe-all", action="store_true", help="bracket every GEMM launch with events, not only forward / dgrad")
@@ -339,27 +415,33 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    main_res = run_workload(args.workload, args.steps, args.warmup, args, rank, world, dev, probe=not args.no_probe)
+    main_res = run_workload(args.workload, args.steps, args.warmup, args, rank, world, dev, probe=not args.no_probe, mode=args.mode)
 
-    secondary, detail, scaling_dp = {}, {}, None
+    secondary, detail, scaling_dp, modes = {}, {}, None, {}
     if not args.no_secondary and args.workload == "c2" and not args.graph and args.flavour == "predictor":
         sec_steps, sec_warm = max(4, args.steps // 2), min(3, args.warmup) or 1
 
         def note(name, r, flav=None, solo=False):
-            secondary[name] = [round(r["ms"], 2), round(r["frames_per_s"], 1)]
+            # [ms per step, frames/s, host enqueue ms per step, library launches per step, whole-step TFLOP/s]
+            secondary[name] = [round(r["ms"], 2), round(r["frames_per_s"], 1), round(r["host_ms"], 1), round(r["launches"]),
+                               round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 1)]
+            if r["mode"] != "eager":
+                modes[name] = r["mode"]
             detail[name] = {"workload": r["name"] + (" - FULL step from pixels through the frozen autoencoder" if flav == "full" else
                                                      " - predictor-only step") + (" [rank 0 alone]" if solo else ""),
                             "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"], "frames_per_s": round(r["frames_per_s"], 2),
                             "ms_per_step": round(r["ms"], 3), "steps": r["steps"], "warmup": r["warmup"],
                             "whole_step_tflops_per_gpu": round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 2),
-                            "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1)}
+                            "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1),
+                            "launches_per_step": round(r["launches"]), "mode": r["mode"], "mode_trial_ms": r["mode_trial"]}
             log(f"secondary {name}: " + json.dumps(detail[name]))
 
         if world == 1:
             # (key in the JSON, workload, flavour): every BASELINE configuration the primary line does not cover
             for name, k, flav in [("c2p", "c2p", None), ("c1", "c1", None), ("c0", "c0", None), ("c3s", "c3", None), ("c4s", "c4", None),
                                   ("c3full", "c3full", None), ("c4full", "c4full", None), ("full64", "c1", "full"), ("full128", "c4", "full")]:
-                note(name, run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False, flavour=flav), flav)
+                note(name, run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False, flavour=flav,
+                                        mode="eager" if flav == "full" else "auto"), flav)
             # what N GPUs can at best make of these shards: N x shard / whole batch on one GPU (the step is not linear in the clip
             # count - an 8-clip shard is bound by kernel count)
             scaling_dp = {"c3_on_4_upper_bound": round(4 * secondary["c3s"][1] / secondary["c3full"][1], 2),
@@ -397,14 +479,16 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"{r['name']} " + ("predictor-only train step (features in HBM)" if args.flavour == "predictor"
                                                          else "FULL train step from pixels (frozen AE)")
-                                      + (" [HIP-graph replay]" if args.graph else "") + f", {r['B']} clips/GPU, To={r['To']}, "
+                                      + (" [HIP-graph replay]" if r["mode"] == "graph" else "") + f", {r['B']} clips/GPU, To={r['To']}, "
                                       f"Tp={r['Tp']}, dropout=drop_path=0.1, AdamW+clip",
                           "global_batch": world * r["B"], "frames_per_clip": r["To"] + r["Tp"], "parallelism": f"dp{world}",
                           "algorithmic_tflop_per_step_per_gpu": round(r["flops_step"] / 1e12, 3), "final_loss": round(r["loss"], 6),
-                          "host_enqueue_ms_per_step": round(r["host_ms"], 2), "peak_device_memory_gib": round(r["peak_gb"], 1),
-                          "f16_range_events": r["range_events"]},
-               "roofline": r["roof"], "roofline_hbm": r["roof_hbm"], "secondary": secondary or None, "scaling_dp": scaling_dp,
-               "dp": r.get("dp")}
+                          "host_enqueue_ms_per_step": round(r["host_ms"], 2), "launches_per_step": round(r["launches"]),
+                          "peak_device_memory_gib": round(r["peak_gb"], 1), "f16_range_events": r["range_events"]},
+               "roofline": r["roof"], "roofline_hbm": r["roof_hbm"], "secondary": secondary or None,
+               "secondary_fields": ["ms_per_step", "frames_per_s", "host_enqueue_ms", "library_launches_per_step", "whole_step_tflops"] if secondary else None,
+               "secondary_mode": modes or None, "scaling_dp": scaling_dp, "dp": r.get("dp"),
+               "host": dict(zip(("cpu", "cores"), host_cpu()))}
         if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")
             res["cpu_baseline"] = cpu_baseline(args.workload)

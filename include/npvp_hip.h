@@ -8,7 +8,8 @@
  * Conventions (all entry points)
  *   - plain pointers + sizes, fp32, row-major, no torch types; every pointer is DEVICE memory
  *     owned and allocated by the caller (including workspaces and saved-for-backward tensors);
- *   - the library never allocates, frees, synchronises or keeps global mutable state; all work
+ *   - the library never allocates, frees, synchronises or keeps global mutable state (but a launch counter and the
+ *     thread-local error string); all work
  *     is enqueued on `stream` (a hipStream_t), so calls are graph-capturable and re-entrant;
  *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 workspace);
  *     npvp_last_error() gives the thread-local message; nothing throws;
@@ -36,6 +37,9 @@ typedef void* npvp_stream_t; /* hipStream_t */
 
 int npvp_version(void);
 const char* npvp_last_error(void);
+/* Diagnostics: kernels this library has launched in this process so far (one relaxed atomic add per launch).  bench.py reads it
+ * around a step so that its record says how many launches a step is. */
+long long npvp_launch_count(void);
 /* A stream of the lowest priority the device offers, for work nothing on the critical path waits for (the in-place
  * weight-gradient writes); least / greatest receive the device's priority range (nullable). */
 void* npvp_stream_create_low_priority(int* least, int* greatest);
@@ -139,6 +143,27 @@ int npvp_wgrad_f16_chained(int M, int N, int K, const float* dy, long long lda, 
                            const unsigned long long* seed, const void* prev_job, void* my_job, void* workspace,
                            long long ws_bytes, npvp_stream_t stream);
 int npvp_splitk_reduce_job(const void* job, npvp_stream_t stream);
+/* n job records (64 bytes each, back to back in HOST memory at `jobs`) in ceil(n / 32) launches; two records of one launch must not
+ * name the same `out`. */
+int npvp_splitk_reduce_multi(const void* jobs, int n, npvp_stream_t stream);
+/* The backward of ONE linear layer y = x w^T (+ b) as ONE launch (precision 6): dx[R,K] = epilogue((adrop mask) dy[R,N] w[N,K]) and
+ * dw[N,K] += dy^T x, db[N] += column sums of dy.  Both GEMMs read dy and nothing of each other; on the 8-clip shards of the
+ * data-parallel configurations each of them alone leaves half the chip idle (256 workgroups), together they fill it - and a step
+ * captured single-stream into a HIP graph (no gradient stream to overlap them) keeps the overlap inside the launch.  Arguments:
+ * the dgrad half as npvp_gemm_f32(a_kc = 1, b_kc = 0, M = R, N = K, K = N) takes them - w_planes_d / w_amax = the weight's D planes
+ * and slot (npvp_split_weight_f16), act 0 / 3 / 4 with aux_in [R][ldx], the dropout REPLAY of a forward site, residual, dx_amax
+ * (nullable) - and the weight-gradient half as npvp_wgrad_f16_chained takes them (always accumulating; its split-K reduction is
+ * handed on in my_job, the previous launch's comes in prev_job; npvp_splitk_reduce_job runs the last one).
+ * npvp_linear_bwd_f16_takes(R, N, K): 1 when the pair is taken - a small-tile dgrad (fewer than 512 tiles of 128 x 256) and a
+ * chainable weight gradient (R >= 4096); everything else stays two launches. */
+int npvp_linear_bwd_f16_takes(int R, int N, int K);
+int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long long ldy, const float* dy_amax, const void* w_planes_d,
+                        const float* w_amax, float* dx, long long ldx, int act, const float* aux_in, const float* residual,
+                        long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2, unsigned int drop_salt, float* dx_amax,
+                        const float* x, long long ldxx, const float* x_amax, float* dw, long long ldw, float* db,
+                        unsigned int* range_flag, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
+                        const unsigned long long* seed, const void* prev_job, void* my_job, void* workspace, long long ws_bytes,
+                        npvp_stream_t stream);
 /* w [N][K] -> the fp16 planes of precision 6: F[2 terms][K/8][N][8 over k], D[2 terms][N/8][K][8 over n] (2*N*K fp16 each,
  * either may be null), scaled by the power of two of w's amax, which is (re)computed into amax_slot (zeroed here first).
  * npvp_split_weights_f16: the same for `count` views in three stream operations; desc is a DEVICE array of records of eight
@@ -163,6 +188,18 @@ int npvp_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
 /* second stage of npvp_layernorm_bwd(accumulate = 2), on a stream of the caller's choice (the gradient stream) */
 int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate,
                               npvp_stream_t stream);
+
+/* Deferred parameter-gradient reductions.  The second stages above (npvp_layernorm_bwd_reduce, npvp_frameln_act_bwd_reduce,
+ * npvp_mlpdw_mid_bwd_reduce_into) each sum a set of partial rows into a gradient slice nobody reads before the optimiser: ~150
+ * small launches per backward pass.  The *_reduce_job forms take the same arguments and, instead of launching, write a 48-byte job
+ * record to HOST memory at `job`; npvp_sum_rows_multi runs n such records (back to back at `jobs`) with ceil(n / 40) launches, the
+ * records travelling in the kernels' argument blocks (nothing to upload or keep alive; graph-capturable).  Same per-column
+ * summation scheme as the single launches, fixed order.  The workspaces must stay alive until npvp_sum_rows_multi has been
+ * enqueued behind their producers (same stream, or a stream ordered after it). */
+int npvp_layernorm_bwd_reduce_job(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate, void* job);
+int npvp_frameln_act_bwd_reduce_job(const void* workspace, float* dw, float* db, int frames, int per_frame, int accumulate, void* job);
+int npvp_mlpdw_mid_bwd_reduce_job(const void* workspace, float* gw, float* gb, int frames, int Ch, void* job);
+int npvp_sum_rows_multi(const void* jobs, int n, npvp_stream_t stream);
 
 /* The decoder's final LayerNorm + ReLU writing the reference's (N,T,C,H,W) tensor directly (ref/models/VidHRFormer.py:150-159:
  * norm, relu_, permute(0,1,4,2,3)).  P must be 64, C 256 or 512; mean / rstd per token row as npvp_layernorm_fwd writes them, so

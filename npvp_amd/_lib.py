@@ -13,6 +13,7 @@ c_int, c_ll, c_f, c_u, c_p = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 SIGNATURES = {
     "npvp_version": (c_int, []),
     "npvp_last_error": (ctypes.c_char_p, []),
+    "npvp_launch_count": (c_ll, []),
     "npvp_stream_create_low_priority": (c_p, [c_p, c_p]),
     "npvp_stream_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
@@ -26,6 +27,10 @@ SIGNATURES = {
     "npvp_wgrad_f16_chained": (c_int, [c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p, c_p, c_f, c_int, c_int,
                                        c_u, c_p, c_p, c_p, c_p, c_ll, c_p]),
     "npvp_splitk_reduce_job": (c_int, [c_p, c_p]),
+    "npvp_splitk_reduce_multi": (c_int, [c_p, c_int, c_p]),
+    "npvp_linear_bwd_f16_takes": (c_int, [c_int, c_int, c_int]),
+    "npvp_linear_bwd_f16": (c_int, [c_int, c_int, c_int, c_p, c_ll, c_p, c_p, c_p, c_p, c_ll, c_int, c_p, c_p, c_ll, c_f, c_int, c_int, c_int,
+                                    c_u, c_p, c_p, c_ll, c_p, c_p, c_ll, c_p, c_p, c_f, c_int, c_int, c_u, c_p, c_p, c_p, c_p, c_ll, c_p]),
     "npvp_split_weight_f16": (c_int, [c_p, c_ll, c_int, c_int, c_p, c_p, c_p, c_p]),
     "npvp_split_weights_f16": (c_int, [c_p, c_int, c_p, c_ll, c_p]),
     "npvp_frame_stats_finalize": (c_int, [c_p, c_int, c_f, c_p, c_p, c_int, c_f, c_p]),
@@ -35,6 +40,10 @@ SIGNATURES = {
     "npvp_layernorm_bwd_workspace_bytes": (c_ll, [c_ll, c_int]),
     "npvp_layernorm_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_int, c_int, c_p, c_int, c_p, c_p, c_ll, c_p]),
     "npvp_layernorm_bwd_reduce": (c_int, [c_p, c_p, c_p, c_ll, c_int, c_int, c_p]),
+    "npvp_layernorm_bwd_reduce_job": (c_int, [c_p, c_p, c_p, c_ll, c_int, c_int, c_p]),
+    "npvp_frameln_act_bwd_reduce_job": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
+    "npvp_mlpdw_mid_bwd_reduce_job": (c_int, [c_p, c_p, c_p, c_int, c_int, c_p]),
+    "npvp_sum_rows_multi": (c_int, [c_p, c_int, c_p]),
     "npvp_layernorm_nchw_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_int, c_p]),
     "npvp_frameln_act_bwd_reduce": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_frame_stats": (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_f, c_p]),

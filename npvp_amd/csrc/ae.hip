@@ -69,8 +69,8 @@ extern "C" int npvp_bias_act(const float* x, const float* bias, const float* res
   NPVP_CHECK_ARG(layout == 1 || inner == C, "bias_act: layout 0 needs inner == C");
   NPVP_CHECK_ARG(act >= 0 && act <= 3, "bias_act: act in 0..3");
   const bool vec = inner % 4 == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, dim3(ae_blocks(outer * inner / 4)), dim3(256), 0, stream, x, bias, residual, out, outer, inner, C, layout, act);
-  else hipLaunchKernelGGL(bias_act_kernel<false>, dim3(ae_blocks(outer * inner)), dim3(256), 0, stream, x, bias, residual, out, outer, inner, C, layout, act);
+  if (vec) NPVP_LAUNCH(bias_act_kernel<true>, dim3(ae_blocks(outer * inner / 4)), dim3(256), 0, stream, x, bias, residual, out, outer, inner, C, layout, act);
+  else NPVP_LAUNCH(bias_act_kernel<false>, dim3(ae_blocks(outer * inner)), dim3(256), 0, stream, x, bias, residual, out, outer, inner, C, layout, act);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -78,7 +78,7 @@ extern "C" int npvp_bias_act(const float* x, const float* bias, const float* res
 extern "C" int npvp_act_bwd(const float* g, const float* y, float* dx, long long n, int act, hipStream_t stream) {
   NPVP_CHECK_ARG(g && y && dx && n > 0, "act_bwd: empty problem");
   NPVP_CHECK_ARG(act >= 0 && act <= 3, "act_bwd: act in 0..3");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ae_blocks(n)), dim3(256), 0, stream, g, y, dx, n, act);
+  NPVP_LAUNCH(act_bwd_kernel, dim3(ae_blocks(n)), dim3(256), 0, stream, g, y, dx, n, act);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -11,6 +11,10 @@ extern "C" void npvp_set_error(const char* msg) {
 extern "C" const char* npvp_last_error(void) { return g_err; }
 extern "C" int npvp_version(void) { return 100; }
 
+// kernels launched by this library in this process so far (every launch site is an NPVP_LAUNCH, common.h)
+namespace npvp { long long g_launches = 0; }
+extern "C" long long npvp_launch_count(void) { return __atomic_load_n(&npvp::g_launches, __ATOMIC_RELAXED); }
+
 // A HIP stream of the LOWEST priority the device offers (PyTorch only hands out normal / high).  The gradient stream
 // (npvp_amd.ops.WgradStream) is created with it so that, whenever CUs free up, the kernels of the critical
 // forward/backward chain are dispatched before the queued weight-gradient workgroups.  *least / *greatest receive the

@@ -530,10 +530,10 @@ extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, lon
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o;
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
-  if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
-  else if (nq == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
-  else if (nk == 1) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
-  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
+  if (nq == 1 && nk == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+  else if (nq == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+  else if (nk == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
+  else NPVP_LAUNCH((attn_fwd_mfma_kernel<2, 2>), mg, mb, 0, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -558,10 +558,10 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   // up to 16 query rows: operands straight from global memory; 17 .. 32: Q / dO / K staged once in LDS, one score orientation
   // (tools/attn_bench.py at the c2 size: T = 28 478 us, 28 x 2 205 us, T = 18 293 us - the two-orientation kernel that used to
   // take 17 .. 24 rows needed 382 us there once the address arithmetic was out of the way, and is gone)
-  if (nq == 1 && nk == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
-  else if (nq == 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
-  else if (nk == 1) hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
-  else hipLaunchKernelGGL((attn_bwd_staged1_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
+  if (nq == 1 && nk == 1) NPVP_LAUNCH((attn_bwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
+  else if (nq == 1) NPVP_LAUNCH((attn_bwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
+  else if (nk == 1) NPVP_LAUNCH((attn_bwd_staged1_kernel<2, 1>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
+  else NPVP_LAUNCH((attn_bwd_staged1_kernel<2, 2>), dim3((unsigned)p.total), dim3(64), staged1_lds, stream, p);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -11,6 +11,16 @@
 // host side: record the last error string (thread local), see api.hip
 extern "C" void npvp_set_error(const char* msg);
 
+// diagnostics: every kernel this library launches goes through NPVP_LAUNCH, which counts it (npvp_launch_count, api.hip; one
+// relaxed atomic add per launch).  bench.py reads the counter around a step to put `launches_per_step` into its record.
+extern "C" long long npvp_launch_count(void);
+namespace npvp { extern long long g_launches; }
+#define NPVP_LAUNCH(...)                                                    \
+  do {                                                                      \
+    __atomic_fetch_add(&npvp::g_launches, 1ll, __ATOMIC_RELAXED);           \
+    hipLaunchKernelGGL(__VA_ARGS__);                                        \
+  } while (0)
+
 #define NPVP_CHECK_ARG(cond, msg)                    \
   do {                                               \
     if (!(cond)) {                                   \

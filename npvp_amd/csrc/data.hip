@@ -40,9 +40,9 @@ extern "C" int npvp_u8hwc_to_f32chw(const void* src, float* dst, long long frame
   }
   const int HW = H * W;
   const dim3 grid((HW + 255) / 256, (unsigned)frames), block(256);
-  if (C == 1) hipLaunchKernelGGL(u8hwc_to_f32chw_kernel<1>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
-  else if (C == 3) hipLaunchKernelGGL(u8hwc_to_f32chw_kernel<3>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
-  else hipLaunchKernelGGL(u8hwc_to_f32chw_kernel<4>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
+  if (C == 1) NPVP_LAUNCH(u8hwc_to_f32chw_kernel<1>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
+  else if (C == 3) NPVP_LAUNCH(u8hwc_to_f32chw_kernel<3>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
+  else NPVP_LAUNCH(u8hwc_to_f32chw_kernel<4>, grid, block, 0, stream, (const uint8_t*)src, dst, HW, a);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -164,7 +164,7 @@ extern "C" int npvp_drop_apply(const float* x, float* out, long long rows, int n
   NPVP_CHECK_ARG(rows > 0 && ncols % 4 == 0, "drop_apply: bad shape");
   NPVP_CHECK_ARG(p > 0.f && p < 1.f && seed, "drop_apply: needs 0 < p < 1 and a device seed");
   const DropSpec d = make_drop_spec(p, salt, mode, g1, g2);
-  hipLaunchKernelGGL(drop_apply_kernel, dim3(ew_blocks(rows * (ncols / 4), 256)), dim3(256), 0, stream, x, out, rows, ncols,
+  NPVP_LAUNCH(drop_apply_kernel, dim3(ew_blocks(rows * (ncols / 4), 256)), dim3(256), 0, stream, x, out, rows, ncols,
                      d, seed, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -172,7 +172,7 @@ extern "C" int npvp_drop_apply(const float* x, float* out, long long rows, int n
 
 extern "C" int npvp_transpose(const float* in, float* out, int batch, int R, int C, hipStream_t stream) {
   NPVP_CHECK_ARG(batch > 0 && R > 0 && C > 0 && batch <= 65535, "transpose: bad shape");
-  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, stream, in, out, R, C);
+  NPVP_LAUNCH(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, stream, in, out, R, C);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -203,21 +203,21 @@ __global__ void dwtb_build_kernel(const float* __restrict__ w, const float* __re
 
 extern "C" int npvp_dwtb_build(const float* w, const float* b, float* wtb, int C, hipStream_t stream) {
   NPVP_CHECK_ARG(C > 0 && w && wtb, "dwtb_build: bad arguments");
-  hipLaunchKernelGGL(dwtb_build_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, w, b, wtb, C);
+  NPVP_LAUNCH(dwtb_build_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, w, b, wtb, C);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
 
 extern "C" int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, hipStream_t stream) {
   NPVP_CHECK_ARG(C > 0 && dwtb && gw && gb, "dwtb_accumulate: bad arguments");
-  hipLaunchKernelGGL(dwtb_accumulate_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, dwtb, gw, gb, C);
+  NPVP_LAUNCH(dwtb_accumulate_kernel, dim3((10 * C + 255) / 256), dim3(256), 0, stream, dwtb, gw, gb, C);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
 
 int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
   NPVP_CHECK_ARG(A > 0 && B > 0 && Cc > 0 && Cc % 4 == 0, "reduce_mid: bad shape");
-  hipLaunchKernelGGL(reduce_mid_kernel, dim3(ew_blocks((long long)A * Cc / 4, 256)), dim3(256), 0, stream, in, out, A, B, Cc,
+  NPVP_LAUNCH(reduce_mid_kernel, dim3(ew_blocks((long long)A * Cc / 4, 256)), dim3(256), 0, stream, in, out, A, B, Cc,
                      scale);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -229,7 +229,7 @@ extern "C" int npvp_reduce_mid(const float* in, float* out, int A, int B, long l
 
 extern "C" int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
   NPVP_CHECK_ARG(A > 0 && B > 0 && Cc > 0 && Cc % 4 == 0, "broadcast_mid: bad shape");
-  hipLaunchKernelGGL(broadcast_mid_kernel, dim3(ew_blocks((long long)A * B * Cc / 4, 256)), dim3(256), 0, stream, in, out, A,
+  NPVP_LAUNCH(broadcast_mid_kernel, dim3(ew_blocks((long long)A * B * Cc / 4, 256)), dim3(256), 0, stream, in, out, A,
                      B, Cc, scale);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -246,7 +246,7 @@ extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, 
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_colsum_workspace_bytes(rows, N), "colsum: workspace too small");
   const int chunks = colsum_chunks(rows);
   const int rpc = (int)((rows + chunks - 1) / chunks), nchunks = (int)((rows + rpc - 1) / rpc);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 4 + 255) / 256, nchunks), dim3(256), 0, stream, x, (float*)workspace,
+  NPVP_LAUNCH(colsum_partial_kernel, dim3((N / 4 + 255) / 256, nchunks), dim3(256), 0, stream, x, (float*)workspace,
                      rows, N, ld, rpc);
   NPVP_CHECK_LAUNCH();
   const int rc = launch_sum_rows((const float*)workspace, out, nchunks, N, N, stream, accumulate);
@@ -260,9 +260,9 @@ extern "C" int npvp_grad_norm_clip(const float* g, long long n, float max_norm, 
   NPVP_CHECK_ARG(n > 0 && ((uintptr_t)g % 16) == 0, "grad_norm_clip: bad buffer");
   NPVP_CHECK_ARG(workspace && ws_bytes >= 1024 * 4, "grad_norm_clip: workspace too small");
   long long nb = (n / 4 + 255) / 256; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, (float*)workspace);
+  NPVP_LAUNCH(sumsq_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, (float*)workspace);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, (int)nb, max_norm, out2);
+  NPVP_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, (int)nb, max_norm, out2);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -271,7 +271,7 @@ extern "C" int npvp_adamw_step(float* p, float* g, float* m, float* v, long long
                                float beta2, float eps, float weight_decay, const float* clip, long long clip_begin,
                                long long clip_end, int write_back_grad, hipStream_t stream) {
   NPVP_CHECK_ARG(n > 0 && hyper, "adamw: bad arguments");
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps,
+  NPVP_LAUNCH(adamw_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps,
                      weight_decay, clip, clip_begin, clip_end, write_back_grad);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;

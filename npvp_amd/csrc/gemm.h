@@ -302,8 +302,7 @@ __device__ __forceinline__ void epilogue_rowstats_block(const GemmParams& p, con
 // reused from its L2 across the tile columns - but then the XCD needs ALL of B resident, and the weights of the
 // 512<->2048 layers do not fit next to the streaming A panels.  colgroups = G > 1: XCD x owns column group x % G (a B
 // slice that stays L2 resident) and row group x / G; A panels are then read by G XCDs.  Placement only changes speed.
-__device__ __forceinline__ void tile_of_block_unsplit(const GemmParams& p, int& tile_m, int& tile_n) {
-  const int nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void tile_of_block_unsplit(const GemmParams& p, const int nwg, const int bid, int& tile_m, int& tile_n) {
   const int xcd = bid & 7, loc = bid >> 3;
   if (p.colgroups > 1) {
     const int G = p.colgroups, tn_g = p.tiles_n / G, tm_g = p.tiles_m / (8 / G);
@@ -316,6 +315,10 @@ __device__ __forceinline__ void tile_of_block_unsplit(const GemmParams& p, int& 
     tile_m = nid / p.tiles_n;
     tile_n = nid - tile_m * p.tiles_n;
   }
+}
+
+__device__ __forceinline__ void tile_of_block_unsplit(const GemmParams& p, int& tile_m, int& tile_n) {
+  tile_of_block_unsplit(p, (int)gridDim.x, (int)blockIdx.x, tile_m, tile_n);
 }
 
 // smallest G in {1,2,4,8} with b_bytes / G <= 2 MB that tiles the grid evenly (see tile_of_block_unsplit)

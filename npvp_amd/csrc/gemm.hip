@@ -515,8 +515,8 @@ extern "C" int npvp_split_weight(const float* w, long long ld, int N, int K, voi
   NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0, "split_weight: w must be 16-byte aligned");
   const long long total = (long long)N * K / 8;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  if (F) { hipLaunchKernelGGL(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)F); NPVP_CHECK_LAUNCH(); }
-  if (D) { hipLaunchKernelGGL(split_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)D); NPVP_CHECK_LAUNCH(); }
+  if (F) { NPVP_LAUNCH(split_weight_fwd_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)F); NPVP_CHECK_LAUNCH(); }
+  if (D) { NPVP_LAUNCH(split_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, w, ld, N, K, (__bf16*)D); NPVP_CHECK_LAUNCH(); }
   return NPVP_OK;
 }
 
@@ -524,7 +524,7 @@ extern "C" int npvp_split_weight(const float* w, long long ld, int N, int K, voi
 // npvp_split_weight contract.  One launch re-splits every weight of the model after an optimiser step.
 extern "C" int npvp_split_weights_batched(const void* desc, int count, hipStream_t stream) {
   NPVP_CHECK_ARG(desc && count > 0, "split_weights_batched: empty table");
-  hipLaunchKernelGGL(split_weights_batched_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDesc*)desc);
+  NPVP_LAUNCH(split_weights_batched_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDesc*)desc);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -633,7 +633,7 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
           const long long total4 = (long long)M * N / 4;
           int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
           const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;       // (a float4-aligned bias gradient rides along)
-          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
+          NPVP_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
                              sh, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr, c_amax);
           NPVP_CHECK_LAUNCH();
           if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, sh, M, M, stream, p.accum)) {
@@ -674,26 +674,26 @@ extern "C" int npvp_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (wide_wgrad) {
     launch_gemm_wgrad_wide(p, splits, stream);
   } else if (precision == 0) {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+    if (a_kc && b_kc) NPVP_LAUNCH((gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) NPVP_LAUNCH((gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
   } else if (precision == 4) {
-    if (rowstats) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false, true>), grid, block, 0, stream, p);
-    else if (b_pre && a_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
-    else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);
+    if (rowstats) NPVP_LAUNCH((gemm_split_db_kernel<3, true, true, false, true>), grid, block, 0, stream, p);
+    else if (b_pre && a_kc) NPVP_LAUNCH((gemm_split_db_kernel<3, true, true, true>), grid, block, 0, stream, p);
+    else if (a_kc && b_kc) NPVP_LAUNCH((gemm_split_db_kernel<3, true, true, false>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) NPVP_LAUNCH((gemm_split_db_kernel<3, true, false, false>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_split_db_kernel<3, false, false, false>), grid, block, 0, stream, p);
   } else {
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, true, false>), grid, block, 0, stream, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_split_db_kernel<2, true, false, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_split_db_kernel<2, false, false, false>), grid, block, 0, stream, p);
+    if (a_kc && b_kc) NPVP_LAUNCH((gemm_split_db_kernel<2, true, true, false>), grid, block, 0, stream, p);
+    else if (a_kc && !b_kc) NPVP_LAUNCH((gemm_split_db_kernel<2, true, false, false>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_split_db_kernel<2, false, false, false>), grid, block, 0, stream, p);
   }
   NPVP_CHECK_LAUNCH();
   if (splits > 1) {
     const long long total4 = (long long)M * N / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     const bool cs_here = colsum_a && M % 4 == 0 && ((uintptr_t)colsum_a % 16) == 0;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
+    NPVP_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, C, M, N, ldc,
                        splits, alpha, p.accum, cs_here ? (const float*)p.colsum : nullptr, cs_here ? colsum_a : nullptr, c_amax);
     NPVP_CHECK_LAUNCH();
     if (colsum_a && !cs_here && launch_sum_rows(p.colsum, colsum_a, splits, M, M, stream, p.accum)) {

@@ -62,8 +62,19 @@ __device__ __forceinline__ bool block_any(bool pred, int* flags, int wave) {
 // 128 x 256 tile: 24 MFMAs per wave and step, two workgroups per CU).  3 (the small tiles, round 4): B tile kt+2 is DMA'd during
 // step kt, i.e. it has two steps to arrive: with 6 - 12 MFMAs per wave and step and one or two workgroups per CU a step was as
 // long as the L2 -> LDS latency of its B pieces (0.42 us per K-step, three quarters of a shard-sized GEMM's loop).
-template <int TM, int TN, int WM, int WN, bool ROWSTATS, int MINB = 2, int NST = 2>
-__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams p) {
+// LDS of one workgroup of gemm_f16_body: the operand stages, reused as the epilogue's scratch
+template <int TM, int TN, int WM, int WN, int NST>
+constexpr int gemm_f16_lds_bytes() {
+  constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int STAGE = 2 * 2 * (BM * 16 + 64) + 2 * 2 * (BN * 16);
+  constexpr int EPI_BYTES = (4 + NW * EPI_FLOATS + BM) * 4;
+  return NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
+}
+
+// The kernel's body: workgroup `bid` of the `nwg` that cover the problem, on `lds` (gemm_f16_lds_bytes of it).  A function so that a
+// launch can hold more than one problem (gemm_f16_group_kernel below: a dgrad and the weight gradient of the same dy in ONE launch).
+template <int TM, int TN, int WM, int WN, bool ROWSTATS, int NST>
+__device__ __forceinline__ void gemm_f16_body(const GemmParams& p, char* lds, const int bid, const int nwg) {
   constexpr int NW = WM * WN, THREADS = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int APASS = BM / (THREADS / 4);
@@ -73,12 +84,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int CPS = BN / 64;                       // 1 KB glds chunks per (term, k-group) slab
   constexpr int NCHUNK = 4 * CPS, CPW = (NCHUNK + NW - 1) / NW;
-  constexpr int EPI_BYTES = (4 + NW * EPI_FLOATS + BM) * 4;          // the epilogue's scratch lives in the idle stages
   static_assert(NST == 2 || NST == 3, "two or three LDS stages");
-  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES];
+  static_assert(gemm_f16_lds_bytes<TM, TN, WM, WN, NST>() >= NST * STAGE, "lds size formula");
 
   int tile_m, tile_n;
-  tile_of_block_unsplit(p, tile_m, tile_n);
+  tile_of_block_unsplit(p, nwg, bid, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
@@ -339,6 +349,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams
   amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);      // (the stages are idle after the K loop's last barrier)
 }
 
+// NST = LDS stages (see gemm_f16_body).
+template <int TM, int TN, int WM, int WN, bool ROWSTATS, int MINB = 2, int NST = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_f16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[gemm_f16_lds_bytes<TM, TN, WM, WN, NST>()];
+  gemm_f16_body<TM, TN, WM, WN, ROWSTATS, NST>(p, lds, blockIdx.x, gridDim.x);
+}
+
 // =====================================================================================================
 // Weight gradients, dW[M,N] = A^T B with A = dy [K][M], B = x [K][N]: gemm_wgrad_wide_kernel's organisation (row-major
 // staging, transposing LDS reads, split-K with one K-chunk per XCD, bias gradient from the staging registers) on two fp16
@@ -353,32 +370,36 @@ __device__ __forceinline__ f16x8 lds_read_tr_pair_h(const char* a, int second_of
   return __builtin_bit_cast(f16x8, v);
 }
 
+constexpr int GEMM_WGRAD_F16_LDS_BYTES = 2 * (2 * 16 * 128 * 2 + 2 * 16 * 256 * 2);      // two stages of a 128 x 256 tile's two planes per operand
+
+// workgroup (bx, by) of a (gx, splits + reduce rows) grid, on `lds` (GEMM_WGRAD_F16_LDS_BYTES): the kernel's body as a function, for
+// launches that hold more than one problem (gemm_f16_group_kernel)
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_wgrad_f16_body(const GemmParams& p, char* lds, const int bx, const int by, const int gx) {
   constexpr int NW = WM * WN, THREADS = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(THREADS == 256 && BM == 128 && BN == 256, "staging maps are written for 256 threads on a 128 x 256 tile");
   constexpr int ROWA = BM * 2, ROWB = BN * 2;
   constexpr int A_PLANE = 16 * ROWA, B_PLANE = 16 * ROWB, A_BYTES = 2 * A_PLANE, B_BYTES = 2 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  static_assert(2 * STAGE == GEMM_WGRAD_F16_LDS_BYTES, "lds size formula");
 
-  if ((int)blockIdx.y >= p.splits) {
+  if (by >= p.splits) {
     // the extra grid rows: the PREVIOUS weight-gradient launch's split-K reduction (ReduceJob, gemm.h).  That launch is complete
     // (same stream), its partial slabs are at rest; these workgroups are HBM-bound and run beside this launch's MFMA-bound ones -
     // no launch of its own, no idle tail.  Same summation order as splitk_reduce_kernel: bit-identical.
     float cm = 0.f;
-    splitk_reduce_body(p.prev, ((int)blockIdx.y - p.splits) * (int)gridDim.x + (int)blockIdx.x, p.prev.blocks, cm);
+    splitk_reduce_body(p.prev, (by - p.splits) * gx + bx, p.prev.blocks, cm);
     return;
   }
   int z, tl;
   {
-    const int tiles = gridDim.x;
+    const int tiles = gx;
     if (p.splits > 1 && (p.splits & 7) == 0) {
-      const int lin = blockIdx.x + tiles * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+      const int lin = bx + tiles * by, xcd = lin & 7, slot = lin >> 3;
       const int g = slot / tiles;
       tl = slot - g * tiles; z = g * 8 + xcd;
-    } else { z = blockIdx.y; tl = blockIdx.x; }
+    } else { z = by; tl = bx; }
   }
   const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -548,6 +569,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
   });
 }
 
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[GEMM_WGRAD_F16_LDS_BYTES];
+  gemm_wgrad_f16_body<TM, TN, WM, WN>(p, lds, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// ---- a dgrad and the weight gradient of the same dy in ONE launch ------------------------------------------------------------------
+// dx = dy W and dW += dy^T x both read dy and nothing of each other.  On an 8-clip shard (8 192 token rows) a dgrad is 256 tiles of
+// 128 x 128 - one workgroup per CU, one wave per SIMD, the matrix pipes mostly idle behind barriers and LDS-DMA latency - and the
+// weight gradient 256 split-K workgroups likewise.  The eager step overlaps them through the gradient stream; a step captured
+// single-stream into a HIP graph (trainer.GraphedTrainStep: the host-independent form) has no second stream.  Here the two problems
+// share a launch: workgroups [0, first[1]) run the dgrad body, the rest the weight-gradient body (its extra rows reduce the previous
+// weight gradient's split-K slabs, as in gemm_wgrad_f16_kernel), so every CU holds one workgroup of each and the launch count of a
+// shard's step drops by the 112 weight-gradient launches.  Block counts per problem are padded to multiples of 8: workgroups are
+// dealt round-robin over the 8 XCDs, and both bodies map block index -> tile by XCD.
+struct GemmGroup { GemmParams p[2]; int first[3]; int count[2]; int gx; };
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void gemm_f16_group_kernel(GemmGroup g) {
+  constexpr int L0 = gemm_f16_lds_bytes<2, TN, 2, 2, 3>();
+  __shared__ __attribute__((aligned(16))) char lds[L0 > GEMM_WGRAD_F16_LDS_BYTES ? L0 : GEMM_WGRAD_F16_LDS_BYTES];
+  const int b = blockIdx.x;
+  if (b < g.first[1]) {
+    if (b < g.count[0]) gemm_f16_body<2, TN, 2, 2, false, 3>(g.p[0], lds, b, g.count[0]);
+  } else {
+    const int lb = b - g.first[1];
+    if (lb < g.count[1]) {
+      const int by = lb / g.gx;
+      gemm_wgrad_f16_body<2, 4, 2, 2>(g.p[1], lds, lb - by * g.gx, by, g.gx);
+    }
+  }
+}
+
 // split count of the fp16 weight-gradient kernel: ~512 workgroups, >= 16 K-steps per split; 0 = shape not taken
 int f16_wgrad_splits(int M, int N, int K) {
   if ((K & 15) || M < 64 || N < 128 || K < 4096) return 0;
@@ -578,7 +632,7 @@ bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream) {
   const int tiles = p.tiles_m * p.tiles_n, rr = reduce_rows_for(p.prev, tiles);
   p.prev.blocks = rr * tiles;
   dim3 grid(tiles, splits + rr), block(256);
-  hipLaunchKernelGGL((gemm_wgrad_f16_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
+  NPVP_LAUNCH((gemm_wgrad_f16_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
   return true;
 }
 
@@ -595,25 +649,32 @@ int gemm_f16_variant(int M, int N, int K) {
   return 2;
 }
 
-bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
-  if (!p.b_pre || !p.a_amax || !p.b_amax || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return false;
-  if (p.adrop.thresh && (p.adrop.mode != 1 || !p.seed)) return false;
+// the tiling of a forward / dgrad launch: -> variant (0 = not taken), p.tiles_* / p.colgroups set for it
+static int prep_gemm_f16(GemmParams& p) {
+  if (!p.b_pre || !p.a_amax || !p.b_amax || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return 0;
+  if (p.adrop.thresh && (p.adrop.mode != 1 || !p.seed)) return 0;
   const int v = gemm_f16_variant(p.M, p.N, p.K);
-  if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return false;
+  if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return 0;
   const int bn = v == 1 ? 256 : (v == 3 ? 64 : 128);
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
+  return v;
+}
+
+bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
+  const int v = prep_gemm_f16(p);
+  if (v == 0) return false;
   dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (v == 1) {
-    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+    if (p.rowstats) NPVP_LAUNCH((gemm_f16_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
   } else if (v == 3 && !p.rowstats) {
-    hipLaunchKernelGGL((gemm_f16_kernel<2, 1, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
+    NPVP_LAUNCH((gemm_f16_kernel<2, 1, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
   } else {
     if (v == 3) { p.tiles_n = (p.N + 127) / 128; grid = dim3(p.tiles_m * p.tiles_n); p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n); }
-    if (p.rowstats) hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, true, 2, 3>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_kernel<2, 2, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
+    if (p.rowstats) NPVP_LAUNCH((gemm_f16_kernel<2, 2, 2, 2, true, 2, 3>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_f16_kernel<2, 2, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
   }
   return true;
 }
@@ -689,7 +750,7 @@ extern "C" int npvp_amax(const float* x, long long rows, long long cols, long lo
   long long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, ld / 4, cols / 4, slot);
+  NPVP_LAUNCH(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n4, ld / 4, cols / 4, slot);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -700,9 +761,9 @@ extern "C" int npvp_split_weights_f16(const void* desc, int count, void* amax_ta
     if (hipMemsetAsync(amax_table, 0, (size_t)amax_bytes, stream) != hipSuccess) { npvp_set_error("split_weights_f16: memset failed"); return NPVP_ERR_LAUNCH; }
   }
   SplitDescH none = {};
-  hipLaunchKernelGGL(weights_amax_kernel, dim3(16, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
+  NPVP_LAUNCH(weights_amax_kernel, dim3(16, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(split_weights_f16_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
+  NPVP_LAUNCH(split_weights_f16_kernel, dim3(128, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -712,9 +773,9 @@ extern "C" int npvp_split_weight_f16(const float* w, long long ld, int N, int K,
   NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0 && amax_slot, "split_weight_f16: w must be 16-byte aligned, amax_slot non-null");
   if (hipMemsetAsync(amax_slot, 0, AMAX_WORDS * AMAX_STRIDE * 4, stream) != hipSuccess) { npvp_set_error("split_weight_f16: memset failed"); return NPVP_ERR_LAUNCH; }
   SplitDescH one = {w, ld, N, K, (_Float16*)F, (_Float16*)D, amax_slot, 0};
-  hipLaunchKernelGGL(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
+  NPVP_LAUNCH(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(split_weights_f16_kernel, dim3(128, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
+  NPVP_LAUNCH(split_weights_f16_kernel, dim3(128, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -761,9 +822,103 @@ extern "C" int npvp_wgrad_f16_chained(int M, int N, int K, const float* dy, long
   return NPVP_OK;
 }
 
+// ---- dgrad + weight gradient of one linear layer in ONE launch (gemm_f16_group_kernel; include/npvp_hip.h) ---------------------------
+extern "C" int npvp_linear_bwd_f16_takes(int R, int N, int K) {
+  const int v = gemm_f16_variant(R, K, N);
+  return ((v == 2 || v == 3) && npvp_wgrad_f16_chainable(N, K, R)) ? 1 : 0;
+}
+
+extern "C" int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long long ldy, const float* dy_amax, const void* w_planes_d,
+                                   const float* w_amax, float* dx, long long ldx, int act, const float* aux_in, const float* residual,
+                                   long long ldr, float drop_p, int drop_mode, int drop_g1, int drop_g2, unsigned int drop_salt,
+                                   float* dx_amax, const float* x, long long ldxx, const float* x_amax, float* dw, long long ldw, float* db,
+                                   unsigned int* range_flag, float adrop_p, int adrop_g1, int adrop_g2, unsigned int adrop_salt,
+                                   const unsigned long long* seed, const void* prev_job, void* my_job, void* workspace,
+                                   long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(npvp_linear_bwd_f16_takes(R, N, K), "linear_bwd_f16: shape not taken (npvp_linear_bwd_f16_takes tells)");
+  NPVP_CHECK_ARG(dy && dy_amax && w_planes_d && w_amax && dx && x && x_amax && dw && my_job, "linear_bwd_f16: null operand / amax slot / job");
+  NPVP_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dw % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+                 ((uintptr_t)w_planes_d % 16) == 0 && ldy % 4 == 0 && ldxx % 4 == 0 && ldw % 4 == 0 && ldx % 4 == 0,
+                 "linear_bwd_f16: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  NPVP_CHECK_ARG((!db || ((uintptr_t)db % 16) == 0) && (!residual || (((uintptr_t)residual % 16) == 0 && ldr % 4 == 0)) &&
+                 (!aux_in || ((uintptr_t)aux_in % 16) == 0), "linear_bwd_f16: db / residual / aux_in must be 16-byte aligned");
+  NPVP_CHECK_ARG(act == 0 || ((act == 3 || act == 4) && aux_in), "linear_bwd_f16: act must be 0, or 3 / 4 with aux_in");
+  NPVP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "linear_bwd_f16: dropout p out of range or no seed");
+  NPVP_CHECK_ARG(adrop_p >= 0.f && adrop_p < 0.5f && (adrop_p == 0.f || (seed && adrop_g1 > 0 && adrop_g2 > 0 && adrop_g1 % 16 == 0)),
+                 "linear_bwd_f16: adrop needs a device seed and groups of a multiple of 16 rows");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_wgrad_f16_chain_workspace_bytes(N, K, R), "linear_bwd_f16: workspace too small");
+  GemmGroup g = {};
+  // problem 0: dx[R][K] = epilogue((mask) dy[R][N] . W[N][K])  - what npvp_gemm_f32(a_kc = 1, b_kc = 0, M = R, N = K, K = N) builds
+  GemmParams& d = g.p[0];
+  d.A = dy; d.lda = ldy; d.C = dx; d.ldc = ldx; d.M = R; d.N = K; d.K = N; d.alpha = 1.f; d.act = act; d.aux_in = aux_in;
+  d.residual = residual; d.ldr = ldr; d.seed = seed; d.splits = 1;
+  d.drop = make_drop_spec(drop_p, drop_salt, drop_mode, drop_g1, drop_g2);
+  d.adrop = make_drop_spec(adrop_p, adrop_salt, 1, adrop_g1, adrop_g2);
+  d.b_pre = w_planes_d; d.b_pre_plane = (long long)N * K;
+  d.a_amax = dy_amax; d.b_amax = w_amax; d.c_amax = dx_amax;
+  const int v = prep_gemm_f16(d);
+  NPVP_CHECK_ARG(v == 2 || v == 3, "linear_bwd_f16: the dgrad is not a small-tile launch");
+  // problem 1: dW[N][K] (+)= dy^T x over R rows, split-K, reduction handed to the next launch (npvp_wgrad_f16_chained)
+  const int sh = f16_wgrad_splits(N, K, R);
+  GemmParams& w = g.p[1];
+  w.A = dy; w.B = x; w.lda = ldy; w.ldb = ldxx; w.M = N; w.N = K; w.K = R / sh; w.alpha = 1.f;
+  w.C = (float*)workspace; w.ldc = K; w.splits = sh; w.colgroups = 1; w.accum = 1;
+  w.colsum = db ? (float*)workspace + (long long)sh * N * K : nullptr;
+  w.seed = seed;
+  w.drop = make_drop_spec(0.f, 0u, 0, 1, 1);
+  w.adrop = d.adrop;
+  w.a_amax = dy_amax; w.b_amax = x_amax; w.range_flag = range_flag;
+  if (prev_job) w.prev = *reinterpret_cast<const ReduceJob*>(prev_job);
+  w.tiles_m = (N + 127) / 128; w.tiles_n = (K + 255) / 256;
+  const int tiles = w.tiles_m * w.tiles_n, rr = reduce_rows_for(w.prev, tiles);
+  w.prev.blocks = rr * tiles;
+  g.count[0] = d.tiles_m * d.tiles_n;
+  g.first[0] = 0; g.first[1] = (g.count[0] + 7) & ~7;
+  g.count[1] = tiles * (sh + rr);
+  g.first[2] = g.first[1] + ((g.count[1] + 7) & ~7);
+  g.gx = tiles;
+  if (v == 2) NPVP_LAUNCH(gemm_f16_group_kernel<2>, dim3(g.first[2]), dim3(256), 0, stream, g);
+  else NPVP_LAUNCH(gemm_f16_group_kernel<1>, dim3(g.first[2]), dim3(256), 0, stream, g);
+  NPVP_CHECK_LAUNCH();
+  ReduceJob mine = {(const float*)workspace, dw, ldw, N, K, sh, 1, 1.f, 0, db ? w.colsum : nullptr, db};
+  *reinterpret_cast<ReduceJob*>(my_job) = mine;
+  return NPVP_OK;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_job_kernel(ReduceJob j) {
   float cm = 0.f;
   splitk_reduce_body(j, blockIdx.x, gridDim.x, cm);
+}
+
+// many split-K reductions in one launch: the records travel in the kernel's argument block (cf. npvp_sum_rows_multi)
+constexpr int RJ_MAX = 32;
+struct ReduceBatch { ReduceJob j[RJ_MAX]; int first[RJ_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceBatch b) {
+  int lo = 0, hi = b.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  float cm = 0.f;
+  splitk_reduce_body(b.j[lo], (int)blockIdx.x - b.first[lo], b.first[lo + 1] - b.first[lo], cm);
+}
+
+extern "C" int npvp_splitk_reduce_multi(const void* jobs, int n, hipStream_t stream) {
+  NPVP_CHECK_ARG(jobs && n > 0, "splitk_reduce_multi: no jobs");
+  const ReduceJob* J = reinterpret_cast<const ReduceJob*>(jobs);
+  for (int at = 0; at < n; at += RJ_MAX) {
+    ReduceBatch b;
+    b.n = n - at < RJ_MAX ? n - at : RJ_MAX;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.j[i] = J[at + i];
+      NPVP_CHECK_ARG(b.j[i].ws && b.j[i].out && b.j[i].M > 0 && b.j[i].N > 0 && b.j[i].splits > 0, "splitk_reduce_multi: empty job");
+      const long long total4 = (long long)b.j[i].M * b.j[i].N / 4;
+      int nb = (int)((total4 + 255) / 256); if (nb > 256) nb = 256;
+      b.first[i] = blocks; blocks += nb;
+    }
+    b.first[b.n] = blocks;
+    NPVP_LAUNCH(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, stream, b);
+    NPVP_CHECK_LAUNCH();
+  }
+  return NPVP_OK;
 }
 
 extern "C" int npvp_splitk_reduce_job(const void* job, hipStream_t stream) {
@@ -772,7 +927,7 @@ extern "C" int npvp_splitk_reduce_job(const void* job, hipStream_t stream) {
   NPVP_CHECK_ARG(j.ws && j.out && j.M > 0 && j.N > 0 && j.splits > 0, "splitk_reduce_job: empty job");
   const long long total4 = (long long)j.M * j.N / 4;
   int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_job_kernel, dim3(blocks), dim3(256), 0, stream, j);
+  NPVP_LAUNCH(splitk_reduce_job_kernel, dim3(blocks), dim3(256), 0, stream, j);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }

@@ -358,7 +358,7 @@ bool launch_gemm_wgrad_wide(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + 127) / 128;
   p.tiles_n = (p.N + 255) / 256;
   dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
-  hipLaunchKernelGGL((gemm_wgrad_wide_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
+  NPVP_LAUNCH((gemm_wgrad_wide_kernel<2, 4, 2, 2>), grid, block, 0, stream, p);
   return true;
 }
 
@@ -398,11 +398,11 @@ bool launch_gemm_wide(GemmParams& p, hipStream_t stream) {
   p.colgroups = pick_colgroups((long long)p.N * p.K * 6, p.tiles_m, p.tiles_n);
   dim3 grid(p.tiles_m * p.tiles_n), block(256);
   if (v == 1) {
-    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_wide_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
+    if (p.rowstats) NPVP_LAUNCH((gemm_wide_kernel<2, 4, 2, 2, true>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_wide_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
   } else {
-    if (p.rowstats) hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_wide_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
+    if (p.rowstats) NPVP_LAUNCH((gemm_wide_kernel<2, 2, 2, 2, true>), grid, block, 0, stream, p);
+    else NPVP_LAUNCH((gemm_wide_kernel<2, 2, 2, 2, false>), grid, block, 0, stream, p);
   }
   return true;
 }

@@ -118,9 +118,9 @@ extern "C" int npvp_sqdiff_per_image(const float* x, const float* y, int N, long
   NPVP_CHECK_ARG(data_range > 0.f, "sqdiff_per_image: data_range must be positive");
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_sqdiff_workspace_bytes(N, per_image), "sqdiff_per_image: workspace too small");
   const int chunks = sq_chunks(per_image);
-  hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(chunks, N), dim3(256), 0, stream, x, y, per_image, 1.f / data_range, (float*)workspace);
+  NPVP_LAUNCH(sqdiff_partial_kernel, dim3(chunks, N), dim3(256), 0, stream, x, y, per_image, 1.f / data_range, (float*)workspace);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(partial_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, chunks, scale, out, N);
+  NPVP_LAUNCH(partial_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, chunks, scale, out, N);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -144,13 +144,13 @@ extern "C" int npvp_ssim_per_image(const float* img1, const float* img2, int N, 
   const dim3 grid(tpp, N * C), block(256);
   float* part = (float*)workspace;
   switch (window_size) {
-    case 11: hipLaunchKernelGGL(ssim_tile_kernel<11>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
-    case 7: hipLaunchKernelGGL(ssim_tile_kernel<7>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
-    case 5: hipLaunchKernelGGL(ssim_tile_kernel<5>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
-    default: hipLaunchKernelGGL(ssim_tile_kernel<3>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
+    case 11: NPVP_LAUNCH(ssim_tile_kernel<11>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
+    case 7: NPVP_LAUNCH(ssim_tile_kernel<7>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
+    case 5: NPVP_LAUNCH(ssim_tile_kernel<5>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
+    default: NPVP_LAUNCH(ssim_tile_kernel<3>, grid, block, 0, stream, img1, img2, H, W, tw, tpp, t, part); break;
   }
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(partial_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)part, C * tpp,
+  NPVP_LAUNCH(partial_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)part, C * tpp,
                      1.f / ((float)C * H * W), out, N);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;

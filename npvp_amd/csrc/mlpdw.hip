@@ -4,6 +4,7 @@
 // the hidden tensor (the 9 neighbour taps hit L1/L2).  Weights are tap-major [9][Ch] so that a lane's
 // 4 channels are one float4.
 #include "common.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace npvp {
@@ -521,14 +522,14 @@ extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && Ch % 4 == 0, "dwconv: bad shape");
   if (H == 8 && W == 8) {
     const long long nthreads = (long long)frames * (Ch / 4);
-    hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a,
+    NPVP_LAUNCH((dwconv3x3_win_kernel<8, 8, false>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a,
                        wt, bias, out, Ch, nthreads, flip, (float*)nullptr);
     NPVP_CHECK_LAUNCH();
     return NPVP_OK;
   }
   const long long total4 = (long long)frames * H * W * Ch / 4;
   long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
+  NPVP_LAUNCH(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, wt, bias, out, H, W, Ch, total4, flip);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -536,7 +537,7 @@ extern "C" int npvp_dwconv3x3(const float* a, const float* wt, const float* bias
 extern "C" int npvp_frame_stats_finalize(const float* part, int parts_per_frame, float values_per_part, float* mean,
                                          float* rstd, int frames, float eps, hipStream_t stream) {
   NPVP_CHECK_ARG(part && mean && rstd && frames > 0 && parts_per_frame > 0, "frame_stats_finalize: bad arguments");
-  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, part, parts_per_frame,
+  NPVP_LAUNCH(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, part, parts_per_frame,
                      values_per_part, mean, rstd, frames, eps);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -551,10 +552,10 @@ extern "C" int npvp_dwconv3x3_stats(const float* a, const float* wt, const float
   const int J = Ch / 1024;
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * J * 8, "dwconv_stats: workspace too small");
   const long long nthreads = (long long)frames * (Ch / 4);
-  hipLaunchKernelGGL((dwconv3x3_win_kernel<8, 8, true>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, a, wt, bias, out,
+  NPVP_LAUNCH((dwconv3x3_win_kernel<8, 8, true>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, a, wt, bias, out,
                      Ch, nthreads, 0, (float*)workspace);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
+  NPVP_LAUNCH(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
                      65536.f, mean, rstd, frames, eps);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -569,10 +570,10 @@ extern "C" int npvp_mlpdw_mid_fwd(const float* h1, const float* mean1, const flo
   const int J = Ch / 512;
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * J * 8, "mlpdw_mid_fwd: workspace too small");
   const long long nthreads = (long long)frames * (Ch / 2);
-  hipLaunchKernelGGL((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, mean1, rstd1, w1n, b1n,
+  NPVP_LAUNCH((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, mean1, rstd1, w1n, b1n,
                      wt, bias, h2, (float*)workspace, Ch, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr, (float*)nullptr);
   NPVP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
+  NPVP_LAUNCH(frame_stats_finalize_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, (const float*)workspace, J,
                      32768.f, mean2, rstd2, frames, eps);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -588,7 +589,7 @@ extern "C" int npvp_mlpdw_mid_fwd_parts(const float* h1, const float* part1, int
   NPVP_CHECK_ARG(frames > 0 && H == 8 && W == 8 && Ch > 0 && Ch % 512 == 0, "mlpdw_mid_fwd_parts: needs an 8x8 grid and Ch % 512 == 0");
   NPVP_CHECK_ARG(part1 && J1 > 0 && nb1 > 0.f && mean1 && rstd1 && part2, "mlpdw_mid_fwd_parts: bad arguments");
   const long long nthreads = (long long)frames * (Ch / 2);
-  hipLaunchKernelGGL((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, (const float*)nullptr,
+  NPVP_LAUNCH((mlpdw_mid_fwd_kernel<2>), dim3((unsigned)(nthreads / 256)), dim3(256), 0, stream, h1, (const float*)nullptr,
                      (const float*)nullptr, w1n, b1n, wt, bias, h2, part2, Ch, part1, J1, nb1, eps, mean1, rstd1);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -612,10 +613,10 @@ static int mid_bwd_launch(const float* dh2, const float* h1, const float* mean1,
   const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
   // one channel per thread: the windows of a1, dh2, gelu'(y1) w1n and hhat (10 rows of 8) fit 242 VGPRs without spilling
   if (n2)
-    hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1, true>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
+    NPVP_LAUNCH((mlpdw_mid_bwd_kernel<1, true>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
                        b1n, wt, da1, (float*)workspace, psum, Ch, frames, fpc, *n2);
   else
-    hipLaunchKernelGGL((mlpdw_mid_bwd_kernel<1, false>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
+    NPVP_LAUNCH((mlpdw_mid_bwd_kernel<1, false>), dim3(Ch / 256, nchunks), dim3(256), 0, stream, dh2, h1, mean1, rstd1, w1n,
                        b1n, wt, da1, (float*)workspace, psum, Ch, frames, fpc, MidN2{});
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;        // the caller reduces the partials (npvp_mlpdw_mid_bwd_reduce)
@@ -667,9 +668,20 @@ extern "C" int npvp_mlpdw_mid_bwd_reduce_into(const void* workspace, float* gw, 
                                               hipStream_t stream) {
   NPVP_CHECK_ARG(workspace && gw && gb && frames > 0 && Ch > 0, "mlpdw_mid_bwd_reduce_into: bad arguments");
   const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(mid_bwd_reduce_into_kernel, dim3((10 * Ch + 255) / 256), dim3(256), 0, stream, (const float*)workspace, gw, gb,
+  NPVP_LAUNCH(mid_bwd_reduce_into_kernel, dim3((10 * Ch + 255) / 256), dim3(256), 0, stream, (const float*)workspace, gw, gb,
                      Ch, nchunks);
   NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// the same as a 48-byte job record for npvp_sum_rows_multi (norm.hip: struct SumRowsJob, mode 1); nothing is launched
+extern "C" int npvp_mlpdw_mid_bwd_reduce_job(const void* workspace, float* gw, float* gb, int frames, int Ch, void* job) {
+  NPVP_CHECK_ARG(workspace && gw && gb && frames > 0 && Ch > 0 && job, "mlpdw_mid_bwd_reduce_job: bad arguments");
+  const int chunks = mid_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  struct { const float* in; float* out; float* out_b; int nb, stride, ncols, split, accum, mode; } j =
+      {(const float*)workspace, gw, gb, nchunks, 10 * Ch, 10 * Ch, Ch, 1, 1};
+  static_assert(sizeof(j) == 48, "SumRowsJob");
+  memcpy(job, &j, sizeof(j));
   return NPVP_OK;
 }
 
@@ -685,7 +697,7 @@ extern "C" int npvp_im2col3x3(const float* in, float* out, int frames, int H, in
   NPVP_CHECK_ARG(frames > 0 && H > 0 && W > 0 && C % 4 == 0, "im2col: bad shape");
   const long long total4 = (long long)frames * H * W * (col2im ? 1 : 9) * C / 4;
   long long blocks = (total4 + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, H, W, C, total4, col2im);
+  NPVP_LAUNCH(im2col3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, H, W, C, total4, col2im);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -701,10 +713,10 @@ extern "C" int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dw
   NPVP_CHECK_ARG(workspace && ws_bytes >= npvp_dwconv3x3_wgrad_workspace_bytes(frames, Ch), "dwconv_wgrad: workspace too small");
   const int chunks = dw_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
   if (H == 8 && W == 8)
-    hipLaunchKernelGGL((dwconv3x3_wgrad_win_kernel<8, 8>), dim3((Ch / 4 + 255) / 256, nchunks), dim3(256), 0, stream, a, dout,
+    NPVP_LAUNCH((dwconv3x3_wgrad_win_kernel<8, 8>), dim3((Ch / 4 + 255) / 256, nchunks), dim3(256), 0, stream, a, dout,
                        (float*)workspace, Ch, frames, fpc);
   else
-    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 63) / 64, nchunks), dim3(256), 0, stream, a, dout,
+    NPVP_LAUNCH(dwconv3x3_wgrad_kernel, dim3((Ch / 4 + 63) / 64, nchunks), dim3(256), 0, stream, a, dout,
                        (float*)workspace, H, W, Ch, frames, fpc);
   NPVP_CHECK_LAUNCH();
   const int rc = launch_sum_rows((const float*)workspace, dwt_db, nchunks, 10 * Ch, 10 * Ch, stream);

@@ -9,6 +9,7 @@
 // and their backward passes.  Algorithmic bytes: one read + one write of the activation per
 // pass (8 B/element); statistics passes re-read a frame that is L2 resident.
 #include "common.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace npvp {
@@ -768,12 +769,52 @@ int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, 
   // few partial rows (frame-LN params: 32 x 262144) -> 4 row lanes of 64 columns; many partial rows over few columns
   // (bias / LayerNorm / split-K column sums: 512 x 1024) -> 16-column blocks with 64 row lanes: 4x the blocks
   if (nb >= 64 && ncols <= 8192)
-    hipLaunchKernelGGL(sum_rows_kernel<16>, dim3((ncols + 15) / 16), dim3(1024), 0, stream, in, out, nb, stride, ncols, accum,
+    NPVP_LAUNCH(sum_rows_kernel<16>, dim3((ncols + 15) / 16), dim3(1024), 0, stream, in, out, nb, stride, ncols, accum,
                        out_b, split);
   else
-    hipLaunchKernelGGL(sum_rows_kernel<64>, dim3((ncols + 63) / 64), dim3(nb >= 64 ? 1024 : 256), 0, stream, in, out, nb, stride,
+    NPVP_LAUNCH(sum_rows_kernel<64>, dim3((ncols + 63) / 64), dim3(nb >= 64 ? 1024 : 256), 0, stream, in, out, nb, stride,
                        ncols, accum, out_b, split);
   return hipGetLastError() == hipSuccess ? NPVP_OK : NPVP_ERR_LAUNCH;
+}
+
+// ---- many column reductions in ONE launch.  A backward pass leaves ~150 sets of partial rows behind (LayerNorm / frame-LN /
+// depthwise parameter gradients: [nb][ncols] each, to be summed over nb into slices of the flat gradient buffer).  One launch per
+// set was 150 launches of ~10 us on the gradient stream of an 8-clip step (and 150 graph nodes with their dispatch gaps when the step
+// is replayed from a graph); the sets have no consumer before the optimiser, so they are queued on the host and summed by a
+// handful of launches when the backward pass ends.  The jobs travel in the kernel's ARGUMENT block (no device table to keep alive,
+// nothing for a graph replay to re-upload).  Per job the same scheme as sum_rows_kernel: a block owns `cw` columns (16 or 64) and
+// splits the nb partial rows over 1024 / cw row lanes; fixed summation order.
+struct SumRowsJob {
+  const float* in; float* out; float* out_b;   // out_b (nullable): columns >= split go to out_b[c - split]
+  int nb, stride, ncols, split;
+  int accum;                                   // 1: += into out / out_b
+  int mode;                                    // 0 plain; 1: depthwise-conv partials [10][Ch] (ncols = 10 Ch, split = Ch): tap t < 9 of channel c
+                                               //    -> out[c*9 + t], the bias row -> out_b[c]   (mid_bwd_reduce_into_kernel's map)
+};
+constexpr int SRJ_MAX = 40;
+struct SumRowsBatch { SumRowsJob j[SRJ_MAX]; int first[SRJ_MAX + 1]; int cw[SRJ_MAX]; int n; };
+
+__global__ __launch_bounds__(1024) void sum_rows_multi_kernel(SumRowsBatch b) {
+  __shared__ float red[1024];
+  int lo = 0, hi = b.n - 1;                    // the job of this block: last j with first[j] <= blockIdx.x
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const SumRowsJob& J = b.j[lo];
+  const int CW = b.cw[lo], sh = CW == 16 ? 4 : 6;
+  const int cx = threadIdx.x & (CW - 1), rl = threadIdx.x >> sh, nrl = 1024 >> sh;
+  const int c = ((int)blockIdx.x - b.first[lo]) * CW + cx;
+  float s = 0.f;
+  if (c < J.ncols)
+    for (int r = rl; r < J.nb; r += nrl) s += J.in[(long long)r * J.stride + c];
+  red[rl * CW + cx] = s;
+  __syncthreads();
+  if (rl == 0 && c < J.ncols) {
+    float t = 0.f;
+    for (int i = 0; i < nrl; ++i) t += red[i * CW + cx];
+    float* o;
+    if (J.mode == 1) { const int tap = c / J.split, ch = c - tap * J.split; o = tap < 9 ? J.out + ch * 9 + tap : J.out_b + ch; }
+    else o = (J.out_b && c >= J.split) ? J.out_b + (c - J.split) : J.out + c;
+    *o = J.accum ? *o + t : t;
+  }
 }
 
 static inline int ew_blocks(long long total, int threads) {
@@ -808,10 +849,10 @@ extern "C" int npvp_layernorm_fwd(const float* x, const float* w, const float* b
   const long long nb = (rows + 3) / 4;
   dim3 grid((unsigned)(nb > 4096 ? 4096 : nb)), block(256);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
-    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
-    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
-    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    case 1: NPVP_LAUNCH(ln_fwd_kernel<1>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    case 2: NPVP_LAUNCH(ln_fwd_kernel<2>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    case 3: NPVP_LAUNCH(ln_fwd_kernel<3>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
+    default: NPVP_LAUNCH(ln_fwd_kernel<4>, grid, block, 0, stream, x, w, b, y, mean, rstd, rows, eps, relu, amax); break;
   }
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -837,10 +878,10 @@ extern "C" int npvp_layernorm_bwd(const float* dy, const float* x, const float* 
   float* part = (float*)workspace;
   dim3 grid(nb), block(256);
   switch (C / 256) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    case 1: NPVP_LAUNCH(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    case 2: NPVP_LAUNCH(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    case 3: NPVP_LAUNCH(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
+    default: NPVP_LAUNCH(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, w, b, mean, rstd, dx, part, rows, relu, dres, amax); break;
   }
   NPVP_CHECK_LAUNCH();
   // partial rows are [dw(C) | db(C)]
@@ -864,6 +905,42 @@ extern "C" int npvp_layernorm_bwd_reduce(const void* workspace, float* dw, float
   return NPVP_OK;
 }
 
+// The same reduction as a JOB for npvp_sum_rows_multi (48 bytes at `job`, see include/npvp_hip.h): nothing is launched.
+static void fill_job(void* job, const float* in, float* out, float* out_b, int nb, int stride, int ncols, int split, int accum, int mode) {
+  SumRowsJob j;
+  j.in = in; j.out = out; j.out_b = out_b; j.nb = nb; j.stride = stride; j.ncols = ncols; j.split = split; j.accum = accum; j.mode = mode;
+  memcpy(job, &j, sizeof(j));
+}
+static_assert(sizeof(SumRowsJob) == 48, "a job is 48 bytes (npvp_amd/ops.py ReduceQueue packs them back to back)");
+
+extern "C" int npvp_layernorm_bwd_reduce_job(const void* workspace, float* dw, float* db, long long rows, int C, int accumulate, void* job) {
+  NPVP_CHECK_ARG(workspace && dw && db && rows > 0 && job, "layernorm_bwd_reduce_job: bad arguments");
+  fill_job(job, (const float*)workspace, dw, db, ln_bwd_blocks(rows), 2 * C, 2 * C, C, accumulate ? 1 : 0, 0);
+  return NPVP_OK;
+}
+
+// `jobs` = n SumRowsJob records in HOST memory (filled by the *_reduce_job entry points); ceil(n / 40) launches
+extern "C" int npvp_sum_rows_multi(const void* jobs, int n, hipStream_t stream) {
+  NPVP_CHECK_ARG(jobs && n > 0, "sum_rows_multi: no jobs");
+  const SumRowsJob* J = (const SumRowsJob*)jobs;
+  for (int at = 0; at < n; at += SRJ_MAX) {
+    SumRowsBatch b;
+    b.n = n - at < SRJ_MAX ? n - at : SRJ_MAX;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.j[i] = J[at + i];
+      NPVP_CHECK_ARG(b.j[i].in && b.j[i].out && b.j[i].nb > 0 && b.j[i].ncols > 0, "sum_rows_multi: bad job");
+      b.cw[i] = (b.j[i].nb >= 64 && b.j[i].ncols <= 8192) ? 16 : 64;         // (launch_sum_rows' choice)
+      b.first[i] = blocks;
+      blocks += (b.j[i].ncols + b.cw[i] - 1) / b.cw[i];
+    }
+    b.first[b.n] = blocks;
+    NPVP_LAUNCH(sum_rows_multi_kernel, dim3(blocks), dim3(1024), 0, stream, b);
+    NPVP_CHECK_LAUNCH();
+  }
+  return NPVP_OK;
+}
+
 // LayerNorm(C) (+ReLU) over the token rows of `frames` frames of 64 pixels, output in the reference's (frames, C, 8, 8) layout
 // (K9).  C in {256, 512}.  mean / rstd are per token row, as npvp_layernorm_fwd writes them: the backward is npvp_transpose of dy
 // + npvp_layernorm_bwd (a fused backward through the same LDS tile was 3x slower than those two kernels: 771 vs 239 us at c2).
@@ -871,8 +948,8 @@ extern "C" int npvp_layernorm_nchw_fwd(const float* x, const float* w, const flo
                                        int frames, int P, int C, float eps, int relu, hipStream_t stream) {
   NPVP_CHECK_ARG(x && w && b && out && mean && rstd && frames > 0, "layernorm_nchw_fwd: bad arguments");
   NPVP_CHECK_ARG(P == 64 && (C == 256 || C == 512), "layernorm_nchw_fwd: 64-pixel frames, C = 256 or 512");
-  if (C == 512) hipLaunchKernelGGL(ln_nchw_fwd_kernel<512>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
-  else hipLaunchKernelGGL(ln_nchw_fwd_kernel<256>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
+  if (C == 512) NPVP_LAUNCH(ln_nchw_fwd_kernel<512>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
+  else NPVP_LAUNCH(ln_nchw_fwd_kernel<256>, dim3(frames), dim3(256), 0, stream, x, w, b, out, mean, rstd, eps, relu);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -881,7 +958,7 @@ extern "C" int npvp_frame_stats(const float* x, const float* add, float* mean, f
                                 int per_frame, float eps, hipStream_t stream) {
   NPVP_CHECK_ARG(frames > 0 && T > 0 && frames % T == 0, "frame_stats: frames must be a multiple of T");
   NPVP_CHECK_ARG(per_frame % 4 == 0, "frame_stats: per_frame must be a multiple of 4");
-  hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
+  NPVP_LAUNCH(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -891,15 +968,15 @@ extern "C" int npvp_posfuse_fwd(const float* x, const float* add, const float* b
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse: bad shape");
   const int frames = N * T;
   if (per_frame == 32768) {          // 8 x 8 x 512: the frame lives in the block's registers
-    hipLaunchKernelGGL((posfuse_fwd_frame_kernel<8>), dim3(frames), dim3(1024), 0, stream, x, add, beta, gamma, y, mean, rstd, T,
+    NPVP_LAUNCH((posfuse_fwd_frame_kernel<8>), dim3(frames), dim3(1024), 0, stream, x, add, beta, gamma, y, mean, rstd, T,
                        eps, amax);
     NPVP_CHECK_LAUNCH();
     return NPVP_OK;
   }
-  hipLaunchKernelGGL(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
+  NPVP_LAUNCH(frame_stats_kernel, dim3(frames), dim3(512), 0, stream, x, add, mean, rstd, T, per_frame, eps);
   NPVP_CHECK_LAUNCH();
   const long long total4 = (long long)frames * per_frame / 4;
-  hipLaunchKernelGGL(posfuse_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, x, add, beta, gamma,
+  NPVP_LAUNCH(posfuse_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, x, add, beta, gamma,
                      (const float*)mean, (const float*)rstd, y, T, per_frame, total4, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -913,7 +990,7 @@ extern "C" int npvp_ln_posfuse_fwd(const float* x, const float* lw, const float*
                                    float* fused_amax, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && P == 64 && C == 512, "ln_posfuse_fwd: frames of 64 token rows x 512 channels only");
   NPVP_CHECK_ARG(x && lw && lb && y1 && ln_mean && ln_rstd && beta && fused && pf_mean && pf_rstd, "ln_posfuse_fwd: null argument");
-  hipLaunchKernelGGL(ln_posfuse_fwd_frame_kernel, dim3(N * T), dim3(1024), 0, stream, x, lw, lb, ln_eps, y1, ln_mean, ln_rstd, add,
+  NPVP_LAUNCH(ln_posfuse_fwd_frame_kernel, dim3(N * T), dim3(1024), 0, stream, x, lw, lb, ln_eps, y1, ln_mean, ln_rstd, add,
                      beta, gamma, fused, pf_mean, pf_rstd, T, pf_eps, y1_amax, fused_amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -939,18 +1016,18 @@ extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* ad
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * 2 * 4, "posfuse_bwd: workspace too small");
   NPVP_CHECK_ARG(!dgamma || gamma, "posfuse_bwd: dgamma without gamma");
   float* s1 = (float*)workspace; float* s2 = s1 + frames;
-  hipLaunchKernelGGL(posfuse_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, dy, x, add, gamma, mean, rstd, s1, s2, T,
+  NPVP_LAUNCH(posfuse_bwd_stats_kernel, dim3(frames), dim3(512), 0, stream, dy, x, add, gamma, mean, rstd, s1, s2, T,
                      per_frame);
   NPVP_CHECK_LAUNCH();
   if (npvp_posfuse_bwd_fused(N, T, per_frame)) {
-    hipLaunchKernelGGL(posfuse_bwd_apply_nsum_kernel, dim3(T * (per_frame / 1024)), dim3(256), 0, stream, dy, x, add, gamma, mean,
+    NPVP_LAUNCH(posfuse_bwd_apply_nsum_kernel, dim3(T * (per_frame / 1024)), dim3(256), 0, stream, dy, x, add, gamma, mean,
                        rstd, (const float*)s1, (const float*)s2, du, dbeta, dgamma, N, T, per_frame);
     NPVP_CHECK_LAUNCH();
     return NPVP_OK;
   }
   NPVP_CHECK_ARG(!dgamma || dyxh, "posfuse_bwd: this shape needs the dy*uhat scratch (dyxh) for dgamma");
   const long long total4 = (long long)frames * per_frame / 4;
-  hipLaunchKernelGGL(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
+  NPVP_LAUNCH(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
                      rstd, (const float*)s1, (const float*)s2, du, dgamma ? dyxh : nullptr, T, per_frame, total4);
   NPVP_CHECK_LAUNCH();
   if (dbeta) { const int rc = npvp_reduce_mid_launch(dy, dbeta, 1, N, (long long)T * per_frame, 1.f, stream); if (rc) return rc; }
@@ -963,7 +1040,7 @@ extern "C" int npvp_posfuse_instance_fwd(const float* x, const float* add, const
                                          float* mean, float* rstd, int N, int T, int P, int C, float eps, float* y_amax,
                                          hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && P > 0 && P <= PFI_MAXP && C > 0, "posfuse_instance: bad shape (P <= 64)");
-  hipLaunchKernelGGL(posfuse_inst_fwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, x, add, beta, gamma, y, mean,
+  NPVP_LAUNCH(posfuse_inst_fwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, x, add, beta, gamma, y, mean,
                      rstd, T, P, C, eps, y_amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -973,7 +1050,7 @@ extern "C" int npvp_posfuse_instance_bwd(const float* dy, const float* x, const 
                                          const float* rstd, float* du, float* dyxh, int N, int T, int P, int C,
                                          hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && T > 0 && P > 0 && P <= PFI_MAXP && C > 0, "posfuse_instance_bwd: bad shape (P <= 64)");
-  hipLaunchKernelGGL(posfuse_inst_bwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, dy, x, add, gamma, mean, rstd,
+  NPVP_LAUNCH(posfuse_inst_bwd_kernel, dim3((C + 255) / 256, N * T), dim3(256), 0, stream, dy, x, add, gamma, mean, rstd,
                      du, dyxh, T, P, C);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -987,7 +1064,7 @@ extern "C" int npvp_frameln_act_fwd(const float* h, const float* mean, const flo
   NPVP_CHECK_ARG((drop_p == 0.f && dp_p == 0.f) || seed, "frameln_act: dropout needs a device seed");
   FlnParams p;
   fill_fln(p, h, mean, rstd, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
-  hipLaunchKernelGGL(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out, amax);
+  NPVP_LAUNCH(frameln_act_fwd_kernel, dim3(ew_blocks(p.total4, 256)), dim3(256), 0, stream, p, out, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
@@ -1003,7 +1080,7 @@ extern "C" int npvp_frameln_act_fwd_parts(const float* h, const float* part, int
   NPVP_CHECK_ARG((long long)frames * (per_frame / 4096) < (1ll << 31), "frameln_act_fwd_parts: too many blocks");
   FlnParams p;
   fill_fln(p, h, nullptr, nullptr, w, b, res, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
-  hipLaunchKernelGGL(frameln_act_fwd_parts_kernel, dim3((unsigned)((long long)frames * (per_frame / 4096))), dim3(256), 0, stream, p,
+  NPVP_LAUNCH(frameln_act_fwd_parts_kernel, dim3((unsigned)((long long)frames * (per_frame / 4096))), dim3(256), 0, stream, p,
                      part, J, nb, eps, mean, rstd, out, amax);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
@@ -1031,11 +1108,11 @@ extern "C" int npvp_frameln_act_bwd(const float* dout, const float* h, const flo
   fill_fln(p, h, mean, rstd, w, b, nullptr, frames, per_frame, drop_p, salt, dp_p, dp_salt, frames_per_sample, seed);
   NPVP_CHECK_ARG(per_frame % (4 * FLN_PARTS) == 0, "frameln_act_bwd: per_frame must be a multiple of 16");
   float* psum = (float*)workspace; float* part = psum + (long long)frames * 2 * FLN_PARTS;
-  hipLaunchKernelGGL(frameln_act_bwd_stats_kernel, dim3(frames, FLN_PARTS), dim3(512), 0, stream, p, dout, psum);
+  NPVP_LAUNCH(frameln_act_bwd_stats_kernel, dim3(frames, FLN_PARTS), dim3(512), 0, stream, p, dout, psum);
   NPVP_CHECK_LAUNCH();
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
+  NPVP_LAUNCH(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
                      dout, (const float*)psum, dh, part, frames, fpc, FLN_PARTS, amax);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;      // the caller reduces the partials itself (npvp_frameln_act_bwd_reduce)
@@ -1061,7 +1138,7 @@ extern "C" int npvp_frameln_act_bwd_apply(const float* dout, const float* h, con
   float* part = (float*)workspace + (long long)frames * 2 * FLN_PARTS;
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
+  NPVP_LAUNCH(frameln_act_bwd_fused_kernel, dim3((per_frame / 4 + 255) / 256, nchunks), dim3(256), 0, stream, p,
                      dout, psum, dh, part, frames, fpc, nparts, amax);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;
@@ -1087,7 +1164,7 @@ extern "C" int npvp_frameln_act_bwd_pgrad(const float* dout, const float* h, con
   float* part = (float*)workspace + (long long)frames * 2 * FLN_PARTS;
   const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks;
   const int nchunks = (frames + fpc - 1) / fpc;
-  hipLaunchKernelGGL(frameln_act_bwd_pgrad_kernel, dim3(per_frame / 1024, nchunks), dim3(256), 0, stream, p, dout, psum, part,
+  NPVP_LAUNCH(frameln_act_bwd_pgrad_kernel, dim3(per_frame / 1024, nchunks), dim3(256), 0, stream, p, dout, psum, part,
                      frames, fpc);
   NPVP_CHECK_LAUNCH();
   if (accumulate == 2) return NPVP_OK;
@@ -1095,6 +1172,15 @@ extern "C" int npvp_frameln_act_bwd_pgrad(const float* dout, const float* h, con
     npvp_set_error("frameln_act_bwd_pgrad: reduce launch failed");
     return NPVP_ERR_LAUNCH;
   }
+  return NPVP_OK;
+}
+
+extern "C" int npvp_frameln_act_bwd_reduce_job(const void* workspace, float* dw, float* db, int frames, int per_frame, int accumulate,
+                                               void* job) {
+  NPVP_CHECK_ARG(workspace && dw && db && frames > 0 && job, "frameln_act_bwd_reduce_job: bad arguments");
+  const int chunks = fln_chunks(frames), fpc = (frames + chunks - 1) / chunks, nchunks = (frames + fpc - 1) / fpc;
+  const float* part = (const float*)workspace + 2 * FLN_PARTS * (long long)frames;
+  fill_job(job, part, dw, db, nchunks, 2 * per_frame, 2 * per_frame, per_frame, accumulate ? 1 : 0, 0);
   return NPVP_OK;
 }
 

@@ -136,6 +136,9 @@ def kitti_clip_lists(kitti_dir, clip_length, test_folder_ids=(10, 11, 12, 13), t
     return {"val": cut(tr[0:2]), "train": cut(tr[2:])} if val else {"train": cut(tr)}
 
 
+_DIGITS = {}          # (root, train, digit_size) -> array: the 60 000 PIL resizes are done once per process, not once per split
+
+
 def load_mnist_digits(root, train=True, digit_size=32):
     """The digit images StochasticMovingMNIST draws from (ref dataset.py:693-700: torchvision datasets.MNIST(root, train,
     transform=Resize(32) + ToTensor)) without torchvision: the raw idx file `<root>/MNIST/raw/{train,t10k}-images-idx3-ubyte[.gz]`,
@@ -143,6 +146,9 @@ def load_mnist_digits(root, train=True, digit_size=32):
     Returns float32 (N, digit_size, digit_size)."""
     import gzip
     from PIL import Image
+    key = (str(Path(root).resolve()), bool(train), int(digit_size))
+    if key in _DIGITS:
+        return _DIGITS[key]
     name = ("train" if train else "t10k") + "-images-idx3-ubyte"
     base = Path(root) / "MNIST" / "raw" / name
     if base.exists():
@@ -158,6 +164,8 @@ def load_mnist_digits(root, train=True, digit_size=32):
     out = np.empty((n, digit_size, digit_size), dtype=np.float32)
     for i in range(n):
         out[i] = np.asarray(Image.fromarray(imgs[i], mode='L').resize((digit_size, digit_size), Image.BILINEAR), dtype=np.float32) / 255.0
+    out.setflags(write=False)
+    _DIGITS[key] = out
     return out
 
 
@@ -169,6 +177,9 @@ class StochasticMovingMNIST:
     object, so concurrent loader threads must go through `__getitem__` under its lock (it is a few hundred microseconds).
     `digits`: float32 (N, 32, 32) in [0, 1] (load_mnist_digits).  __getitem__ gives the clip as uint8 (T, H, W, 1) = what the
     reference's ToPILImage makes of the float frames (x 255, truncated), ready for ClipLoader (mean 0, std 1: VidToTensor only)."""
+
+    sequential_draw = True      # every clip is a draw from ONE random stream: ClipLoader draws them in submission order on one thread,
+                                # so a fixed seed gives the same clips run to run (the reference is deterministic per worker process)
 
     def __init__(self, digits, num_past_frames, num_future_frames, num_digits=2, image_size=64, deterministic=False):
         import threading
@@ -436,7 +447,10 @@ class ClipLoader:
     def __iter__(self):
         batches = self._batches()
         P = self.ds.num_past_frames
-        with ThreadPoolExecutor(self.num_workers) as pool:
+        # a dataset whose items are consecutive draws from one random stream (StochasticMovingMNIST) gets ONE worker thread: tasks
+        # run in submission order, so the clips of a batch - and of an epoch - do not depend on thread scheduling
+        workers = 1 if getattr(self.ds, "sequential_draw", False) else self.num_workers
+        with ThreadPoolExecutor(workers) as pool:
             pending = []
             nxt = 0
             while nxt < len(batches) or pending:

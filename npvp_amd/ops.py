@@ -403,7 +403,8 @@ class GemmProbe:
     records = []          # (start_event, end_event, flops, bytes, (layout, kernel id))
     KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel<2, 4, 2, 2>",
                3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>", 5: "npvp::gemm_f16_kernel<2, 4, 2, 2>",
-               6: "npvp::gemm_wgrad_f16_kernel", 7: "npvp::gemm_f16_kernel<2, 2, 2, 2>"}
+               6: "npvp::gemm_wgrad_f16_kernel", 7: "npvp::gemm_f16_kernel<2, 2, 2, 2>",
+               8: "npvp::gemm_f16_group_kernel (dgrad + weight gradient in one launch)"}
 
     only = None           # set of kernel ids to bracket (None = every GEMM launch)
 
@@ -573,7 +574,7 @@ class WgradStream:
         return cls._side[key]
 
     in_flush = False         # inside flush(): the current stream is the gradient stream (WgradChain defers reductions there)
-    _held, _held_bytes = [], 0
+    _held, _held_bytes, _held_storages = [], 0, set()
     HOLD_BYTES = 2048 << 20
     _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
     BATCH = 16
@@ -612,22 +613,35 @@ class WgradStream:
                     # data parallel: the slots reported below must be COMPLETE on this stream when a bucket's all-reduce is
                     # ordered behind it - a split-K reduction still waiting for its next launch is not
                     WgradChain.flush()
+                if ReduceQueue.pending() and (GradSink.listener is not None or ReduceQueue.due()):
+                    ReduceQueue._launch(side)   # a launch's worth of deferred parameter-gradient reductions (or, data parallel, all)
             finally:
                 cls.in_flush = False
         for _, keep, slots in q:
             for t in keep:
-                # the gradient stream reads t after the caller may have dropped it: either HOLD a reference until the join (after
-                # which the compute stream is ordered behind everything the gradient stream did - freeing is then safe without
-                # any allocator bookkeeping) or, past a byte budget (the large workloads: tens of GB of dy per backward pass),
-                # record the stream on the block (an event per block when it is freed: 500 of them were ~1 ms of a shard's step)
-                nb = t.numel() * 4
-                if cls._held_bytes + nb <= cls.HOLD_BYTES:
-                    cls._held.append(t)
-                    cls._held_bytes += nb
-                else:
-                    t.record_stream(side)
+                cls.hold(t)
             if slots is not None:
                 GradSink.wrote(*slots)          # (on the caller's stream: the listener orders its collective after both streams)
+
+    @classmethod
+    def hold(cls, t):
+        """The gradient stream reads t after the caller may have dropped it: either HOLD a reference until the join (after which the
+        compute stream is ordered behind everything the gradient stream did - freeing is then safe without any allocator
+        bookkeeping) or, past a byte budget (the large workloads: tens of GB of dy per backward pass), record the stream on the
+        block (an event per block when it is freed: 500 of them were ~1 ms of a shard's step).  The budget counts what a reference
+        really pins - the tensor's whole STORAGE, once (a small view of a large activation holds all of it: ADVICE r4)."""
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key in cls._held_storages:
+            cls._held.append(t)
+            return
+        nb = st.nbytes()
+        if cls._held_bytes + nb <= cls.HOLD_BYTES:
+            cls._held.append(t)
+            cls._held_storages.add(key)
+            cls._held_bytes += nb
+        else:
+            t.record_stream(cls._pending[1] if cls._pending is not None else cls.stream(t.device))
 
     @classmethod
     def pending_stream(cls):
@@ -642,11 +656,128 @@ class WgradStream:
         if cls._pending is not None:
             cls.flush()
             dev, side = cls._pending
+            if ReduceQueue.pending():
+                side.wait_stream(torch.cuda.current_stream(dev))      # (the partials' producers ran on the caller's stream)
             with torch.cuda.stream(side):
                 WgradChain.flush()               # the last weight gradient's split-K reduction has no launch to ride in
+                if ReduceQueue.pending():
+                    ReduceQueue._launch(side)
             torch.cuda.current_stream(dev).wait_stream(side)
             cls._pending = None
-            cls._held, cls._held_bytes = [], 0
+            cls._held, cls._held_bytes, cls._held_storages = [], 0, set()
+
+
+class ReduceQueue:
+    """Deferred parameter-gradient reductions (include/npvp_hip.h, npvp_sum_rows_multi).  The LayerNorm / frame-LayerNorm / fused
+    MlpDWBN-middle backward kernels leave per-block partial sums of their parameter gradients in a workspace; summing them into
+    the flat gradient buffer has no consumer before the optimiser.  One launch per site was ~150 launches of ~10 us per 8-clip step
+    (a tenth of its launches).  Here a site only writes a 48-byte job record into a host buffer; the records are run 40 per launch
+      * on the gradient stream, by WgradStream.flush() once 40 have gathered (the large workloads: the reductions keep overlapping
+        the backward pass, the workspaces - 2 GB per c2 step - do not pile up) and by WgradStream.join();
+      * on the current stream when the backward pass ends (autograd engine callback), if there is no gradient stream (single-stream
+        capture of the step into a HIP graph: 146 graph nodes become 4).
+    Two jobs that write the same gradient slice (a LayerNorm applied twice per step: the tied final norm, the encoder of NPVP-S
+    training) never share a launch: the queue is run before the second one is added.  Same summation order whoever runs it."""
+    enabled = os.environ.get("NPVP_REDUCE_QUEUE", "1") == "1"
+    JOB, CAP, LAUNCH = 48, 480, 40
+    SKJOB, SKCAP, SKLAUNCH = 64, 256, 16      # split-K reductions of fused dgrad + weight-gradient launches (linear_bwd): 64-byte records
+    _buf = _addr = _skbuf = _skaddr = None
+    _n = _skn = 0
+    _keep, _wrote, _outs = [], [], set()
+    _armed = False
+
+    @classmethod
+    def pending(cls):
+        return cls._n + cls._skn
+
+    @classmethod
+    def due(cls):
+        """a launch's worth has gathered (WgradStream.flush runs the queue then, so that the reductions keep overlapping the pass)"""
+        return cls._n >= cls.LAUNCH or cls._skn >= cls.SKLAUNCH
+
+    @classmethod
+    def splitk_slot(cls, out_ptrs):
+        """host address for the next 64-byte split-K job record (the C call that leaves the partial slabs writes it)"""
+        if cls._skbuf is None:
+            cls._skbuf = ctypes.create_string_buffer(cls.SKJOB * cls.SKCAP)
+            cls._skaddr = ctypes.addressof(cls._skbuf)
+        if cls._skn == cls.SKCAP or not cls._outs.isdisjoint(out_ptrs):
+            cls.run_pending()
+        return cls._skaddr + cls.SKJOB * cls._skn
+
+    @classmethod
+    def splitk_added(cls, out_ptrs, keep, wrote):
+        cls._skn += 1
+        cls._keep.append(keep)
+        cls._outs.update(out_ptrs)
+        if wrote is not None:
+            cls._wrote.append(wrote)
+        cls._arm()
+
+    @classmethod
+    def _arm(cls):
+        if not cls._armed:
+            cls._armed = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.finish)
+            except RuntimeError:                    # not inside a backward pass (an op test calling the wrappers directly):
+                cls._armed = False                  # the caller runs finish() itself
+
+    @classmethod
+    def add(cls, filler, name, args, out_ptrs, keep, wrote):
+        """filler(*args, job address) = one of the npvp_*_reduce_job entry points; out_ptrs: device addresses the job writes"""
+        if cls._buf is None:
+            cls._buf = ctypes.create_string_buffer(cls.JOB * cls.CAP)
+            cls._addr = ctypes.addressof(cls._buf)
+        if cls._n == cls.CAP or not cls._outs.isdisjoint(out_ptrs):
+            cls.run_pending()
+        check(filler(*args, cls._addr + cls.JOB * cls._n), name)
+        cls._n += 1
+        cls._keep.append(keep)
+        cls._outs.update(out_ptrs)
+        if wrote is not None:
+            cls._wrote.append(wrote)
+        cls._arm()
+
+    @classmethod
+    def run_pending(cls):
+        """the queued jobs, now, on the stream where in-place gradient writes belong"""
+        if cls._n + cls._skn == 0:
+            return
+        if WgradStream.enabled and WgradStream._pending is not None and not WgradStream.in_flush:
+            dev, side = WgradStream._pending
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                cls._launch(side)
+        else:
+            cls._launch(None)
+
+    @classmethod
+    def _launch(cls, side):
+        n, skn, keep, wrote = cls._n, cls._skn, cls._keep, cls._wrote
+        cls._n, cls._skn, cls._keep, cls._wrote, cls._outs = 0, 0, [], [], set()
+        if n:
+            check(lib().npvp_sum_rows_multi(cls._addr, n, _stream()), "npvp_sum_rows_multi")
+        if skn:
+            check(lib().npvp_splitk_reduce_multi(cls._skaddr, skn, _stream()), "npvp_splitk_reduce_multi")
+        if side is not None or WgradStream.in_flush:
+            for t in keep:                         # read on the gradient stream after the caller drops them (see WgradStream.flush)
+                WgradStream.hold(t)
+        for sk in wrote:
+            GradSink.wrote(*sk)
+
+    @classmethod
+    def finish(cls):
+        """end of the backward pass (autograd engine callback; also FlatAdamW.step / zero_grad)"""
+        cls._armed = False
+        if not WgradStream.enabled:
+            WgradChain.flush()                      # (single stream: the last fused launch's split-K reduction has no launch to ride in)
+        if cls._n + cls._skn == 0:
+            return
+        if WgradStream.enabled and WgradStream._pending is not None:
+            WgradStream.join()                      # (runs the queue on the gradient stream before the streams re-join)
+        else:
+            cls._launch(None)
 
 
 # --------------------------------------------------------------------------- raw kernel wrappers
@@ -830,7 +961,7 @@ class WgradChain:
         if probe:
             e1.record()
             GemmProbe.records.append((e0, e1, 2.0 * N * K * R, 4.0 * (N * R + K * R + N * K), ((0, 0), 6)))
-        cls._pending[st] = (job, ws, dw, db)
+        cls._pending[st] = (job, ws, dw, db, None)
 
     @classmethod
     def flush(cls):
@@ -839,6 +970,8 @@ class WgradChain:
         prev = cls._pending.pop(st, None)
         if prev is not None:
             check(lib().npvp_splitk_reduce_job(ctypes.addressof(prev[0]), st), "npvp_splitk_reduce_job")
+            if prev[4] is not None:
+                GradSink.wrote(*prev[4])
 
 
 class RangeGuard:
@@ -928,6 +1061,80 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc, precision=prec, a_amax=dy_amax, b_amax=x_amax,
          a_drop=a_drop, range_flag=flag)
     return (dw, db) if with_bias_grad else dw
+
+
+class FusedLinearBwd:
+    """dgrad + weight gradient of one linear layer as ONE launch (include/npvp_hip.h, npvp_linear_bwd_f16) - for the shapes on which
+    each of the two alone leaves half the chip idle: small-tile dgrads with at least 4 096 and at most MAX_ROWS token rows (the
+    8-clip shards of the data-parallel configurations; the large workloads keep the two-stream schedule).  The weight gradient's
+    split-K reduction is the only in-place gradient write: with a gradient stream it is queued for that stream (ReduceQueue), where
+    every in-place write is serialised; without one (the step captured single-stream into a HIP graph) it rides in the next fused
+    launch on the same stream (WgradChain)."""
+    enabled = os.environ.get("NPVP_FUSED_LINEAR_BWD", "1") == "1"
+    MAX_ROWS = int(os.environ.get("NPVP_FUSED_LINEAR_BWD_ROWS", "16384"))
+    _ok = {}
+
+    @classmethod
+    def takes(cls, R, N, K):
+        key = (R, N, K)
+        v = cls._ok.get(key)
+        if v is None:
+            v = cls._ok[key] = bool(lib().npvp_linear_bwd_f16_takes(R, N, K)) and WgradChain.takes(N, K, R)
+        return v and R <= cls.MAX_ROWS
+
+
+def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None, a_drop=NO_DROP):
+    """The backward of y = x w^T + b given dy [R, N]: -> dx = epilogue((a_drop mask) dy w), gw, gb - the weight (+ bias) gradient goes
+    into the sink `sk` (-> None, None) or is returned.  One launch where FusedLinearBwd takes the shape, else the dgrad on this
+    stream and the weight gradient on the gradient stream as before."""
+    R, N = dy.shape
+    K = w.shape[1]
+    has_b = b is not None
+    if (FusedLinearBwd.enabled and GEMM_PRECISION == 6 and sk and has_b == (sk[1] is not None) and FusedLinearBwd.takes(R, N, K)
+            and not RangeGuard.fallback and not RangeGuard.strict and dy.stride(1) == 1 and x.stride(1) == 1):
+        pl = _planes(w, "D", R)
+        gw = sk[0][0]
+        if pl is not None and gw.stride(1) == 1:
+            planes, w_amax = pl
+            gb = sk[1][0] if has_b else None
+            dev = dy.device
+            dy_amax, x_amax = amax_of(dy, dy_amax), amax_of(x)
+            dx = torch.empty(R, K, dtype=torch.float32, device=dev)
+            ws, wsn = _ws(WgradChain._wsb[(N, K, R)], dev)
+            st = _stream()
+            seed = rng.seed_tensor(dev) if (drop.on or a_drop.on) else None
+            outs = (gw.data_ptr(),) if gb is None else (gw.data_ptr(), gb.data_ptr())
+            chain = not WgradStream.enabled
+            if chain:
+                job = ctypes.create_string_buffer(64)
+                prev = WgradChain._pending.pop(st, None)
+                job_addr, prev_addr = ctypes.addressof(job), (ctypes.addressof(prev[0]) if prev is not None else None)
+            else:
+                job_addr, prev_addr = ReduceQueue.splitk_slot(outs), None
+            probe = GemmProbe.armed and (GemmProbe.only is None or 8 in GemmProbe.only)
+            if probe:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib().npvp_linear_bwd_f16(R, N, K, dy.data_ptr(), dy.stride(0), dy_amax.data_ptr(), planes.data_ptr(), w_amax.data_ptr(),
+                                            dx.data_ptr(), dx.stride(0), act, _ptr(aux_in), _ptr(residual),
+                                            0 if residual is None else residual.stride(0), drop.p, drop.mode, drop.g1, drop.g2, drop.salt,
+                                            _ptr(dx_amax), x.data_ptr(), x.stride(0), x_amax.data_ptr(), gw.data_ptr(), gw.stride(0),
+                                            _ptr(gb), _ptr(RangeGuard.flag(dev)), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(seed),
+                                            prev_addr, job_addr, ws.data_ptr(), wsn, st), "npvp_linear_bwd_f16")
+            if probe:
+                e1.record()
+                GemmProbe.records.append((e0, e1, 4.0 * R * N * K, 4.0 * (2 * R * N + 2 * R * K + 2 * N * K), ((1, 0), 8)))
+            if chain:
+                if prev is not None and prev[4] is not None:
+                    GradSink.wrote(*prev[4])            # (its reduction rode in the launch just enqueued)
+                WgradChain._pending[st] = (job, ws, gw, gb, sk)
+                ReduceQueue._arm()                      # (the backward pass's end runs the last one: ReduceQueue.finish)
+            else:
+                ReduceQueue.splitk_added(outs, ws, sk)
+            return dx, None, None
+    dx = linear_dgrad(dy, w, act=act, aux_in=aux_in, drop=drop, residual=residual, dy_amax=dy_amax, dx_amax=dx_amax, a_drop=a_drop)
+    gw, gb = _lin_grads(dy, x, w, b, sk, a_drop=a_drop)
+    return dx, gw, gb
 
 
 def colsum(x):
@@ -1050,14 +1257,31 @@ def _sink_mode(sk):
     """`accumulate` argument of the norm backward entry points: 0 plain outputs, 1 accumulate into the gradient slots
     on this stream, 2 leave the partial sums in the workspace - their reduction into the slots then runs on the
     gradient stream (WgradStream), where EVERY in-place gradient write is serialised."""
-    return 0 if not sk else (2 if WgradStream.enabled else 1)
+    return 0 if not sk else (2 if (WgradStream.enabled or ReduceQueue.enabled) else 1)
 
 
 def _sunk_ln_reduce(sk, ws, rows, C):
-    if WgradStream.enabled:
+    gw, gb = sk[0][0], sk[1][0]
+    if ReduceQueue.enabled:
+        ReduceQueue.add(lib().npvp_layernorm_bwd_reduce_job, "npvp_layernorm_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1),
+                        (gw.data_ptr(), gb.data_ptr()), ws, sk)
+    elif WgradStream.enabled:
         # (deferred: every value is bound NOW, the closure runs a few launches later)
-        WgradStream.run(lambda ws=ws, gw=sk[0][0], gb=sk[1][0], rows=rows, C=C: check(
+        WgradStream.run(lambda ws=ws, gw=gw, gb=gb, rows=rows, C=C: check(
             lib().npvp_layernorm_bwd_reduce(_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1, _stream()), "npvp_layernorm_bwd_reduce"), ws, wrote=sk)
+    else:
+        GradSink.wrote(*sk)
+
+
+def _sunk_fln_reduce(sk, ws, dw, db, frames, PF):
+    """the frame-LayerNorm parameter-gradient partials left in `ws` (accumulate mode 2) -> the gradient slices"""
+    if ReduceQueue.enabled:
+        ReduceQueue.add(lib().npvp_frameln_act_bwd_reduce_job, "npvp_frameln_act_bwd_reduce_job", (_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1),
+                        (dw.data_ptr(), db.data_ptr()), ws, sk)
+    elif WgradStream.enabled:
+        WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
+            lib().npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
+            ws, wrote=sk)
     else:
         GradSink.wrote(*sk)
 
@@ -1551,12 +1775,7 @@ class _FrameLnAct(torch.autograd.Function):
                                      _ptr(ws), wsn, _stream()), "npvp_frameln_act_bwd")
         tag_amax(dh, slot)
         if sk:
-            if WgradStream.enabled:
-                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
-                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
-                    ws, wrote=sk)
-            else:
-                GradSink.wrote(*sk)
+            _sunk_fln_reduce(sk, ws, dw, db, frames, PF)
             dw = db = None
         return dh, dw, db, (dout if has_res else None), None, None, None, None, None, None
 
@@ -1706,12 +1925,7 @@ class _MlpDwbn(torch.autograd.Function):
                   "npvp_frameln_act_bwd_apply")
             HbmProbe.end(pe, "npvp::frameln_act_bwd_fused_kernel", 4.0 * 3 * frames * PF)            # reads dout, h; writes dh
         if sk:
-            if WgradStream.enabled:
-                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
-                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
-                    ws, wrote=sk)
-            else:
-                GradSink.wrote(*sk)
+            _sunk_fln_reduce(sk, ws, dw, db, frames, PF)
             return dh, None, None
         return dh, dw, db
 
@@ -1728,24 +1942,14 @@ class _MlpDwbn(torch.autograd.Function):
                                            frames, PF, d.p, d.salt, 0.0, 0, 1, _ptr(seed), _sink_mode(sk), _ptr(ws), wsn, _stream()),
               "npvp_frameln_act_bwd_pgrad")
         if sk:
-            if WgradStream.enabled:
-                WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
-                    L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
-                    ws, wrote=sk)
-            else:
-                GradSink.wrote(*sk)
+            _sunk_fln_reduce(sk, ws, dw, db, frames, PF)
             return psum, None, None
         return psum, dw, db
 
     @staticmethod
     def _lin_bwd(dy, x, w, sk, has_b):
         """dgrad on this stream, weight (+bias) gradient into the sink on the gradient stream or returned"""
-        dx = linear_dgrad(dy, w)
-        if sk and (has_b == (sk[1] is not None)):
-            _sunk_wgrad(dy, x, has_b, sk)
-            return dx, None, None
-        g = linear_wgrad(dy, x, has_b)
-        return (dx, g[0], g[1]) if has_b else (dx, g, None)
+        return linear_bwd(dy, x, w, True if has_b else None, sk)      # (`b` only says whether there is a bias gradient to take)
 
     @staticmethod
     def backward(ctx, dout):
@@ -1802,7 +2006,11 @@ class _MlpDwbn(torch.autograd.Function):
             # autograd's accumulate adds
             fn = lambda ws=ws, gw=sk_dw[0][0], gb=sk_dw[1][0], F=frames, C=hid: check(
                 L.npvp_mlpdw_mid_bwd_reduce_into(_ptr(ws), _ptr(gw), _ptr(gb), F, C, _stream()), "npvp_mlpdw_mid_bwd_reduce_into")
-            if WgradStream.enabled:
+            if ReduceQueue.enabled:
+                gw, gb = sk_dw[0][0], sk_dw[1][0]
+                ReduceQueue.add(L.npvp_mlpdw_mid_bwd_reduce_job, "npvp_mlpdw_mid_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), frames, hid),
+                                (gw.data_ptr(), gb.data_ptr()), ws, sk_dw)
+            elif WgradStream.enabled:
                 WgradStream.run(fn, ws, wrote=sk_dw)
             else:
                 fn()
@@ -1950,18 +2158,13 @@ class _SelfAttnSublayer(torch.autograd.Function):
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
         dz, ad = masked_grad(dy2, drop, wo)
-        do = linear_dgrad(dz, wo, a_drop=ad)
-        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o, a_drop=ad)
+        do, gwo, gbo = linear_bwd(dz, o, wo, bo, s_o, a_drop=ad)
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
         _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg, packed=dqk)
-        dfused = linear_dgrad(dqk, wqk)
-        gwqk, gbqk = _lin_grads(dqk, fused, wqk, bqk, s_qk)
+        dfused, gwqk, gbqk = linear_bwd(dqk, fused, wqk, bqk, s_qk)
         du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dfused, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
         # dx1 = dv Wv + du: the second consumer's gradient rides in as the dgrad GEMM's residual input (no separate add)
-        dx1 = torch.empty_like(x1)
-        gemm(1, 0, dv.shape[0], C, C, dv, dv.stride(0), wv, wv.stride(0), dx1, residual=du,
-             b_pre=_planes(wv, "D", dv.shape[0]), replay=True)
-        gwv, gbv = _lin_grads(dv, x1, wv, bv, s_v)
+        dx1, gwv, gbv = linear_bwd(dv, x1, wv, bv, s_v, residual=du)
         dx, glw, glb = _raw_ln_bwd(dx1, x2, lw, lb, lst, dy2, s_ln)
         return (dx.view(xshape), glw, glb, None, dbeta, dgamma, dadd, gwqk, gbqk, gwv, gbv, gwo, gbo, None, None, None, None)
 
@@ -1999,12 +2202,10 @@ class _CrossAttnSublayer(torch.autograd.Function):
         C = x2.shape[1]
         dy2 = _c(dy).reshape(-1, C)
         dz, ad = masked_grad(dy2, drop, wo)
-        do = linear_dgrad(dz, wo, a_drop=ad)
-        gwo, gbo = _lin_grads(dz, o, wo, bo, s_o, a_drop=ad)
+        do, gwo, gbo = linear_bwd(dz, o, wo, bo, s_o, a_drop=ad)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(q, k, v, do, dq, dk, dv, cfg)
-        dquery = linear_dgrad(dq, wq)
-        gq = _lin_grads(dq, query, wq, bq, s_q)
+        dquery, *gq = linear_bwd(dq, query, wq, bq, s_q)
         du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dquery, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
         dkey = linear_dgrad(dk, wk).view(kshape) if ctx.needs_input_grad[7] else None
         gk = _lin_grads(dk, k2, wk, bk, s_k)
@@ -2044,10 +2245,9 @@ class _FfnSublayer(torch.autograd.Function):
         dy2 = _c(dy).reshape(-1, C)
         dz2, ad = masked_grad(dy2, d3, w2)
         dh_slot = _new_slot(dy2.device)
-        dh = tag_amax(linear_dgrad(dz2, w2, act=3, aux_in=h, drop=d2, dx_amax=dh_slot, a_drop=ad), dh_slot)
-        gw2, gb2 = _lin_grads(dz2, a, w2, b2, s2, a_drop=ad)
-        dxn = linear_dgrad(dh, w1)
-        gw1, gb1 = _lin_grads(dh, xn, w1, b1, s1)
+        dh, gw2, gb2 = linear_bwd(dz2, a, w2, b2, s2, act=3, aux_in=h, drop=d2, dx_amax=dh_slot, a_drop=ad)
+        tag_amax(dh, dh_slot)
+        dxn, gw1, gb1 = linear_bwd(dh, xn, w1, b1, s1)
         dx, glw, glb = _raw_ln_bwd(dxn, x2, lw, lb, lst, dy2, s_ln)
         return dx.view(xshape), glw, glb, None, gw1, gb1, gw2, gb2, None
 

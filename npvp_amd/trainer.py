@@ -57,6 +57,7 @@ class FlatBuffers:
         # ran): hand them over and join BEFORE the buffer is cleared, so that nothing stale lands in the new step's gradients and
         # the next backward registers its own callback
         if self.flat_g.is_cuda:
+            ops.ReduceQueue.finish()
             ops.WgradStream.join()
         self.flat_g.zero_()
         for p, v in zip(self.params, self.views):
@@ -112,7 +113,8 @@ class FlatAdamW:
         self.param_groups[0]["lr"] = lr
 
     def step(self):
-        ops.WgradStream.join()               # no-op after a finished backward pass (the engine callback joined already)
+        ops.ReduceQueue.finish()             # both: no-ops after a finished backward pass (the engine callbacks ran already)
+        ops.WgradStream.join()
         self.buf.gather_stray_grads()
         L, P = lib(), ops._p
         s = P(torch.cuda.current_stream().cuda_stream)
@@ -426,31 +428,81 @@ def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, str
 
 
 class GraphedTrainStep:
-    """The whole optimisation step (forward, losses, backward incl. the gradient / auxiliary streams, clip, AdamW) captured
-    ONCE into a HIP graph and replayed per step: the host side of a step (~70 ms of Python and ~3500 launches at any
-    batch size) shrinks to one graph launch, which is what small per-GPU batches (c0: 4 clips, c3/c4: 8 clips per GPU) are
-    bound by.  Everything a replay must see differently lives in device memory: the input batch (copied into static
-    buffers), the dropout seed (bumped by a kernel inside the graph), lr / step count / clip coefficient.
+    """The whole optimisation step (forward, losses, backward, clip, AdamW, weight-plane refresh) captured ONCE into a HIP graph and
+    replayed per step: the host side of a step (1 000 - 3 000 launches and their Python at any batch size) shrinks to one graph
+    launch, which is what small per-GPU batches (c0: 4 clips, c3 / c4: 8 clips per GPU) are bound by on a slow host.  Everything a
+    replay must see differently lives in device memory: the input batch (copied into static buffers), the dropout seed (bumped by a
+    kernel inside the graph), lr / step count / clip coefficient.
+
+    single_stream (default): the step is captured WITHOUT the gradient stream - a graph with one chain of nodes replays through the
+    runtime's batched-packet path, a graph with cross-stream edges does not (measured: 62 - 77 ms against 34 ms for an 8-clip
+    step).  The overlap the second stream gives the eager step comes from inside the launches instead (grouped GEMM launches).
+
+    Range of the fp16 arithmetic (ops.RangeGuard): the weight-gradient kernels baked into the graph raise the device counter like the
+    eager ones; every `poll_every` replays the counter is copied to pinned host memory WITHOUT blocking and looked at on the next call.
+    From the first event on the step is captured again with the weight gradients in the bf16x6 arithmetic (`recaptures` counts them;
+    `range_events` is the running total) - a replayed graph cannot be switched, only re-captured.
+
     Single-process only: collectives are not captured (use the eager step with GradSync for N > 1)."""
 
-    def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3):
+    def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3,
+                 single_stream=True, poll_every=32):
         self.opt = opt
         self.past, self.fut = past_feats.clone(), future_feats.clone()
-        args = (predictor, opt, self.past, self.fut, lam_PF_L1, KL_beta, max_grad_norm)
-        side = torch.cuda.Stream(device=self.past.device)
-        side.wait_stream(torch.cuda.current_stream(self.past.device))
-        with torch.cuda.stream(side):               # eager warm-up on a side stream (lazy streams / workspaces get created)
-            for _ in range(warmup):
-                predictor_train_step(*args, sync=False)
-        torch.cuda.current_stream(self.past.device).wait_stream(side)
-        torch.cuda.synchronize(self.past.device)
-        self.graph = torch.cuda.CUDAGraph()
-        # amax slots (f16x3 GEMMs) must be zero when their tensor is produced: the captured step cuts its slots from chunks
-        # created INSIDE the capture, so their zero fill is a node of the graph and every replay starts from clean slots
-        ops.AmaxSlot.reset_chunks()
-        with torch.cuda.graph(self.graph):
-            self.out = predictor_train_step(*args, sync=False)
-        ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code)
+        self._args = (predictor, opt, self.past, self.fut, lam_PF_L1, KL_beta, max_grad_norm)
+        self.single_stream, self.poll_every, self.warmup = single_stream, max(1, int(poll_every)), warmup
+        self.replays = self.recaptures = self.range_events = 0
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._flag_event = None
+        self._capture()
+
+    def _capture(self):
+        dev = self.past.device
+        two_streams = ops.WgradStream.enabled
+        if self.single_stream:
+            ops.WgradStream.join()
+            ops.WgradStream.enabled = False
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):               # eager warm-up on a side stream (lazy streams / workspaces get created)
+                for _ in range(self.warmup):
+                    predictor_train_step(*self._args, sync=False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            # amax slots (f16x3 GEMMs) must be zero when their tensor is produced: the captured step cuts its slots from chunks
+            # created INSIDE the capture, so their zero fill is a node of the graph and every replay starts from clean slots
+            ops.AmaxSlot.reset_chunks()
+            n0 = lib().npvp_launch_count()
+            with torch.cuda.graph(self.graph):
+                self.out = predictor_train_step(*self._args, sync=False)
+            self.launches = lib().npvp_launch_count() - n0          # library launches of one step (what a replay enqueues on the device)
+            ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code)
+        finally:
+            ops.WgradStream.enabled = two_streams
+
+    def _poll_range(self):
+        """non-blocking: look at the copy issued `poll_every` replays ago; issue the next one"""
+        dev = self.past.device
+        if self._flag_event is not None and self._flag_event.query():
+            n = int(self._flag_host[0])
+            self._flag_event = None
+            if n:
+                flag = ops.RangeGuard.flag(dev)
+                flag.zero_()
+                ops.RangeGuard.events += n
+                self.range_events += n
+                if not ops.RangeGuard.fallback:
+                    ops.RangeGuard.fallback = True      # the new capture bakes the bf16x6 weight gradients in
+                    self.recaptures += 1
+                    self._capture()
+        if self._flag_event is None and self.replays % self.poll_every == 0:
+            flag = ops.RangeGuard._flags.get(dev)
+            if flag is not None:
+                self._flag_host.copy_(flag, non_blocking=True)
+                self._flag_event = torch.cuda.Event()
+                self._flag_event.record()
 
     def __call__(self, past_feats=None, future_feats=None, lr=None):
         if lr is not None:
@@ -459,6 +511,8 @@ class GraphedTrainStep:
             self.past.copy_(past_feats)
         if future_feats is not None:
             self.fut.copy_(future_feats)
+        self._poll_range()                  # (before the replay: a re-capture replaces self.out)
         ops.WeightPlanes.refresh_if_stale()
         self.graph.replay()
+        self.replays += 1
         return self.out

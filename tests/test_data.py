@@ -238,3 +238,30 @@ def test_clip_loader_end_to_end(tmp_path):
         assert torch.equal(back.round().to(torch.uint8), torch.from_numpy(np.stack([truth[(f, t0 + t)] for t in range(10)], 0)[None]).permute(0, 1, 4, 2, 3))
     with pytest.raises(RuntimeError):
         D.ClipLoader(ds, 1, mean, std, "cpu")
+
+
+def test_mnist_digits_are_resized_once_per_process(tmp_path):
+    """build_split('SMMNIST', 'train') and (..., 'val') read the same idx file: the 60 000 PIL resizes are cached"""
+    raw = tmp_path / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    imgs = np.random.default_rng(1).integers(0, 256, size=(12, 28, 28), dtype=np.uint8)
+    (raw / "train-images-idx3-ubyte").write_bytes(np.array([2051, 12, 28, 28], dtype=">i4").tobytes() + imgs.tobytes())
+    a, b = D.load_mnist_digits(tmp_path, train=True), D.load_mnist_digits(tmp_path, train=True)
+    assert a is b and not a.flags.writeable
+    assert D.StochasticMovingMNIST.sequential_draw
+
+
+@pytest.mark.gpu
+def test_smmnist_loader_is_reproducible():
+    """StochasticMovingMNIST draws every clip from ONE random stream: ClipLoader hands such a dataset to one worker thread, so two
+    loaders with the same seeds yield the same batches (with eight threads racing for the stream's lock they did not: ADVICE r4)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "smmnist.npz"))
+    runs = []
+    for _ in range(2):
+        ds = D.StochasticMovingMNIST(g["digits"], 5, 7)
+        ld = D.ClipLoader(ds, 4, 0.0, 1.0, DEV, shuffle=True, seed=11, num_workers=8, prefetch=3)
+        ld.set_epoch(2)
+        runs.append([torch.cat([p, f], 1).cpu() for (p, f), _ in zip(ld, range(3))])
+    assert len(runs[0]) == 3
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)

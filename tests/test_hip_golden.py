@@ -1,6 +1,7 @@
 """GPU: the HIP path (npvp_amd, through the C ABI) reproduces the golden vectors captured from the
 imported reference, and agrees with the oracle at larger / full BASELINE sizes.  Bar: 1e-3 rel fp32
 (BASELINE.json north_star); the fp32-MFMA GEMM path is held to 1e-4 here so regressions show early."""
+import math
 import os
 
 import pytest
@@ -222,7 +223,8 @@ def test_chained_split_k_reductions_are_bit_identical(impl):
     N, To, Tp = 8, 2, 8
     past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
     fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
-    old = ops.WgradChain.enabled
+    old, old_fused = ops.WgradChain.enabled, ops.FusedLinearBwd.enabled
+    ops.FusedLinearBwd.enabled = False          # (the fused dgrad + weight-gradient launches hand their reductions to ReduceQueue)
     flat, launches = {}, {}
     try:
         for on in (True, False):
@@ -241,7 +243,82 @@ def test_chained_split_k_reductions_are_bit_identical(impl):
         assert float(flat[True].abs().max()) > 0
         assert torch.equal(flat[True], flat[False]), f"chained vs stand-alone reductions differ: {GC.rel_err(flat[True], flat[False]):.3e}"
     finally:
-        ops.WgradChain.enabled = old
+        ops.WgradChain.enabled, ops.FusedLinearBwd.enabled = old, old_fused
+
+
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_fused_linear_backward_is_bit_identical(impl, two_streams):
+    """ops.linear_bwd: the dgrad and the weight gradient of a linear layer in ONE launch (npvp_linear_bwd_f16: the same two kernel
+    bodies on disjoint workgroups, the split-K reduction queued for the gradient stream - or, single stream, riding in the next fused
+    launch) against the two launches on two streams.  Same tiles, same split counts, same summation order: the flat gradient of a
+    whole step (4 096 decoder token rows, dropout and drop-path on) must be bit-identical, with and without a gradient stream."""
+    from npvp_amd import ops
+    if MODE != "f16x3":
+        pytest.skip("the fused launch belongs to the fp16 kernels")
+    N, To, Tp = 8, 2, 8
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+    old = (ops.FusedLinearBwd.enabled, ops.WgradStream.enabled)
+    flat, launches = {}, {}
+    try:
+        ops.WgradStream.join()
+        ops.WgradStream.enabled = two_streams
+        for on in (True, False):
+            ops.FusedLinearBwd.enabled = on
+            m = GC._small_predictor(impl, False, 101, DEV, To=To, Tp=Tp, dropout=0.1, drop_path=0.1)
+            m.train()
+            opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+            ops.rng.manual_seed(777, torch.device(DEV))
+            ops.rng.begin_step(torch.device(DEV))
+            opt.zero_grad()
+            n0 = impl._lib.lib().npvp_launch_count()
+            (m(past) - fut).abs().mean().backward()
+            ops.WgradStream.join()
+            torch.cuda.synchronize()
+            launches[on] = impl._lib.lib().npvp_launch_count() - n0
+            assert not ops.WgradChain._pending and not ops.ReduceQueue.pending(), "a deferred reduction was left behind"
+            flat[on] = opt.flat_g.clone()
+        assert float(flat[True].abs().max()) > 0
+        assert launches[True] < launches[False], launches
+        assert torch.equal(flat[True], flat[False]), f"fused vs two launches: {GC.rel_err(flat[True], flat[False]):.3e}"
+    finally:
+        ops.FusedLinearBwd.enabled, ops.WgradStream.enabled = old
+
+
+def test_deferred_parameter_gradient_reductions(impl):
+    """ops.ReduceQueue: the LayerNorm / frame-LayerNorm / depthwise parameter-gradient partials summed by a few npvp_sum_rows_multi
+    launches when the backward pass ends, against one reduction launch per site (same partials, a different split of the partial
+    rows over a block's threads: equal to rounding)."""
+    from npvp_amd import ops
+    N, To, Tp = 2, 3, 4
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+    old = ops.ReduceQueue.enabled
+    flat, launches = {}, {}
+    try:
+        for on in (True, False):
+            ops.ReduceQueue.enabled = on
+            m = GC._small_predictor(impl, True, 101, DEV, To=To, Tp=Tp, dropout=0.0, drop_path=0.0)      # NPVP-S: the encoder runs twice
+            m.train()
+            opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+            ops.rng.manual_seed(777, torch.device(DEV))
+            ops.rng.begin_step(torch.device(DEV))
+            opt.zero_grad()
+            torch.manual_seed(5)
+            n0 = impl._lib.lib().npvp_launch_count()
+            out = m(past, fut)
+            (out[0] - fut).abs().mean().backward()
+            ops.WgradStream.join()
+            torch.cuda.synchronize()
+            launches[on] = impl._lib.lib().npvp_launch_count() - n0
+            assert not ops.ReduceQueue.pending()
+            flat[on] = opt.flat_g.clone()
+        assert launches[True] < launches[False] - 20, launches
+        assert GC.rel_err(flat[True], flat[False]) < 1e-6
+        n = flat[True].numel() // 1024 * 1024         # chunk by chunk: no gradient slice was skipped or doubled
+        assert GC.max_row_rel_err(flat[True][:n].view(-1, 1024), flat[False][:n].view(-1, 1024), 1e-9) < 1e-4
+    finally:
+        ops.ReduceQueue.enabled = old
 
 
 @pytest.mark.parametrize("which", ["dual_encoder", "decoder_split"])
@@ -420,9 +497,11 @@ def test_training_step_is_bitwise_deterministic(impl):
     assert digests[0] == digests[1]
 
 
-def test_graphed_step_equals_eager(impl):
-    """GraphedTrainStep (the whole optimisation step captured into a HIP graph, gradient stream included) replays to the
-    same parameters as the eager step; the dropout seed, lr and step count live in device memory."""
+@pytest.mark.parametrize("single_stream", [True, False])
+def test_graphed_step_equals_eager(impl, single_stream):
+    """GraphedTrainStep (the whole optimisation step captured into a HIP graph - on one stream, the default, or with the gradient
+    stream inside the capture) replays to the same parameters as the eager step; the dropout seed, lr and step count live in
+    device memory."""
     past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
     runs = {}
     for graphed in (False, True):
@@ -431,7 +510,8 @@ def test_graphed_step_equals_eager(impl):
         opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
         impl.ops.rng.manual_seed(77, torch.device(DEV))
         if graphed:
-            step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1)
+            step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1, single_stream=single_stream)
+            assert step.launches > 100
             # the warm-up and the capture executed steps of their own: rewind to the same starting point
             O.key_hashed_fill(m, 181)
             opt.m.zero_(); opt.v.zero_(); opt.hyper[1:2].zero_()
@@ -447,6 +527,39 @@ def test_graphed_step_equals_eager(impl):
     assert abs(le - lg) <= 1e-5 * abs(le), (le, lg)
     err = float((pe - pg).norm() / pe.norm())
     assert err < 1e-6, f"graph replay vs eager parameters after 3 steps: rel-L2 {err:.3e}"
+
+
+def test_graphed_step_polls_the_range_guard(impl):
+    """A replayed graph cannot be switched to the bf16x6 weight gradients, and nobody reads the range counter inside a replay
+    loop: GraphedTrainStep copies the counter to pinned memory every `poll_every` replays without blocking and, on an
+    event, captures the step again with RangeGuard.fallback set.  The event is injected here (real training tensors never raise
+    it: profiles/r04_f16_range_audit.txt)."""
+    if MODE != "f16x3":
+        pytest.skip("the range guard belongs to the fp16 arithmetic")
+    RG = impl.ops.RangeGuard
+    RG.reset()
+    past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
+    m = GC._small_predictor(impl, False, 181, DEV, evt_layers=1, dec_layers=1, dropout=0.0, drop_path=0.0)
+    m.train()
+    opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+    try:
+        step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1, poll_every=1)
+        step(); step()
+        torch.cuda.synchronize()
+        assert step.recaptures == 0 and step.range_events == 0
+        RG.flag(torch.device(DEV)).fill_(3)              # three weight-gradient launches met an out-of-range feature
+        step()                                           # issues the copy of the counter
+        torch.cuda.synchronize()
+        out = step()                                     # sees it: re-captures with the bf16x6 weight gradients, replays
+        torch.cuda.synchronize()
+        assert step.recaptures == 1 and step.range_events == 3 and RG.fallback and RG.events == 3
+        assert int(RG.flag(torch.device(DEV)).item()) == 0
+        assert math.isfinite(float(out["loss"]))
+        step(); step()
+        torch.cuda.synchronize()
+        assert step.recaptures == 1                      # (sticky: nothing further to switch)
+    finally:
+        RG.reset()
 
 
 def test_predictor_full_depth(impl):

@@ -1,0 +1,65 @@
+#!/bin/bash
+# Round-5 profile set, run on the GPU box from the repo root:  bash tools/profile_r05.sh <step> [<step> ...]
+# Writes under gpurun_out/r05/ (summaries copied to profiles/r05_* afterwards).  Counter passes carry no other tracing domain and
+# the profiled program stands directly after `--`.
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/r05"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+QUIET="--no-secondary --no-cpu-baseline --no-probe"
+
+for STEP in "$@"; do
+case "$STEP" in
+bench)      # the default command, as the driver runs it
+  python3 $ROOT/bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
+  tail -c 1500 "$OUT/bench_default.json" ;;
+mfma)       # BASELINE's "MFMA util %": one --pmc pass per workload, the bench record beside it for the unprofiled step time
+  for W in c2p c2; do
+    python3 $ROOT/bench.py --workload $W --steps 6 --warmup 3 $QUIET > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err" || exit 1
+    MS=$(python3 -c "import json,sys; print(json.load(open('$OUT/bench_$W.json'))['ms_per_step'])")
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/mu_$W" -o $W -- python3 $ROOT/bench.py --workload $W --steps 3 --warmup 2 $QUIET > /dev/null 2> "$OUT/mu_$W.err" || exit 1
+    python3 $ROOT/tools/rocpd_mfma_util.py $(ls "$OUT"/mu_$W/*.db | head -1) --steps 3 --ms $MS --workload $W --out "$OUT/mfma_util_$W.md" --json "$OUT/mfma_util_$W.json" | head -12
+    rm -rf "$OUT/mu_$W"
+  done ;;
+graphs)     # the 8-clip shards and c0: eager / single-stream graph / two-stream graph (and the runtime's graph knobs)
+  for W in c4 c3 c0; do
+    python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET 2>&1 | grep -E "timed steps|metric" | cut -c1-400 > "$OUT/g_${W}_eager.txt"
+    python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph1.txt"
+    cat "$OUT/g_${W}_eager.txt" "$OUT/g_${W}_graph1.txt" | grep "timed steps"
+  done
+  W=c4
+  NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2.txt"
+  DEBUG_HIP_FORCE_GRAPH_QUEUES=2 NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q2.txt"
+  DEBUG_HIP_FORCE_GRAPH_QUEUES=1 NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q1.txt"
+  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph1_nocap.txt"
+  grep -H "timed steps" "$OUT"/g_${W}_graph*.txt ;;
+shard)      # kernel trace of the 8-clip shard (c4): eager and graph replay
+  rocprofv3 --kernel-trace -d "$OUT/kt4" -o c4 -- python3 $ROOT/bench.py --steps 7 --warmup 3 --workload c4 $QUIET > "$OUT/bench_c4_profiled.json" 2> "$OUT/kt4.err"
+  python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt4/*.db | head -1) "$OUT/kernel_stats_c4shard.csv" > /dev/null
+  python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt4/*.db | head -1) 5 "$OUT/streams_c4shard.md" > /dev/null
+  rm -rf "$OUT/kt4"
+  rocprofv3 --kernel-trace -d "$OUT/kt4g" -o c4 -- python3 $ROOT/bench.py --steps 7 --warmup 3 --workload c4 $QUIET --graph > "$OUT/bench_c4_graph_profiled.json" 2> "$OUT/kt4g.err"
+  python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt4g/*.db | head -1) "$OUT/kernel_stats_c4shard_graph.csv" > /dev/null
+  python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt4g/*.db | head -1) 5 "$OUT/streams_c4shard_graph.md" > /dev/null
+  rm -rf "$OUT/kt4g"
+  head -12 "$OUT/streams_c4shard_graph.md" ;;
+c2trace)    # kernel trace + stream view of the primary workload
+  rocprofv3 --kernel-trace -d "$OUT/kt" -o c2 -- python3 $ROOT/bench.py --steps 3 --warmup 2 $QUIET > "$OUT/bench_c2_profiled.json" 2> "$OUT/kt.err"
+  python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2.csv" > /dev/null
+  python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2_by_grid.csv" --by-grid > /dev/null
+  python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt/*.db | head -1) 2 "$OUT/streams_c2.md" > /dev/null
+  rm -rf "$OUT/kt"
+  head -30 "$OUT/streams_c2.md" ;;
+traffic)    # HBM-side traffic of the primary workload (separate FETCH_SIZE / WRITE_SIZE passes)
+  BENCH="python3 $ROOT/bench.py --steps 3 --warmup 2 $QUIET"
+  rocprofv3 --pmc FETCH_SIZE -d "$OUT/pf" -o c2 -- $BENCH > /dev/null 2> "$OUT/pf.err"
+  rocprofv3 --pmc WRITE_SIZE -d "$OUT/pw" -o c2 -- $BENCH > /dev/null 2> "$OUT/pw.err"
+  python3 $ROOT/tools/rocpd_traffic.py $(ls "$OUT"/pf/*.db | head -1) $(ls "$OUT"/pw/*.db | head -1) "$OUT/hbm_traffic_c2.md" "$OUT/hbm_traffic_c2.json" > /dev/null
+  rm -rf "$OUT/pf" "$OUT/pw" ;;
+gemm)       # GEMM micro-benchmarks
+  python3 $ROOT/tools/gemm_bench.py --mode f16x3 --rows 114688 20480 8192 --check > "$OUT/gemm_bench_f16x3.txt" 2>/dev/null
+  tail -8 "$OUT/gemm_bench_f16x3.txt" ;;
+*) echo "unknown step $STEP"; exit 2 ;;
+esac
+done
