@@ -144,7 +144,15 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None, mode="eager"):
+def run_workload(key, *a, **kw):
+    """one workload = one trainer = one scheduling context (npvp_amd.sched.StepContext: dropout stream, gradient-stream queue, deferred
+    reductions, data-parallel listener, range guard): nothing of it outlives the workload or is shared with the next one"""
+    from npvp_amd import ops
+    with ops.use(ops.StepContext(key)):
+        return _run_workload(key, *a, **kw)
+
+
+def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None, mode="eager"):
     """Build the workload's model / optimiser / synthetic batch, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict.  world = 1 inside a multi-rank job =
     a SOLO run of the calling rank (no collectives, no barrier): the one-GPU denominators of `scaling_dp`.

@@ -63,7 +63,7 @@ int npvp_stream_destroy(void* stream);
  * comes with an AMAX SLOT (2 KB of device memory holding 32 words whose maximum bounds |operand|; see npvp_amax) and is scaled by the power
  * of two that puts the bound into [2^14, 2^15) - exact, undone in the epilogue.  It is taken by (a) a_kc = 1 launches with
  * fp16 planes in `b_pre` (npvp_split_weight_f16) and both a_amax / b_amax, (b) weight gradients (a_kc = b_kc = 0, plain
- * epilogue, K >= 4096) with both slots; every other launch with precision 6 runs as precision 4 without planes.
+ * epilogue, K >= 1024) with both slots; every other launch with precision 6 runs as precision 4 without planes.
  * c_amax (nullable, any precision, unsplit launches): the kernel adds the bound of the values it stores to C to that slot -
  * the next GEMM's a_amax, at no extra pass.
  * Kernels: gemm_wide_kernel (128 x 256 tiles, 4 waves, A split on the fly, B = pre-split planes `b_pre` copied by LDS-DMA:
@@ -155,7 +155,7 @@ int npvp_splitk_reduce_multi(const void* jobs, int n, npvp_stream_t stream);
  * (nullable) - and the weight-gradient half as npvp_wgrad_f16_chained takes them (always accumulating; its split-K reduction is
  * handed on in my_job, the previous launch's comes in prev_job; npvp_splitk_reduce_job runs the last one).
  * npvp_linear_bwd_f16_takes(R, N, K): 1 when the pair is taken - a small-tile dgrad (fewer than 512 tiles of 128 x 256) and a
- * chainable weight gradient (R >= 4096); everything else stays two launches. */
+ * chainable weight gradient (R >= 1024); everything else stays two launches. */
 int npvp_linear_bwd_f16_takes(int R, int N, int K);
 int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long long ldy, const float* dy_amax, const void* w_planes_d,
                         const float* w_amax, float* dx, long long ldx, int act, const float* aux_in, const float* residual,

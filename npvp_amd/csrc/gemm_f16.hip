@@ -586,13 +586,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void gemm_wgrad_f16_ke
 // dealt round-robin over the 8 XCDs, and both bodies map block index -> tile by XCD.
 struct GemmGroup { GemmParams p[2]; int first[3]; int count[2]; int gx; };
 
-template <int TN>
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void gemm_f16_group_kernel(GemmGroup g) {
-  constexpr int L0 = gemm_f16_lds_bytes<2, TN, 2, 2, 3>();
+  constexpr int L0 = gemm_f16_lds_bytes<TM, TN, 2, 2, 3>();
   __shared__ __attribute__((aligned(16))) char lds[L0 > GEMM_WGRAD_F16_LDS_BYTES ? L0 : GEMM_WGRAD_F16_LDS_BYTES];
   const int b = blockIdx.x;
   if (b < g.first[1]) {
-    if (b < g.count[0]) gemm_f16_body<2, TN, 2, 2, false, 3>(g.p[0], lds, b, g.count[0]);
+    if (b < g.count[0]) gemm_f16_body<TM, TN, 2, 2, false, 3>(g.p[0], lds, b, g.count[0]);
   } else {
     const int lb = b - g.first[1];
     if (lb < g.count[1]) {
@@ -602,9 +602,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_group_kernel(GemmGroup g) {
   }
 }
 
-// split count of the fp16 weight-gradient kernel: ~512 workgroups, >= 16 K-steps per split; 0 = shape not taken
+// split count of the fp16 weight-gradient kernel: ~512 workgroups, >= 16 K-steps per split; 0 = shape not taken.  From 1 024 token
+// rows (round 5; 4 096 before): the encoder of an 8-clip shard (1 024 - 2 048 rows) then takes the chained / fused route instead of
+// the 128 x 128 bf16 kernel + a split-K reduction launch + a column-sum launch per weight gradient.
 int f16_wgrad_splits(int M, int N, int K) {
-  if ((K & 15) || M < 64 || N < 128 || K < 4096) return 0;
+  if ((K & 15) || M < 64 || N < 128 || K < 1024) return 0;
   const int tiles = ((M + 127) / 128) * ((N + 255) / 256);
   const int want = 512;                 // workgroups per launch (256 / 384 / 1024 measured within noise of it: DESIGN.md section 5)
   int s = (want + tiles - 1) / tiles;
@@ -637,11 +639,19 @@ bool launch_gemm_wgrad_f16(GemmParams& p, int splits, hipStream_t stream) {
 }
 
 // forward / dgrad with scaled fp16 planes: 1 = 128 x 256 tiles, 2 = 128 x 128 tiles (outputs that 128 x 256 tiles do not
-// fill the chip with), 3 = 128 x 64 tiles (outputs of at most 128 tiles of 128 x 128), 0 = shape not taken (the caller falls back to the three-term bf16 kernels WITHOUT planes)
+// fill the chip with), 4 = 64 x 128 tiles (outputs of at most 256 tiles of 128 x 128), 3 = 128 x 64 tiles (the same for row counts
+// that are not a multiple of 64, at most 128 tiles), 0 = shape not taken (the caller falls back to the three-term bf16 kernels WITHOUT planes)
 int gemm_f16_variant(int M, int N, int K) {
   if ((K & 15) || (N & 7) || M < 128) return 0;
   const int tw = ((M + 127) / 128) * ((N + 255) / 256);
   if (N % 128 != 0 || tw >= 512) return 1;
+  // up to 256 tiles of 128 x 128 (every [R x 512] output of an 8-clip shard, its whole encoder) half the chip or more would hold
+  // one workgroup per CU - one wave per SIMD with nothing to hide a barrier or an LDS-DMA round trip behind: 64 x 128 tiles double
+  // the workgroups at the SAME operand-split work per MFMA (the A rows a workgroup splits halve with its MFMAs; only the weight's
+  // LDS-DMA, which costs no VALU, doubles).  Round 5, tools/gemm_bench.py over the five layer shapes, forward / dgrad TF: 8 192 rows
+  // 259 -> 265, 4 096 rows 187 -> 212, 2 048 rows 114 -> 137 (there against round 4's 128 x 64 tiles, which double the A split
+  // instead: profiles/r05_gemm_bench_tiles.txt); above 256 tiles no gain.
+  if (M % 64 == 0 && ((M + 127) / 128) * (N / 128) <= 256) return 4;
   // up to 128 tiles of 128 x 128 (the encoder of an 8-clip shard: 1 024 .. 2 048 token rows) half the chip would idle: 128 x 64
   // tiles double the workgroups (R = 2 048: forward 18.8 -> 15.4 us at N = K = 512, 58 -> 49 us at K = 2 048; from 256 tiles on the
   // narrow tile loses - the A staging per MFMA doubles - profiles/r04_gemm_bench_narrow.txt)
@@ -650,13 +660,14 @@ int gemm_f16_variant(int M, int N, int K) {
 }
 
 // the tiling of a forward / dgrad launch: -> variant (0 = not taken), p.tiles_* / p.colgroups set for it
-static int prep_gemm_f16(GemmParams& p) {
+static int prep_gemm_f16(GemmParams& p, int v128 = 0) {
   if (!p.b_pre || !p.a_amax || !p.b_amax || p.splits != 1 || p.colsum || ((uintptr_t)p.b_pre & 15) != 0) return 0;
   if (p.adrop.thresh && (p.adrop.mode != 1 || !p.seed)) return 0;
-  const int v = gemm_f16_variant(p.M, p.N, p.K);
+  int v = gemm_f16_variant(p.M, p.N, p.K);
+  if (v == 4 && v128) v = 2;                         // (the caller wants 128 x 128 tiles where 64 x 128 would be taken)
   if (v == 0 || (p.rowstats && (p.N % 64 != 0 || p.M % 64 != 0))) return 0;
   const int bn = v == 1 ? 256 : (v == 3 ? 64 : 128);
-  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_m = v == 4 ? (p.M + 63) / 64 : (p.M + 127) / 128;
   p.tiles_n = (p.N + bn - 1) / bn;
   p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n);
   return v;
@@ -671,7 +682,10 @@ bool launch_gemm_f16(GemmParams& p, hipStream_t stream) {
     else NPVP_LAUNCH((gemm_f16_kernel<2, 4, 2, 2, false>), grid, block, 0, stream, p);
   } else if (v == 3 && !p.rowstats) {
     NPVP_LAUNCH((gemm_f16_kernel<2, 1, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
+  } else if (v == 4 && !p.rowstats) {
+    NPVP_LAUNCH((gemm_f16_kernel<1, 2, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
   } else {
+    if (v == 4) { p.tiles_m = (p.M + 127) / 128; grid = dim3(p.tiles_m * p.tiles_n); p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n); }
     if (v == 3) { p.tiles_n = (p.N + 127) / 128; grid = dim3(p.tiles_m * p.tiles_n); p.colgroups = pick_colgroups((long long)p.N * p.K * 4, p.tiles_m, p.tiles_n); }
     if (p.rowstats) NPVP_LAUNCH((gemm_f16_kernel<2, 2, 2, 2, true, 2, 3>), grid, block, 0, stream, p);
     else NPVP_LAUNCH((gemm_f16_kernel<2, 2, 2, 2, false, 2, 3>), grid, block, 0, stream, p);
@@ -825,7 +839,7 @@ extern "C" int npvp_wgrad_f16_chained(int M, int N, int K, const float* dy, long
 // ---- dgrad + weight gradient of one linear layer in ONE launch (gemm_f16_group_kernel; include/npvp_hip.h) ---------------------------
 extern "C" int npvp_linear_bwd_f16_takes(int R, int N, int K) {
   const int v = gemm_f16_variant(R, K, N);
-  return ((v == 2 || v == 3) && npvp_wgrad_f16_chainable(N, K, R)) ? 1 : 0;
+  return ((v == 2 || v == 3 || v == 4) && npvp_wgrad_f16_chainable(N, K, R)) ? 1 : 0;
 }
 
 extern "C" int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long long ldy, const float* dy_amax, const void* w_planes_d,
@@ -856,10 +870,14 @@ extern "C" int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long lo
   d.adrop = make_drop_spec(adrop_p, adrop_salt, 1, adrop_g1, adrop_g2);
   d.b_pre = w_planes_d; d.b_pre_plane = (long long)N * K;
   d.a_amax = dy_amax; d.b_amax = w_amax; d.c_amax = dx_amax;
-  const int v = prep_gemm_f16(d);
-  NPVP_CHECK_ARG(v == 2 || v == 3, "linear_bwd_f16: the dgrad is not a small-tile launch");
   // problem 1: dW[N][K] (+)= dy^T x over R rows, split-K, reduction handed to the next launch (npvp_wgrad_f16_chained)
   const int sh = f16_wgrad_splits(N, K, R);
+  // the dgrad's tiles: 64 x 128 where the launch then still fits the chip's 512 workgroup slots with the weight gradient's
+  // workgroups beside it, else 128 x 128 (8 192 rows: 256 + 256 workgroups in one round beat 512 + 256 in one and a half -
+  // profiles/r05_linear_bwd_bench.txt)
+  const int t128 = ((R + 127) / 128) * ((K + 127) / 128), wwg = ((N + 127) / 128) * ((K + 255) / 256) * sh;
+  const int v = prep_gemm_f16(d, 2 * t128 + wwg > 512 ? 1 : 0);
+  NPVP_CHECK_ARG(v == 2 || v == 3 || v == 4, "linear_bwd_f16: the dgrad is not a small-tile launch");
   GemmParams& w = g.p[1];
   w.A = dy; w.B = x; w.lda = ldy; w.ldb = ldxx; w.M = N; w.N = K; w.K = R / sh; w.alpha = 1.f;
   w.C = (float*)workspace; w.ldc = K; w.splits = sh; w.colgroups = 1; w.accum = 1;
@@ -877,8 +895,9 @@ extern "C" int npvp_linear_bwd_f16(int R, int N, int K, const float* dy, long lo
   g.count[1] = tiles * (sh + rr);
   g.first[2] = g.first[1] + ((g.count[1] + 7) & ~7);
   g.gx = tiles;
-  if (v == 2) NPVP_LAUNCH(gemm_f16_group_kernel<2>, dim3(g.first[2]), dim3(256), 0, stream, g);
-  else NPVP_LAUNCH(gemm_f16_group_kernel<1>, dim3(g.first[2]), dim3(256), 0, stream, g);
+  if (v == 2) NPVP_LAUNCH((gemm_f16_group_kernel<2, 2>), dim3(g.first[2]), dim3(256), 0, stream, g);
+  else if (v == 4) NPVP_LAUNCH((gemm_f16_group_kernel<1, 2>), dim3(g.first[2]), dim3(256), 0, stream, g);
+  else NPVP_LAUNCH((gemm_f16_group_kernel<2, 1>), dim3(g.first[2]), dim3(256), 0, stream, g);
   NPVP_CHECK_LAUNCH();
   ReduceJob mine = {(const float*)workspace, dw, ldw, N, K, sh, 1, 1.f, 0, db ? w.colsum : nullptr, db};
   *reinterpret_cast<ReduceJob*>(my_job) = mine;

@@ -223,6 +223,13 @@ struct MidN2 {
   const unsigned long long* seed; unsigned int drop_thresh; float drop_inv_keep; unsigned int salt;
 };
 
+// Round 5 measured a different thread map for the FUSE2 form - the 8 pixel columns on 8 lanes (neighbours by DPP row shifts), four
+// channels per thread, float4 loads (7 per row instead of 56 dword loads), no block-wide barrier at all - in the belief that this
+// kernel is bound by its 448 load instructions per frame and its four barriers per frame.  It is not: bit-for-bit the same results,
+// 203 VGPRs, and the layer's backward went 5.04 -> 5.43 ms at the c2 size (profiles/r05_mlpdw_mid_bwd_cols.txt).  The kernel
+// executes ~110 vector instructions per element (two GELU' evaluations and one GELU with their exponentials and reciprocals, the
+// mask hash, 18 tap multiply-adds): 0.92 M elements per CU x 110 / 64 lanes per cycle = 1.6 M cycles = 0.9 ms at 1.7 GHz - what
+// it takes.  It is VALU bound; only fewer instructions per element would move it.  The column-lane kernel is in the git history.
 template <int VEC, bool FUSE2>
 __global__ __launch_bounds__(256, NPVP_MID_BWD_WAVES) void mlpdw_mid_bwd_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
                                                             const float* __restrict__ mean1, const float* __restrict__ rstd1,

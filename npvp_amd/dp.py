@@ -74,11 +74,14 @@ def broadcast_module(module, src=0):
 class GradSync:
     """Bucketed, overlapped all-reduce(mean) of a FlatBuffers gradient buffer."""
 
-    def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20):
+    def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20, ctx=None):
+        """ctx: the trainer's sched.StepContext (FlatAdamW.ctx) whose gradient sink reports contributions to this object and whose
+        gradient stream the bucket all-reduces are ordered after; default: the context current at construction"""
         self.buf, self.group = buf, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on = active(group)                 # (one rank with NPVP_DP_FORCE=1 runs the whole machinery on a group of one)
         from . import ops
+        self.ctx = ctx if ctx is not None else ops.current()
         if self.on and ops.AuxStream.enabled:
             # a bucket's all-reduce is ordered after the compute stream and the gradient stream only: contributions
             # produced on the auxiliary encoder stream (NPVP_DUAL_ENCODER=1) could land after it
@@ -119,8 +122,7 @@ class GradSync:
         if self.on:
             for p in buf.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
-            from . import ops
-            ops.GradSink.listener = self._hook
+            self.ctx.grad_sink.listener = self._hook
         self.launched = 0
 
     def _hook(self, p):
@@ -142,8 +144,7 @@ class GradSync:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
-            from . import ops
-            gs = ops.WgradStream.pending_stream()           # weight gradients are accumulated on their own stream
+            gs = self.ctx.wgrad.pending_stream()            # weight gradients are accumulated on their own stream
             if gs is not None:
                 self.side.wait_stream(gs)
             with torch.cuda.stream(self.side):
@@ -227,9 +228,8 @@ class GradSync:
     def remove(self):
         for h in self._handles:
             h.remove()
-        from . import ops
-        if ops.GradSink.listener == self._hook:
-            ops.GradSink.listener = None
+        if self.ctx.grad_sink.listener == self._hook:
+            self.ctx.grad_sink.listener = None
 
 
 _SYNCBN_GROUP = None

@@ -70,26 +70,7 @@ class Predictor(nn.Module):
         """z [N, H*W, C] canonical"""
         N, T1, H, W, C = memory.shape
         zc = z.view(N, H, W, C)
-        if ops.DecoderSplit.wanted(N, self.TP) and memory.is_cuda:
-            # Two half-batches through the decoder on two HIP streams (samples are independent inside the decoder: the only
-            # batch coupling of the path, the EventEncoder's BatchNorm, lies in front of it).  The forward and - because
-            # autograd replays a node on the stream of its forward - the backward chains of the two halves interleave, so
-            # the HBM-bound kernels of one half can run under the MFMA-bound GEMMs of the other.
-            dev = memory.device
-            main, aux = torch.cuda.current_stream(dev), ops.AuxStream.stream(dev)
-            half = N // 2
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                o1 = self.transformer.forward_canonical(zc[half:], memory[half:], op, pp, self.fuser, self.TP)
-            for t in (zc, memory, op[0], pp[0]) + tuple(x for x in (op[1], pp[1]) if x is not None):
-                t.record_stream(aux)
-            o0 = self.transformer.forward_canonical(zc[:half], memory[:half], op, pp, self.fuser, self.TP)
-            main.wait_stream(aux)
-            o1.record_stream(main)
-            out = torch.cat([o0, o1], dim=0)
-        else:
-            return self.transformer.forward_canonical(zc, memory, op, pp, self.fuser, self.TP, nchw=True)
-        return ops.canonical_to_nchw(out, N, self.TP, H, W)
+        return self.transformer.forward_canonical(zc, memory, op, pp, self.fuser, self.TP, nchw=True)
 
     def _nchw(self, t):
         N, P, C = t.shape

@@ -9,64 +9,10 @@ import os
 import torch
 
 from ._lib import lib, check
-
-_p = ctypes.c_void_p
-
-
-def _ptr(t):
-    """device address as a plain int (None -> NULL): the ctypes prototypes declare c_void_p, which takes either"""
-    return None if t is None else t.data_ptr()
-
-
-class AmaxSlot:
-    """One amax slot (2 KB of device memory: 32 words, 64 bytes apart, see include/npvp_hip.h): the bound of |x| over a tensor
-    that feeds a precision-6 GEMM.  Slots are cut from zero-filled chunks (one torch.zeros per 1024 slots); a slot keeps its
-    chunk alive, so a saved-for-backward slot is valid until the node that holds it is freed.
-
-    One current chunk per (device, STREAM): the chunk's zero fill is enqueued on the stream that cuts the slots, so it is ordered
-    before every producer's atomic max and every consumer's read on that stream (autograd replays a node on the stream of its
-    forward; streams that consume a tensor produced elsewhere are ordered behind its producer by the caller's wait_stream, which
-    covers the slot too).  A chunk is also protected from allocator reuse on every side stream this module runs (gradient stream,
-    auxiliary stream) and on the device's default stream - its slots may be read there after the cutting stream has moved on."""
-    __slots__ = ("ptr", "chunk")
-    CHUNK, BYTES, FLOATS = 1024, 2048, 512
-    _cur = {}                 # (device index, raw stream) -> [chunk, next slot]
-
-    def __init__(self, ptr, chunk):
-        self.ptr, self.chunk = ptr, chunk
-
-    def data_ptr(self):
-        return self.ptr
-
-    def read(self):
-        """host value (synchronises; tests and diagnostics only)"""
-        i = (self.ptr - self.chunk.data_ptr()) // self.BYTES
-        return float(self.chunk.view(-1, self.FLOATS)[i].max())
-
-    @classmethod
-    def reset_chunks(cls):
-        """forget the current chunks (a HIP-graph capture cuts its slots from chunks created INSIDE the capture)"""
-        cls._cur = {}
-
-    @classmethod
-    def new(cls, dev):
-        key = (dev.index, _stream())             # (one C call; the tensors of this module live on the current device)
-        st = cls._cur.get(key)
-        if st is None or st[1] >= cls.CHUNK:
-            cur = torch.cuda.current_stream(dev)
-            ch = torch.zeros(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev)
-            others = [torch.cuda.default_stream(dev)]
-            if WgradStream.enabled:
-                others.append(WgradStream.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
-            if AuxStream.enabled or DecoderSplit.enabled:
-                others.append(AuxStream.stream(dev))
-            for o in others:
-                if o.cuda_stream != cur.cuda_stream:
-                    ch.record_stream(o)
-            st = cls._cur[key] = [ch, 0]
-        s = cls(st[0].data_ptr() + cls.BYTES * st[1], st[0])
-        st[1] += 1
-        return s
+# scheduling state (per trainer: sched.StepContext) and the process-wide pieces beside it; re-exported here because the rest of the
+# package, the tests and the tools reach them as ops.<name>
+from .sched import (_p, _ptr, _stream, _ws, AmaxSlot, GemmProbe, HbmProbe, AuxStream, StepContext, current, use, scoped,
+                    remember, rng, GradSink, WgradStream, WgradChain, ReduceQueue, RangeGuard)
 
 
 def amax_of(t, slot=None):
@@ -100,17 +46,6 @@ def _row(t, i):
     return t.data_ptr() + 4 * i * t.stride(0)
 
 
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device      # (the C call, without the lazy-init checks)
-
-
-def _stream():
-    """the calling thread's current HIP stream as a raw handle (one C call: this runs once per kernel launch)"""
-    if _raw_stream is not None:
-        return _raw_stream(_cur_dev())
-    return torch.cuda.current_stream().cuda_stream
-
-
 def _chk(*ts):
     for t in ts:
         if t is None:
@@ -125,42 +60,7 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _ws(nbytes, dev):
-    n = max(int(nbytes), 16)
-    return torch.empty((n + 3) // 4, dtype=torch.float32, device=dev), n
-
-
 # --------------------------------------------------------------------------- dropout state
-class _RngState:
-    """Device seed + per-call-site salt counter for the in-kernel counter-hash dropout masks.
-    `begin_step()` bumps the device seed (a captured graph replays that bump) and restarts the
-    salt counter, so eager and graph-replayed steps draw identical mask streams."""
-
-    def __init__(self):
-        self.seed = None
-        self.salt = 0
-
-    def seed_tensor(self, dev):
-        if self.seed is None or self.seed.device != dev:
-            self.seed = torch.full((1,), 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF, dtype=torch.int64, device=dev)
-        return self.seed
-
-    def manual_seed(self, s, dev):
-        self.seed_tensor(dev).fill_(int(s) & 0x7FFFFFFFFFFFFFFF)
-        self.salt = 0
-
-    def begin_step(self, dev):
-        self.seed_tensor(dev).add_(0x632BE5AB)
-        self.salt = 0
-
-    def next_salt(self):
-        self.salt += 1
-        return self.salt
-
-
-rng = _RngState()
-
-
 class Drop:
     """A dropout / drop-path site: probability, keying mode (0 element, 1 row group) and salt."""
     __slots__ = ("p", "mode", "g1", "g2", "salt")
@@ -267,9 +167,10 @@ class WeightPlanes:
         cls._dirty = True
 
     @classmethod
-    def invalidate(cls):
-        """the parameters changed under the planes (optimiser step): re-split everything now"""
-        cls.refresh_all()
+    def invalidate(cls, owner=None):
+        """the parameters changed under the planes (optimiser step): re-split now - every registered weight, or those that are
+        views of `owner` (a trainer's flat parameter buffer: another trainer's planes are still current)"""
+        cls.refresh_all(owner)
 
     @classmethod
     def forget(cls, owner):
@@ -359,17 +260,18 @@ class WeightPlanes:
     epoch = 0               # bumped whenever the parameters changed under us (caches derived from parameters key on it)
 
     @classmethod
-    def refresh_all(cls):
+    def refresh_all(cls, owner=None):
         cls.epoch += 1
         if not cls.enabled:
             return
         if cls._dirty or cls._tables is None:
+            owner = None                # (the rebuild below hands every entry a fresh, zeroed amax slot: everything is split again)
             groups = {}
             for ent in cls._entries():
-                if ent.w.is_cuda:
-                    groups.setdefault((ent.fmt, ent.w.device), []).append(ent)
+                if ent.w.is_cuda:       # (grouped by STORAGE: the weights of one trainer are views of its flat parameter buffer)
+                    groups.setdefault((ent.w.untyped_storage().data_ptr(), ent.fmt, ent.w.device), []).append(ent)
             cls._tables = []
-            for (fmt, dev), ents in groups.items():
+            for (own_id, fmt, dev), ents in groups.items():
                 amax_t = None
                 if fmt == 6:             # one contiguous slot table per device: zeroed by ONE memset in the batched call
                     amax_t = torch.zeros(len(ents), AmaxSlot.FLOATS, dtype=torch.float32, device=dev)
@@ -381,9 +283,12 @@ class WeightPlanes:
                     N, K = ent.w.shape
                     r = [ent.w.data_ptr(), ent.w.stride(0), N, K, ent.planes[0].data_ptr(), ent.planes[1].data_ptr()]
                     rows.append(r + [ent.amax.ptr, 0] if fmt == 6 else r)
-                cls._tables.append((fmt, torch.tensor(rows, dtype=torch.int64).to(dev), amax_t, ents))
+                cls._tables.append((fmt, torch.tensor(rows, dtype=torch.int64).to(dev), amax_t, ents, own_id))
             cls._dirty = False
-        for fmt, table, amax_t, ents in cls._tables:
+        only = None if owner is None else owner.untyped_storage().data_ptr()
+        for fmt, table, amax_t, ents, own_id in cls._tables:
+            if only is not None and own_id != only:
+                continue
             with torch.cuda.device(table.device):
                 if fmt == 6:
                     check(lib().npvp_split_weights_f16(_p(table.data_ptr()), table.shape[0], _p(amax_t.data_ptr()),
@@ -392,392 +297,6 @@ class WeightPlanes:
                     check(lib().npvp_split_weights_batched(_p(table.data_ptr()), table.shape[0], _stream()), "npvp_split_weights_batched")
             for ent in ents:
                 ent.version = ent.w._version
-
-
-class GemmProbe:
-    """bench.py's live roofline probe: when armed, every GEMM launch is bracketed by a pair of HIP events on the stream
-    it is launched on (no synchronisation; read after the timed region), keyed by (layout, kernel): layout (1,1) forward,
-    (1,0) dgrad, (0,0) weight gradient; kernel = npvp_gemm_kernel_id (so the groups line up with the per-kernel rows of a
-    rocprofv3 trace of the same command)."""
-    armed = False
-    records = []          # (start_event, end_event, flops, bytes, (layout, kernel id))
-    KERNELS = {0: "npvp::gemm_f32_kernel", 1: "npvp::gemm_split_db_kernel", 2: "npvp::gemm_wide_kernel<2, 4, 2, 2>",
-               3: "npvp::gemm_wgrad_wide_kernel", 4: "npvp::gemm_wide_kernel<2, 2, 2, 2>", 5: "npvp::gemm_f16_kernel<2, 4, 2, 2>",
-               6: "npvp::gemm_wgrad_f16_kernel", 7: "npvp::gemm_f16_kernel<2, 2, 2, 2>",
-               8: "npvp::gemm_f16_group_kernel (dgrad + weight gradient in one launch)"}
-
-    only = None           # set of kernel ids to bracket (None = every GEMM launch)
-
-    @classmethod
-    def arm(cls, only=None):
-        """only = kernel ids to time: every event pair is a pair of marker packets that fences the launches around it, so the
-        benchmark brackets the critical-path (forward / dgrad) kernels by default and the gradient stream's on request"""
-        cls.armed, cls.records, cls.only = True, [], (None if only is None else set(only))
-
-    @classmethod
-    def disarm(cls):
-        cls.armed = False
-
-    @classmethod
-    def summary(cls):
-        """{(layout, kernel id): (launches, total_ms, total_flops, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
-        out = {}
-        for e0, e1, fl, by, key in cls.records:
-            n, ms, f, b = out.get(key, (0, 0.0, 0.0, 0.0))
-            out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
-        return out
-
-
-class HbmProbe:
-    """bench.py's live probe of the HBM-bound family: when armed, the three kernels that lead the non-GEMM time of a step (the
-    fused MlpDWBN middle backward, the token LayerNorm backward, the frame-LayerNorm backward apply pass) are bracketed by HIP
-    event pairs on the stream they run on, with their ALGORITHMIC bytes (every operand read once, every result
-    written once, fp32).  Armed for a few extra steps AFTER the timed region, so the event packets do not perturb `value`."""
-    armed = False
-    records = []          # (start_event, end_event, kernel name, algorithmic bytes)
-
-    @classmethod
-    def begin(cls):
-        if not cls.armed:
-            return None
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        return e0
-
-    @classmethod
-    def end(cls, e0, name, nbytes):
-        if e0 is None:
-            return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        cls.records.append((e0, e1, name, float(nbytes)))
-
-    @classmethod
-    def summary(cls):
-        """{kernel: (launches, total_ms, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
-        out = {}
-        for e0, e1, name, by in cls.records:
-            n, ms, b = out.get(name, (0, 0.0, 0.0))
-            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + by)
-        return out
-
-
-class GradSink:
-    """Parameter gradients go STRAIGHT into the flat gradient buffer.  When a weight / bias / LayerNorm parameter is a
-    FlatBuffers parameter (or a contiguous view into one, e.g. the q|k rows of an in_proj_weight or a 1x1 conv weight
-    seen as [N, K]), the backward kernels accumulate into the matching slice of its .grad (`accumulate=1` on the C
-    entry points) and the autograd Function returns None for it.  This removes the temporary gradient tensors, the
-    slice-backward zero+copy kernels and autograd's per-parameter accumulate adds (about 1000 small kernels and 7 ms of
-    a 160 ms c1 step).  The flat buffer is zeroed once per step by FlatBuffers.zero_grad(), so every contribution is a
-    plain accumulate.  `listener(param)` is called after each contribution (npvp_amd.dp.GradSync counts them to know
-    when a bucket is complete)."""
-    enabled = True
-    listener = None
-
-    @classmethod
-    def slot(cls, t):
-        """-> (grad slice shaped like t, owning parameter) or None"""
-        if not cls.enabled or t is None or not t.requires_grad:
-            return None
-        base = t if t.is_leaf else t._base
-        if base is None or not base.is_leaf:
-            return None
-        d = base.__dict__
-        if not d.get("_npvp_flat", False):
-            return None
-        g = base.grad
-        if g is None or not t.is_contiguous():
-            return None
-        # the slot of a given (offset, shape) view never changes while .grad is the same flat-buffer view: cache it on
-        # the parameter (this runs ~750 times per step)
-        off = t.storage_offset() - base.storage_offset()
-        key = (off, t.shape)
-        cache = d.get("_npvp_slots")
-        if cache is None or cache[0] is not g:
-            cache = d["_npvp_slots"] = (g, {})
-        hit = cache[1].get(key)
-        if hit is None:
-            if not g.is_contiguous() or off < 0 or off + t.numel() > g.numel():
-                return None
-            hit = cache[1][key] = (g.view(-1)[off:off + t.numel()].view(t.shape), base)
-        return hit
-
-    @classmethod
-    def wrote(cls, *slots):
-        if cls.listener is not None:
-            for s in slots:
-                if s is not None:
-                    cls.listener(s[1])
-
-
-class AuxStream:
-    """A second compute stream for INDEPENDENT sub-graphs of the forward pass (the two encoder passes of NPVP-S
-    training).  autograd runs each backward node on the stream of its forward, so the two backward chains overlap
-    as well; MFMA-bound GEMMs of one chain fill the gaps of the HBM-bound kernels of the other."""
-    # opt-in (NPVP_DUAL_ENCODER=1): measured -2.6 ms (2 %) on a c1 step.  Off by default so that (a) every kernel has
-    # the device to itself in the forward pass and per-kernel timings agree between bench.py's live probe and a
-    # rocprofv3 trace (which serialises the two streams), and (b) under data parallelism the SyncBatchNorm collectives
-    # of the two passes are issued from ONE stream in program order.
-    enabled = os.environ.get("NPVP_DUAL_ENCODER", "0") == "1"
-    active = False           # inside a two-stream region (GemmProbe skips launches there: their durations overlap)
-    _streams = {}
-
-    @classmethod
-    def stream(cls, dev):
-        key = (dev.type, dev.index)
-        if key not in cls._streams:
-            cls._streams[key] = torch.cuda.Stream(device=dev)
-            # gradients of the few parameters that still go through autograd's AccumulateGrad are produced on two
-            # streams on purpose; the engine synchronises them, the advisory warning about it is noise here
-            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if quiet is not None:
-                quiet(False)
-        return cls._streams[key]
-
-
-class DecoderSplit:
-    """EXPERIMENT (NPVP_DECODER_SPLIT=1, off by default): run the decoder on two half-batches on two streams
-    (npvp_amd.models.Predictor._decode)."""
-    enabled = os.environ.get("NPVP_DECODER_SPLIT", "0") == "1"
-    min_rows = int(os.environ.get("NPVP_DECODER_SPLIT_MIN_ROWS", "32768"))
-
-    @classmethod
-    def wanted(cls, N, T):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return False        # under data parallelism the bucket all-reduces are ordered after the compute and gradient streams only
-        return cls.enabled and N >= 2 and N % 2 == 0 and (N // 2) * T * 64 >= cls.min_rows and torch.is_grad_enabled()
-
-
-class WgradStream:
-    """Weight-gradient GEMMs run on a SECOND HIP stream.  In backward a layer's dgrad feeds the next layer, but its
-    wgrad feeds nobody until the optimiser: when it is accumulated in place (GradSink) it has no consumer in the
-    autograd graph at all.  Launched on a side stream (ordered after the producer of dy), the MFMA-bound wgrad GEMMs
-    overlap the HBM-bound backward kernels of the following layers (LayerNorm / frame-LN / depthwise / attention
-    backward, ~35 ms of a c1 step) and fill the tail of the dgrad GEMMs.  The main stream re-joins the side stream when
-    the backward pass finishes (autograd engine callback), so .grad is complete wherever it is read."""
-    enabled = os.environ.get("NPVP_WGRAD_STREAM", "1") == "1"
-    _side = {}
-    _pending = None          # (device, side stream) while a backward pass has work in flight on the side stream
-
-    @classmethod
-    def stream(cls, dev):
-        key = (dev.type, dev.index)
-        if key not in cls._side:
-            st = None
-            # lowest device priority (torch only offers normal / high): critical-path kernels are dispatched first
-            with torch.cuda.device(dev):
-                h = lib().npvp_stream_create_low_priority(None, None)
-            if h:
-                st = torch.cuda.ExternalStream(h, device=dev)
-            cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
-        return cls._side[key]
-
-    in_flush = False         # inside flush(): the current stream is the gradient stream (WgradChain defers reductions there)
-    _held, _held_bytes, _held_storages = [], 0, set()
-    HOLD_BYTES = 2048 << 20
-    _queue = []              # deferred (fn, keep_alive tensors, gradient slots to report) - see run()
-    BATCH = 16
-
-    @classmethod
-    def run(cls, fn, *keep_alive, wrote=None, urgent=False):
-        """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors are protected
-        from allocator reuse until the side stream has consumed them; `wrote` = gradient slots to report to the GradSink
-        listener once fn is enqueued.  Calls are QUEUED and handed to the side stream BATCH at a time (16 since round 4: on host-bound
-        shards 3 -> 16 measured 0 .. -4.7 ms per step depending on the box's CPU, c1 -1 ms; and when the backward
-        pass ends): one event record / wait and one stream switch per batch instead of per call - 300 of them were 8 ms of an
-        8-clip step's 42 ms of host time (c3 shard 48.5 -> 43 ms).  `urgent` hands the queue over at once: large GEMMs, whose
-        early start is worth more than the host time (c2: 257 vs 260 ms).  The inputs of fn are never written again on the main stream (they are already read
-        concurrently with later main-stream kernels), so starting it a few launches later changes no result."""
-        cls._queue.append((fn, keep_alive, wrote))
-        if cls._pending is None:
-            dev = keep_alive[0].device
-            cls._pending = (dev, cls.stream(dev))
-            torch.autograd.Variable._execution_engine.queue_callback(cls.join)
-        if urgent or len(cls._queue) >= cls.BATCH:
-            cls.flush()
-
-    @classmethod
-    def flush(cls):
-        if not cls._queue:
-            return
-        q, cls._queue = cls._queue, []
-        dev, side = cls._pending
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            cls.in_flush = True
-            try:
-                for fn, _, _ in q:
-                    fn()
-                if GradSink.listener is not None:
-                    # data parallel: the slots reported below must be COMPLETE on this stream when a bucket's all-reduce is
-                    # ordered behind it - a split-K reduction still waiting for its next launch is not
-                    WgradChain.flush()
-                if ReduceQueue.pending() and (GradSink.listener is not None or ReduceQueue.due()):
-                    ReduceQueue._launch(side)   # a launch's worth of deferred parameter-gradient reductions (or, data parallel, all)
-            finally:
-                cls.in_flush = False
-        for _, keep, slots in q:
-            for t in keep:
-                cls.hold(t)
-            if slots is not None:
-                GradSink.wrote(*slots)          # (on the caller's stream: the listener orders its collective after both streams)
-
-    @classmethod
-    def hold(cls, t):
-        """The gradient stream reads t after the caller may have dropped it: either HOLD a reference until the join (after which the
-        compute stream is ordered behind everything the gradient stream did - freeing is then safe without any allocator
-        bookkeeping) or, past a byte budget (the large workloads: tens of GB of dy per backward pass), record the stream on the
-        block (an event per block when it is freed: 500 of them were ~1 ms of a shard's step).  The budget counts what a reference
-        really pins - the tensor's whole STORAGE, once (a small view of a large activation holds all of it: ADVICE r4)."""
-        st = t.untyped_storage()
-        key = st.data_ptr()
-        if key in cls._held_storages:
-            cls._held.append(t)
-            return
-        nb = st.nbytes()
-        if cls._held_bytes + nb <= cls.HOLD_BYTES:
-            cls._held.append(t)
-            cls._held_storages.add(key)
-            cls._held_bytes += nb
-        else:
-            t.record_stream(cls._pending[1] if cls._pending is not None else cls.stream(t.device))
-
-    @classmethod
-    def pending_stream(cls):
-        """the gradient stream if this backward pass has work in flight on it, else None (npvp_amd.dp orders a bucket's
-        all-reduce after it)"""
-        return cls._pending[1] if cls._pending is not None else None
-
-    @classmethod
-    def join(cls):
-        """the caller's current stream waits for the gradient stream (the autograd engine runs its final callbacks
-        under the streams that were current when backward() was called)"""
-        if cls._pending is not None:
-            cls.flush()
-            dev, side = cls._pending
-            if ReduceQueue.pending():
-                side.wait_stream(torch.cuda.current_stream(dev))      # (the partials' producers ran on the caller's stream)
-            with torch.cuda.stream(side):
-                WgradChain.flush()               # the last weight gradient's split-K reduction has no launch to ride in
-                if ReduceQueue.pending():
-                    ReduceQueue._launch(side)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            cls._pending = None
-            cls._held, cls._held_bytes, cls._held_storages = [], 0, set()
-
-
-class ReduceQueue:
-    """Deferred parameter-gradient reductions (include/npvp_hip.h, npvp_sum_rows_multi).  The LayerNorm / frame-LayerNorm / fused
-    MlpDWBN-middle backward kernels leave per-block partial sums of their parameter gradients in a workspace; summing them into
-    the flat gradient buffer has no consumer before the optimiser.  One launch per site was ~150 launches of ~10 us per 8-clip step
-    (a tenth of its launches).  Here a site only writes a 48-byte job record into a host buffer; the records are run 40 per launch
-      * on the gradient stream, by WgradStream.flush() once 40 have gathered (the large workloads: the reductions keep overlapping
-        the backward pass, the workspaces - 2 GB per c2 step - do not pile up) and by WgradStream.join();
-      * on the current stream when the backward pass ends (autograd engine callback), if there is no gradient stream (single-stream
-        capture of the step into a HIP graph: 146 graph nodes become 4).
-    Two jobs that write the same gradient slice (a LayerNorm applied twice per step: the tied final norm, the encoder of NPVP-S
-    training) never share a launch: the queue is run before the second one is added.  Same summation order whoever runs it."""
-    enabled = os.environ.get("NPVP_REDUCE_QUEUE", "1") == "1"
-    JOB, CAP, LAUNCH = 48, 480, 40
-    SKJOB, SKCAP, SKLAUNCH = 64, 256, 16      # split-K reductions of fused dgrad + weight-gradient launches (linear_bwd): 64-byte records
-    _buf = _addr = _skbuf = _skaddr = None
-    _n = _skn = 0
-    _keep, _wrote, _outs = [], [], set()
-    _armed = False
-
-    @classmethod
-    def pending(cls):
-        return cls._n + cls._skn
-
-    @classmethod
-    def due(cls):
-        """a launch's worth has gathered (WgradStream.flush runs the queue then, so that the reductions keep overlapping the pass)"""
-        return cls._n >= cls.LAUNCH or cls._skn >= cls.SKLAUNCH
-
-    @classmethod
-    def splitk_slot(cls, out_ptrs):
-        """host address for the next 64-byte split-K job record (the C call that leaves the partial slabs writes it)"""
-        if cls._skbuf is None:
-            cls._skbuf = ctypes.create_string_buffer(cls.SKJOB * cls.SKCAP)
-            cls._skaddr = ctypes.addressof(cls._skbuf)
-        if cls._skn == cls.SKCAP or not cls._outs.isdisjoint(out_ptrs):
-            cls.run_pending()
-        return cls._skaddr + cls.SKJOB * cls._skn
-
-    @classmethod
-    def splitk_added(cls, out_ptrs, keep, wrote):
-        cls._skn += 1
-        cls._keep.append(keep)
-        cls._outs.update(out_ptrs)
-        if wrote is not None:
-            cls._wrote.append(wrote)
-        cls._arm()
-
-    @classmethod
-    def _arm(cls):
-        if not cls._armed:
-            cls._armed = True
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(cls.finish)
-            except RuntimeError:                    # not inside a backward pass (an op test calling the wrappers directly):
-                cls._armed = False                  # the caller runs finish() itself
-
-    @classmethod
-    def add(cls, filler, name, args, out_ptrs, keep, wrote):
-        """filler(*args, job address) = one of the npvp_*_reduce_job entry points; out_ptrs: device addresses the job writes"""
-        if cls._buf is None:
-            cls._buf = ctypes.create_string_buffer(cls.JOB * cls.CAP)
-            cls._addr = ctypes.addressof(cls._buf)
-        if cls._n == cls.CAP or not cls._outs.isdisjoint(out_ptrs):
-            cls.run_pending()
-        check(filler(*args, cls._addr + cls.JOB * cls._n), name)
-        cls._n += 1
-        cls._keep.append(keep)
-        cls._outs.update(out_ptrs)
-        if wrote is not None:
-            cls._wrote.append(wrote)
-        cls._arm()
-
-    @classmethod
-    def run_pending(cls):
-        """the queued jobs, now, on the stream where in-place gradient writes belong"""
-        if cls._n + cls._skn == 0:
-            return
-        if WgradStream.enabled and WgradStream._pending is not None and not WgradStream.in_flush:
-            dev, side = WgradStream._pending
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                cls._launch(side)
-        else:
-            cls._launch(None)
-
-    @classmethod
-    def _launch(cls, side):
-        n, skn, keep, wrote = cls._n, cls._skn, cls._keep, cls._wrote
-        cls._n, cls._skn, cls._keep, cls._wrote, cls._outs = 0, 0, [], [], set()
-        if n:
-            check(lib().npvp_sum_rows_multi(cls._addr, n, _stream()), "npvp_sum_rows_multi")
-        if skn:
-            check(lib().npvp_splitk_reduce_multi(cls._skaddr, skn, _stream()), "npvp_splitk_reduce_multi")
-        if side is not None or WgradStream.in_flush:
-            for t in keep:                         # read on the gradient stream after the caller drops them (see WgradStream.flush)
-                WgradStream.hold(t)
-        for sk in wrote:
-            GradSink.wrote(*sk)
-
-    @classmethod
-    def finish(cls):
-        """end of the backward pass (autograd engine callback; also FlatAdamW.step / zero_grad)"""
-        cls._armed = False
-        if not WgradStream.enabled:
-            WgradChain.flush()                      # (single stream: the last fused launch's split-K reduction has no launch to ride in)
-        if cls._n + cls._skn == 0:
-            return
-        if WgradStream.enabled and WgradStream._pending is not None:
-            WgradStream.join()                      # (runs the queue on the gradient stream before the streams re-join)
-        else:
-            cls._launch(None)
 
 
 # --------------------------------------------------------------------------- raw kernel wrappers
@@ -918,110 +437,7 @@ def masked_grad(dy2, drop, w):
 # Up to this many token rows (the launch-bound shards: c4 36.4 -> 35.1 ms).  On the large workloads the step does not change
 # (c2: 245.6 vs 246.2 ms) and the only effect is on what shares the device with what: without the masking pass in front of it the
 # weight-gradient GEMM of the site starts earlier and runs beside its dgrad GEMM (event-pair time of the dgrad launches +10 %).
-DROP_PATH_IN_GEMM_ROWS = int(os.environ.get("NPVP_DROP_PATH_IN_GEMM_ROWS", "32768"))
-
-
-class WgradChain:
-    """Split-K reductions of the fp16 weight gradients, handed from launch to launch (include/npvp_hip.h, npvp_wgrad_f16_chained):
-    a weight gradient accumulated in place on the gradient stream leaves its `splits` partial slabs in a workspace and a 64-byte
-    job; the NEXT weight-gradient launch on that stream does the sum with extra workgroups (no launch of its own: 110 of the 170
-    reduction launches of an 8-clip step; HBM-bound work beside MFMA-bound work), WgradStream.join() runs the last one.  Same
-    summation order as the stand-alone reduction, so results are bit-identical.  `enabled = False`: one reduction launch each."""
-    enabled = True
-    _pending = {}          # raw stream -> (job bytes, workspace, dw, db): kept alive until the job has been handed on
-    _ok, _wsb = {}, {}
-
-    @classmethod
-    def takes(cls, M, N, K):
-        key = (M, N, K)
-        v = cls._ok.get(key)
-        if v is None:
-            v = cls._ok[key] = bool(lib().npvp_wgrad_f16_chainable(M, N, K))
-            cls._wsb[key] = lib().npvp_wgrad_f16_chain_workspace_bytes(M, N, K)
-        return v
-
-    @classmethod
-    def launch(cls, dy, x, dw, db, dy_amax, x_amax, a_drop, flag):
-        """dw (+)= dy^T x, db (+)= colsum(dy), both ACCUMULATED (GradSink slices), reduction deferred"""
-        R, N = dy.shape
-        K = x.shape[1]
-        st = _stream()
-        ws, wsn = _ws(cls._wsb[(N, K, R)], dy.device)
-        job = ctypes.create_string_buffer(64)
-        prev = cls._pending.pop(st, None)
-        seed = rng.seed_tensor(dy.device) if a_drop.on else None
-        probe = GemmProbe.armed and (GemmProbe.only is None or 6 in GemmProbe.only)
-        if probe:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        check(lib().npvp_wgrad_f16_chained(N, K, R, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), _ptr(db), 1,
-                                           _ptr(dy_amax), _ptr(x_amax), _ptr(flag), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt,
-                                           _ptr(seed), ctypes.addressof(prev[0]) if prev is not None else None, ctypes.addressof(job),
-                                           _ptr(ws), wsn, st), "npvp_wgrad_f16_chained")
-        if probe:
-            e1.record()
-            GemmProbe.records.append((e0, e1, 2.0 * N * K * R, 4.0 * (N * R + K * R + N * K), ((0, 0), 6)))
-        cls._pending[st] = (job, ws, dw, db, None)
-
-    @classmethod
-    def flush(cls):
-        """the pending job of the CURRENT stream, as a launch of its own"""
-        st = _stream()
-        prev = cls._pending.pop(st, None)
-        if prev is not None:
-            check(lib().npvp_splitk_reduce_job(ctypes.addressof(prev[0]), st), "npvp_splitk_reduce_job")
-            if prev[4] is not None:
-                GradSink.wrote(*prev[4])
-
-
-class RangeGuard:
-    """The per-ROW range of the two-term fp16 arithmetic (include/npvp_hip.h, `range_flag`).  Forward / dgrad GEMMs repair a tile
-    whose rows lie 2^18 or more below the operand's bound themselves (a second pass with per-row scales, inside the kernel).  The
-    weight-gradient kernel only DETECTS a feature (a column of dy = a row of dW) that far below dy's bound and raises a device
-    counter; what happens then:
-      strict (NPVP_RANGE_GUARD=strict, RangeGuard.strict = True: tests, audits): linear_wgrad reads the counter right after the
-          launch (a device synchronisation per weight gradient) and re-runs THAT gradient in the six-term bf16 arithmetic, which
-          has fp32's exponent range;
-      default: nothing is read inside the step.  The training step reads the counter where it reads its loss scalars anyway
-          (trainer.predictor_train_step(sync=True) -> 'f16_range_events'); from the first event on, every weight gradient of the
-          process runs as bf16x6 (sticky; RangeGuard.reset() re-arms).  One step's smallest feature rows are then late by one
-          step, never silently wrong for long.
-    NPVP_RANGE_GUARD=off passes no counter (the kernel then skips the column maxima)."""
-    mode = os.environ.get("NPVP_RANGE_GUARD", "on")
-    strict = mode == "strict"
-    fallback = False             # sticky: weight gradients run as bf16x6
-    events = 0                   # total raised so far (host view)
-    _flags = {}
-
-    @classmethod
-    def flag(cls, dev):
-        if cls.mode == "off":
-            return None
-        f = cls._flags.get(dev)
-        if f is None:
-            f = cls._flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-            if WgradStream.enabled:
-                f.record_stream(WgradStream.stream(dev))
-        return f
-
-    @classmethod
-    def poll(cls, dev):
-        """read and clear the device counter (synchronises); arms the sticky fallback if it was raised"""
-        f = cls._flags.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
-        if f is None:
-            return 0
-        n = int(f.item())
-        if n:
-            f.zero_()
-            cls.events += n
-            cls.fallback = True
-        return n
-
-    @classmethod
-    def reset(cls):
-        cls.fallback, cls.events = False, 0
-        for f in cls._flags.values():
-            f.zero_()
+DROP_PATH_IN_GEMM_ROWS = 32768
 
 
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None, a_drop=NO_DROP):
@@ -1065,13 +481,13 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
 
 class FusedLinearBwd:
     """dgrad + weight gradient of one linear layer as ONE launch (include/npvp_hip.h, npvp_linear_bwd_f16) - for the shapes on which
-    each of the two alone leaves half the chip idle: small-tile dgrads with at least 4 096 and at most MAX_ROWS token rows (the
+    each of the two alone leaves half the chip idle: small-tile dgrads with at least 1 024 and at most MAX_ROWS token rows (the
     8-clip shards of the data-parallel configurations; the large workloads keep the two-stream schedule).  The weight gradient's
     split-K reduction is the only in-place gradient write: with a gradient stream it is queued for that stream (ReduceQueue), where
     every in-place write is serialised; without one (the step captured single-stream into a HIP graph) it rides in the next fused
     launch on the same stream (WgradChain)."""
-    enabled = os.environ.get("NPVP_FUSED_LINEAR_BWD", "1") == "1"
-    MAX_ROWS = int(os.environ.get("NPVP_FUSED_LINEAR_BWD_ROWS", "16384"))
+    enabled = True
+    MAX_ROWS = 16384
     _ok = {}
 
     @classmethod
@@ -1188,9 +604,10 @@ def broadcast_mid(x, B, scale=1.0):
 class _Transpose(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        remember(ctx)
         return transpose(x)
 
-    @staticmethod
+    @scoped
     def backward(ctx, g):
         return transpose(g)
 
@@ -1200,10 +617,11 @@ class _MeanMid(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        remember(ctx)
         ctx.B = x.shape[1]
         return reduce_mid(x, 1.0 / x.shape[1])
 
-    @staticmethod
+    @scoped
     def backward(ctx, g):
         return broadcast_mid(g, ctx.B, 1.0 / ctx.B)
 
@@ -1211,6 +629,7 @@ class _MeanMid(torch.autograd.Function):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, relu):
+        remember(ctx)
         _chk(x, w, b)
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
@@ -1227,7 +646,7 @@ class _LayerNorm(torch.autograd.Function):
         ctx.sink = _ln_sink(w, b)
         return y.reshape(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x2, w, b, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
@@ -1296,6 +715,7 @@ class _LayerNormNchw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, eps, relu, N, T, H, W):
+        remember(ctx)
         _chk(x, w, b)
         C = x.shape[-1]
         x3 = _c(x).reshape(N * T, H * W, C)
@@ -1309,7 +729,7 @@ class _LayerNormNchw(torch.autograd.Function):
         ctx.sink = _ln_sink(w, b)
         return out
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         # dy (N,T,C,H,W) -> canonical rows (the LDS-tiled transpose), then the row-wise LayerNorm backward: a fused backward
         # through the forward kernel's tile was 3x slower than these two kernels
@@ -1351,6 +771,7 @@ class _LayerNormRes(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, eps):
+        remember(ctx)
         _chk(x, w, b)
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
@@ -1367,7 +788,7 @@ class _LayerNormRes(torch.autograd.Function):
         ctx.sink = _ln_sink(w, b)
         return x.view_as(x), y.reshape(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dres, dy):
         x2, w, b, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
@@ -1401,6 +822,7 @@ class _PosFuse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, add, beta, gamma, N, T):
+        remember(ctx)
         _chk(x, add, beta, gamma)
         x = _c(x)
         F_, PF = N * T, x.numel() // (N * T)
@@ -1419,7 +841,7 @@ class _PosFuse(torch.autograd.Function):
         ctx.beta_shape = beta.shape
         return y
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x, add, gamma, mean, rstd = ctx.saved_tensors
         N, T, PF = ctx.N, ctx.T, ctx.PF
@@ -1455,6 +877,7 @@ class _PosFuseInstance(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, add, beta, gamma, N, T):
+        remember(ctx)
         _chk(x, add, beta, gamma)
         x = _c(x)
         C = x.shape[-1]
@@ -1472,7 +895,7 @@ class _PosFuseInstance(torch.autograd.Function):
         ctx.cfg = (N, T, P, C, beta.shape)
         return y
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x, add, gamma, st = ctx.saved_tensors
         N, T, P, C, beta_shape = ctx.cfg
@@ -1498,6 +921,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, drop, frame_stats=False):
+        remember(ctx)
         _chk(x, w, b, residual)
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
@@ -1524,7 +948,7 @@ class _Linear(torch.autograd.Function):
         y = linear_fwd(x2, w, b, residual=r2, drop=drop)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy, *_stats_grads):
         x2, w = ctx.saved_tensors
         N = w.shape[0]
@@ -1596,6 +1020,7 @@ class _FFN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xn, x, w1, b1, w2, b2, p):
+        remember(ctx)
         _chk(xn, x, w1, b1, w2, b2)
         C = xn.shape[-1]
         xn2, x2 = _c(xn).reshape(-1, C), _c(x).reshape(-1, C)
@@ -1611,7 +1036,7 @@ class _FFN(torch.autograd.Function):
         ctx.sink = (s1, s2) if (s1 and s2 and s1[1] is not None and s2[1] is not None) else None
         return y.reshape(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         xn2, h, a, w1, w2 = ctx.saved_tensors
         C = xn2.shape[1]
@@ -1681,6 +1106,7 @@ class _AttnPacked(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qk, v, cfg):
+        remember(ctx)
         _chk(qk, v)
         C = v.shape[1]
         o = torch.empty_like(v)
@@ -1689,7 +1115,7 @@ class _AttnPacked(torch.autograd.Function):
         ctx.cfg = cfg
         return o
 
-    @staticmethod
+    @scoped
     def backward(ctx, go):
         qk, v = ctx.saved_tensors
         C = v.shape[1]
@@ -1704,6 +1130,7 @@ class _Attn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, cfg):
+        remember(ctx)
         _chk(q, k, v)
         o = torch.empty_like(q)
         _attn_fwd(q, k, v, o, cfg)
@@ -1711,7 +1138,7 @@ class _Attn(torch.autograd.Function):
         ctx.cfg = cfg
         return o
 
-    @staticmethod
+    @scoped
     def backward(ctx, go):
         q, k, v = ctx.saved_tensors
         go = _c(go)
@@ -1733,6 +1160,7 @@ class _FrameLnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w_cl, b_cl, res, frames, p_drop, p_dp, frames_per_sample, mean=None, rstd=None):
+        remember(ctx)
         _chk(h, w_cl, b_cl, res)
         h = _c(h)
         PF = h.numel() // frames
@@ -1758,7 +1186,7 @@ class _FrameLnAct(torch.autograd.Function):
         ctx.sink = _ln_sink(w_cl, b_cl)
         return out
 
-    @staticmethod
+    @scoped
     def backward(ctx, dout):
         h, mean, rstd, w_cl, b_cl = ctx.saved_tensors
         frames, PF, d, dp, fps, has_res = ctx.cfg
@@ -1791,6 +1219,7 @@ class _DwConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, wtb, frames, H, W, want_stats):
+        remember(ctx)
         _chk(a, wtb)
         a, wtb = _c(a), _c(wtb)
         Ch = wtb.shape[1]
@@ -1810,7 +1239,7 @@ class _DwConv(torch.autograd.Function):
               "npvp_dwconv3x3")
         return out
 
-    @staticmethod
+    @scoped
     def backward(ctx, dout, *_unused):
         a, wtb = ctx.saved_tensors
         frames, H, W, Ch = ctx.cfg
@@ -1830,9 +1259,6 @@ def dwconv3x3(a, wtb, frames, H, W, want_stats=False):
     return _DwConv.apply(a, wtb, frames, H, W, bool(want_stats))
 
 
-MID_BWD_FENCE = os.environ.get("NPVP_MID_BWD_FENCE", "0") == "1"
-
-
 class _MlpDwbn(torch.autograd.Function):
     """The whole conv feed-forward sub-layer body of the reference's MlpDWBN (ref/models/VidHRFormer.py:374-392) as ONE
     autograd node:  out = res + droppath(drop(GELU(norm3(fc2(drop(GELU(norm2(dw3x3(GELU(norm1(fc1(x))))))))))))
@@ -1844,6 +1270,7 @@ class _MlpDwbn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, w1, b1, n1w, n1b, dww, dwb, n2w, n2b, w2, b2, n3w, n3b, frames, T, p_drop, p_dp):
+        remember(ctx)
         _chk(x, res, w1, b1, w2, b2)
         L = lib()
         R, C = x.shape
@@ -1951,7 +1378,7 @@ class _MlpDwbn(torch.autograd.Function):
         """dgrad on this stream, weight (+bias) gradient into the sink on the gradient stream or returned"""
         return linear_bwd(dy, x, w, True if has_b else None, sk)      # (`b` only says whether there is a bias gradient to take)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dout):
         x, h1, h2, a2, h3, stats, wtb, w1, w2, n1w, n1b, n2w, n2b, n3w, n3b = ctx.saved_tensors
         frames, T, d2, d3, dp, has_res, has_b1, has_b2 = ctx.cfg
@@ -1976,15 +1403,9 @@ class _MlpDwbn(torch.autograd.Function):
         # fused middle backward: da1, depthwise weight / bias gradient (a1 recomputed from h1), norm1's backward statistics
         da1 = torch.empty_like(h1)
         dwtb = torch.empty(10, hid, dtype=torch.float32, device=dev)
-        psum = torch.empty(frames * (hid // 256) * 2, dtype=torch.float32, device=dev)
+        nparts = hid // 256                     # partials per frame of norm1's backward statistics (one per block of the kernel below)
+        psum = torch.empty(frames * nparts * 2, dtype=torch.float32, device=dev)
         ws, wsn = _ws(L.npvp_mlpdw_mid_bwd_workspace_bytes(frames, hid), dev)
-        # NPVP_MID_BWD_FENCE=1 (off by default since round 4): a wait for the gradient stream in front of this kernel.  Round 2's
-        # packed-FMA build of mlpdw_mid_bwd_kernel was not bitwise reproducible while a weight-gradient GEMM shared the CUs; the
-        # kernel has accumulated with scalar v_fmac_f32 since, 28 soak runs without the wait give one digest per batch size
-        # (profiles/r04_determinism_soak.txt) and the wait costs 2.4 ms of a c2 step.
-        if MID_BWD_FENCE and WgradStream._pending is not None:
-            WgradStream.flush()
-            torch.cuda.current_stream(dev).wait_stream(WgradStream._pending[1])
         sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
         wmode = 2 if sk_dw else 0          # 2: the depthwise gradient partials stay in `ws` for the gradient stream (below)
         if fuse_n2:
@@ -2021,14 +1442,14 @@ class _MlpDwbn(torch.autograd.Function):
             check(L.npvp_transpose(_ptr(dwtb), _ptr(gdww), 1, 9, hid, _stream()), "npvp_transpose")
             gdwb = dwtb[9]
         dh1, gn1w, gn1b = F_._fln_bwd(L, da1, h1, stats[0], stats[1], n1w, n1b, frames, 64 * hid, NO_DROP, NO_DROP, 1, s_n1,
-                                      psum=psum, nparts=hid // 256)
+                                      psum=psum, nparts=nparts)
         del da1
         dx, gw1, gb1 = F_._lin_bwd(dh1, x, w1, s_fc1, has_b1)
         return (dx, dout if has_res else None, gw1, gb1, gn1w, gn1b, gdww, gdwb, gn2w, gn2b, gw2, gb2, gn3w, gn3b,
                 None, None, None, None)
 
 
-MID_BWD_N2 = os.environ.get("NPVP_MID_BWD_N2", "1") == "1"        # A/B switch: norm2's input gradient inside the fused middle's backward
+MID_BWD_N2 = True        # (False: norm2's backward as two kernels of its own - the op test compares the two routes)
 
 
 def mlpdwbn_fused_supported(R, C, hid, Co, H, W):
@@ -2131,6 +1552,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lw, lb, eps, beta, gamma, add, wqk, bqk, wv, bv, wo, bo, cfg, drop, N, T):
+        remember(ctx)
         # wqk / wv are the [:2C] / [2C:] row slices of in_proj_weight, sliced by the caller WITH grad mode on: a slice taken in
         # here (grad mode off) would not be recognised as a view of a flat-buffer parameter by GradSink
         _chk(x, lw, lb, beta, gamma, add, wqk, bqk, wv, bv, wo, bo)
@@ -2150,7 +1572,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
         ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wqk, bqk), _wb_sink(wv, bv), _wb_sink(wo, bo))
         return y.view(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x2, x1, lst, fused, pst, qk, v, o, lw, lb, gamma, add, wqk, bqk, wv, bv, wo, bo = ctx.saved_tensors
         cfg, drop, N, T, xshape, beta_shape = ctx.cfg
@@ -2175,6 +1597,7 @@ class _CrossAttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lw, lb, eps, beta, gamma, add, key, memory, wq, bq, wk, bk, wv, bv, wo, bo, cfg, drop, N, T):
+        remember(ctx)
         _chk(x, lw, lb, beta, gamma, add, key, memory, wq, bq, wk, bk, wv, bv, wo, bo)
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
@@ -2194,7 +1617,7 @@ class _CrossAttnSublayer(torch.autograd.Function):
         ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wq, bq), _wb_sink(wk, bk), _wb_sink(wv, bv), _wb_sink(wo, bo))
         return y.view(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x2, x1, lst, query, pst, q, k, v, o, k2, m2, lw, lb, gamma, add, wq, bq, wk, bk, wv, bv, wo, bo = ctx.saved_tensors
         cfg, drop, N, T, xshape, beta_shape, kshape, mshape = ctx.cfg
@@ -2221,6 +1644,7 @@ class _FfnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lw, lb, eps, w1, b1, w2, b2, p):
+        remember(ctx)
         _chk(x, lw, lb, w1, b1, w2, b2)
         C = x.shape[-1]
         x2 = _c(x).reshape(-1, C)
@@ -2236,7 +1660,7 @@ class _FfnSublayer(torch.autograd.Function):
         ctx.sinks = (_ln_sink(lw, lb), _wb_sink(w1, b1), _wb_sink(w2, b2))
         return y.view(x.shape)
 
-    @staticmethod
+    @scoped
     def backward(ctx, dy):
         x2, xn, lst, h, a, lw, lb, w1, b1, w2, b2 = ctx.saved_tensors
         d2, d3, xshape = ctx.cfg
@@ -2275,6 +1699,7 @@ class _Im2Col(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, frames, H, W):
+        remember(ctx)
         _chk(x)
         x = _c(x)
         C = x.shape[-1]
@@ -2283,7 +1708,7 @@ class _Im2Col(torch.autograd.Function):
         ctx.cfg = (frames, H, W, C, x.shape)
         return out
 
-    @staticmethod
+    @scoped
     def backward(ctx, g):
         frames, H, W, C, shape = ctx.cfg
         g = _c(g)
@@ -2328,6 +1753,7 @@ class _BiasAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, residual, act):
+        remember(ctx)
         _chk(x, bias, residual)
         need_x, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[2]     # (read before x may be rebound to a no-grad copy)
         N, C, H, W = x.shape
@@ -2347,7 +1773,7 @@ class _BiasAct(torch.autograd.Function):
             ctx.save_for_backward(out)
         return out
 
-    @staticmethod
+    @scoped
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         g = g.contiguous(memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)

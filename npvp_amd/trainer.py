@@ -88,7 +88,12 @@ class FlatAdamW:
     out last so the clip_grad_norm_ range is contiguous."""
 
     def __init__(self, module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_module=None,
-                 max_grad_norm=1.0):
+                 max_grad_norm=1.0, ctx=None):
+        """ctx: the sched.StepContext this trainer's steps run under - dropout seed, gradient stream queue, deferred reductions,
+        data-parallel listener, fp16 range guard.  Default: the context current at construction, i.e. the process's default one
+        unless built under `ops.use(...)` (a single-trainer process: ops.rng.manual_seed etc. act on it).  Two trainers in one
+        process each get their own with ctx=ops.StepContext(): their steps can then be interleaved without sharing any of it."""
+        self.ctx = ctx if ctx is not None else ops.current()
         self.buf = FlatBuffers(module, clip_module)
         if not self.buf.flat_p.is_cuda:
             raise RuntimeError("FlatAdamW needs the module on an MI355X device (no CPU fallback)")
@@ -106,13 +111,18 @@ class FlatAdamW:
         self.param_groups = [{"lr": lr, "initial_lr": lr}]      # initial_lr: the base LR a torch scheduler would record at construction
 
     def zero_grad(self, set_to_none=False):
-        self.buf.zero_grad()
+        with ops.use(self.ctx):
+            self.buf.zero_grad()
 
     def set_lr(self, lr):
         self.hyper[0:1].fill_(lr)
         self.param_groups[0]["lr"] = lr
 
     def step(self):
+        with ops.use(self.ctx):
+            self._step()
+
+    def _step(self):
         ops.ReduceQueue.finish()             # both: no-ops after a finished backward pass (the engine callbacks ran already)
         ops.WgradStream.join()
         self.buf.gather_stray_grads()
@@ -129,7 +139,7 @@ class FlatAdamW:
                                 P(self.v.data_ptr()), self.total, P(self.hyper.data_ptr()), self.betas[0], self.betas[1],
                                 self.eps, self.weight_decay, clip_ptr, self.clip_begin, self.clip_end, 1, s),
               "npvp_adamw_step")
-        ops.WeightPlanes.invalidate()        # the parameters just changed under the cached bf16 planes
+        ops.WeightPlanes.invalidate(self.flat_p)     # this trainer's parameters just changed under their cached planes
 
     def grad_norm(self):
         """Total L2 norm of the clipped range measured by the last step() (device scalar)."""
@@ -234,6 +244,13 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
     """One optimisation step on frozen-encoder features (predictor-only flavour), or the full step when the
     frozen decoder and the target frames are given.  `opt` must be a FlatAdamW.  With sync=False nothing is
     read back (bench / graph capture) and device scalars are returned."""
+    with ops.use(opt.ctx):            # this trainer's dropout stream / gradient stream / deferred reductions / range guard
+        return _predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm, frozen_dec,
+                                     future_frames, sync, grad_sync)
+
+
+def _predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm, frozen_dec, future_frames, sync,
+                          grad_sync):
     dev = past_feats.device
     ops.WgradStream.join()            # (a backward pass that raised leaves queued weight-gradient work and an open join behind)
     ops.rng.begin_step(dev)
@@ -457,6 +474,10 @@ class GraphedTrainStep:
         self._capture()
 
     def _capture(self):
+        with ops.use(self.opt.ctx):
+            self._capture_in_ctx()
+
+    def _capture_in_ctx(self):
         dev = self.past.device
         two_streams = ops.WgradStream.enabled
         if self.single_stream:
@@ -484,6 +505,10 @@ class GraphedTrainStep:
 
     def _poll_range(self):
         """non-blocking: look at the copy issued `poll_every` replays ago; issue the next one"""
+        with ops.use(self.opt.ctx):
+            self._poll_range_in_ctx()
+
+    def _poll_range_in_ctx(self):
         dev = self.past.device
         if self._flag_event is not None and self._flag_event.query():
             n = int(self._flag_host[0])

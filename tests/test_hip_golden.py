@@ -285,6 +285,54 @@ def test_fused_linear_backward_is_bit_identical(impl, two_streams):
         ops.FusedLinearBwd.enabled, ops.WgradStream.enabled = old
 
 
+def test_two_trainers_in_one_process_do_not_share_state(impl):
+    """npvp_amd.sched.StepContext: the dropout seed and salts, the gradient-stream queue, the deferred reductions, the range guard
+    and the data-parallel listener belong to a TRAINER (FlatAdamW(ctx=...)), not to the process (class attributes, one
+    backward pass / one listener / one seed per process).  Two predictors of different shapes with their own optimisers, stepped
+    alternately in one process, must end with the parameters - bit for bit - that each reaches when it runs alone; and one
+    trainer's range event must not switch the other's weight gradients to the fallback arithmetic."""
+    import hashlib
+    from npvp_amd import ops
+    dev = torch.device(DEV)
+    shapes = {"A": (2, 3, 4, 181), "B": (1, 2, 5, 281)}
+
+    def make(tag):
+        N, To, Tp, seed = shapes[tag]
+        m = GC._small_predictor(impl, False, seed, DEV, evt_layers=1, dec_layers=2, To=To, Tp=Tp, dropout=0.1, drop_path=0.1)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0, ctx=ops.StepContext(tag))
+        opt.ctx.rng.manual_seed(seed, dev)
+        past = O.synth_features((N, To, 512, 8, 8), seed + 1).to(DEV)
+        fut = O.synth_features((N, Tp, 512, 8, 8), seed + 2).to(DEV)
+        return m, opt, past, fut
+
+    def digest(opt):
+        torch.cuda.synchronize()
+        return hashlib.sha256(opt.flat_p.cpu().numpy().tobytes()).hexdigest()
+
+    alone = {}
+    for tag in shapes:
+        m, opt, past, fut = make(tag)
+        for _ in range(3):
+            impl.predictor_train_step(m, opt, past, fut, 0.01, 1e-6, 1.0, sync=False)
+        alone[tag] = digest(opt)
+        del m, opt
+    a, b = make("A"), make("B")
+    assert a[1].ctx is not b[1].ctx and a[1].ctx is not ops.current()
+    for i in range(3):
+        impl.predictor_train_step(a[0], a[1], a[2], a[3], 0.01, 1e-6, 1.0, sync=False)
+        impl.predictor_train_step(b[0], b[1], b[2], b[3], 0.01, 1e-6, 1.0, sync=False)
+    assert digest(a[1]) == alone["A"], "trainer A stepped beside trainer B differs from A alone"
+    assert digest(b[1]) == alone["B"], "trainer B stepped beside trainer A differs from B alone"
+    assert a[1].ctx.rng.seed is not b[1].ctx.rng.seed
+    with ops.use(b[1].ctx):
+        ops.RangeGuard.fallback = True                     # B's guard fires (through the module-level name, under B's context) ...
+    assert b[1].ctx.range_guard.fallback
+    assert not a[1].ctx.range_guard.fallback and not ops.RangeGuard.fallback      # ... A's and the default context's do not
+    ops.WgradStream.BATCH = ops.WgradStream.BATCH          # (configuration goes to the class: one knob for every trainer)
+    assert "BATCH" not in a[1].ctx.wgrad.__dict__
+
+
 def test_deferred_parameter_gradient_reductions(impl):
     """ops.ReduceQueue: the LayerNorm / frame-LayerNorm / depthwise parameter-gradient partials summed by a few npvp_sum_rows_multi
     launches when the backward pass ends, against one reduction launch per site (same partials, a different split of the partial
@@ -321,30 +369,26 @@ def test_deferred_parameter_gradient_reductions(impl):
         ops.ReduceQueue.enabled = old
 
 
-@pytest.mark.parametrize("which", ["dual_encoder", "decoder_split"])
-def test_stream_experiments_keep_the_amax_slots_ordered(impl, which):
-    """the opt-in stream experiments (NPVP_DUAL_ENCODER: the two NPVP-S encoder passes on two streams, forward and
-    backward; NPVP_DECODER_SPLIT: the decoder's half-batches on two streams) cut fp16 amax slots inside their auxiliary-stream
-    regions.  A slot chunk is now per (device, stream) - zero-filled on the stream that cuts from it - so a step with either
-    switch on must still meet the reference's training-step vectors (a slot that read 0 would flush 1e-8-sized gradients)."""
+def test_stream_experiments_keep_the_amax_slots_ordered(impl):
+    """the opt-in stream experiment (NPVP_DUAL_ENCODER: the two NPVP-S encoder passes on two streams, forward and
+    backward) cuts fp16 amax slots inside its auxiliary-stream region.  A slot chunk is per (device, stream) - zero-filled on the
+    stream that cuts from it - so a step with the switch on must still meet the reference's training-step vectors (a slot that
+    read 0 would flush 1e-8-sized gradients)."""
     from npvp_amd import ops
     if MODE != "f16x3":
         pytest.skip("amax slots belong to the f16x3 arithmetic")
-    old = (ops.AuxStream.enabled, ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows)
+    old = ops.AuxStream.enabled
     try:
-        if which == "dual_encoder":
-            ops.AuxStream.enabled = True
-        else:
-            ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows = True, 1
+        ops.AuxStream.enabled = True
         ops.AmaxSlot.reset_chunks()
         mk = lambda m: impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
         res = GC.case_train_step(impl, DEV, "S", make_opt=mk)
         g = GC.load("train_step_S")
         GC.compare({k: v for k, v in res.items() if k.endswith("_0")}, {k: v for k, v in g.items() if k.endswith("_0")}, TOL,
-                   tag=f"train_step_S[{which}]")
+                   tag="train_step_S[dual_encoder]")
         GC.compare({k: v for k, v in res.items() if k.endswith("_1")}, {k: v for k, v in g.items() if k.endswith("_1")}, max(3e-3, TOL))
     finally:
-        ops.AuxStream.enabled, ops.DecoderSplit.enabled, ops.DecoderSplit.min_rows = old
+        ops.AuxStream.enabled = old
         ops.AmaxSlot.reset_chunks()
         torch.cuda.synchronize()
 

@@ -1,6 +1,6 @@
 """Run-to-run bitwise reproducibility soak of the predictor train step (GPU).
 
-    B=32 RUNS=12 [NPVP_MID_BWD_FENCE=0] python tools/determinism_soak.py
+    B=32 RUNS=12 python tools/determinism_soak.py
 
 Builds the same model RUNS times from the same seeds, takes 3 training steps on the same synthetic features and
 prints the number of distinct SHA-256 digests of the flat parameter buffer (1 = reproducible).  DESIGN.md section 7
@@ -36,4 +36,4 @@ for r in range(RUNS):
     torch.cuda.synchronize()
     digests.append(hashlib.sha256(opt.flat_p.cpu().numpy().tobytes()).hexdigest()[:8])
     del m, opt
-print(f"B={B} runs={RUNS} fence={'on' if ops.MID_BWD_FENCE else 'off'}: {len(set(digests))} distinct digest(s): {digests}")
+print(f"B={B} runs={RUNS}: {len(set(digests))} distinct digest(s): {digests}")

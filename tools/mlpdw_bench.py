@@ -1,5 +1,5 @@
 """MlpDWBN forward + backward at a workload's decoder size (frames of 64 tokens, C = 512, hidden = 2048), stand-alone.
-python tools/mlpdw_bench.py [frames]   (NPVP_MID_BWD_N2=0/1, NPVP_WGRAD_STREAM=0 for one stream)"""
+python tools/mlpdw_bench.py [frames]   (NPVP_WGRAD_STREAM=0 for one stream)"""
 import os
 import sys
 import torch
@@ -42,6 +42,6 @@ for _ in range(8):
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ts.sort()
-print(f"frames={frames} N2={os.environ.get('NPVP_MID_BWD_N2', '1')}: backward {ts[len(ts) // 2] * 1e3:.0f} us (median of 8); "
+print(f"frames={frames}: backward {ts[len(ts) // 2] * 1e3:.0f} us (median of 8); "
       f"checks dx {float(gr[0].double().abs().sum()):.6e} dn2w {float(gr[8].double().abs().sum()):.6e} ddww {float(gr[6].double().abs().sum()):.6e} "
       f"dn1w {float(gr[4].double().abs().sum()):.6e}")

@@ -60,6 +60,14 @@ traffic)    # HBM-side traffic of the primary workload (separate FETCH_SIZE / WR
 gemm)       # GEMM micro-benchmarks
   python3 $ROOT/tools/gemm_bench.py --mode f16x3 --rows 114688 20480 8192 --check > "$OUT/gemm_bench_f16x3.txt" 2>/dev/null
   tail -8 "$OUT/gemm_bench_f16x3.txt" ;;
+tiles)      # shard-sized GEMMs: the forward / dgrad tiles and the fused dgrad + weight-gradient launch
+  python3 $ROOT/tools/gemm_bench.py --mode f16x3 --rows 8192 4096 2048 --iters 50 > "$OUT/gemm_bench_small.txt" 2>/dev/null
+  grep -E "all shapes" "$OUT/gemm_bench_small.txt"
+  python3 $ROOT/tools/linear_bwd_bench.py > "$OUT/linear_bwd_bench.txt" 2>&1
+  cat "$OUT/linear_bwd_bench.txt" ;;
+mid)        # MlpDWBN layer backward at the c2 decoder size and at an 8-clip shard's
+  for F in 1792 160; do python3 $ROOT/tools/mlpdw_bench.py $F >> "$OUT/mlpdw_bench.txt" 2>/dev/null; done
+  cat "$OUT/mlpdw_bench.txt" ;;
 *) echo "unknown step $STEP"; exit 2 ;;
 esac
 done
