@@ -218,7 +218,8 @@ int npvp_posfuse_fwd(const float* x, const float* add, const float* beta, const 
 /* bwd: du = d(x+add) [N*T][per_frame]; dbeta / dgamma [T][per_frame] (nullable) = the sums over the batch of dy and dy*uhat (the
  * reference's autograd sums them where beta / gamma broadcast over N).  npvp_posfuse_bwd_fused(N, T, per_frame) == 1: they come out
  * of the apply pass itself (the batch loop runs inside the thread; dyxh is not touched and may be NULL); == 0 (few (t, e) columns,
- * many samples): dyxh [N*T][per_frame] is scratch for dy*uhat and two reductions follow. */
+ * many samples): dyxh [N*T][per_frame] is scratch for dy*uhat and two reductions follow.  accumulate = 1: dbeta / dgamma += (a
+ * positional table feeds ~30 sub-layers per step: its gradient is summed in place instead of by autograd's add kernels). */
 /* The pre-norm LayerNorm of an attention sub-layer and the positional fuse of its output in ONE kernel (frames of P = 64 token rows,
  * C = 512): y1 = LayerNorm(x) [N*T*P][C] with its row statistics ln_mean / ln_rstd [N*T*P], fused = posfuse(y1 (+ add)) with
  * its frame statistics pf_mean / pf_rstd [N*T]; the same results as npvp_layernorm_fwd followed by npvp_posfuse_fwd. */
@@ -228,7 +229,7 @@ int npvp_ln_posfuse_fwd(const float* x, const float* lw, const float* lb, float 
 int npvp_posfuse_bwd_fused(int N, int T, int per_frame);
 int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
                      const float* rstd, float* du, float* dyxh, float* dbeta, float* dgamma, int N, int T, int per_frame,
-                     void* workspace, long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
+                     int accumulate, void* workspace, long long ws_bytes /* >= 8*N*T */, npvp_stream_t stream);
 
 /* param_free_norm_type = 'instance' of the same module (ref/models/submodules.py:427-431: InstanceNorm2d(affine=False), statistics
  * per (frame, channel) over the P = H*W <= 64 pixels): x [N*T][P][C] channels-last, add [N][P][C] or NULL, beta / gamma [T][P][C],
@@ -350,7 +351,7 @@ int npvp_transpose(const float* in, float* out, int batch, int R, int C, npvp_st
 int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int C, npvp_stream_t stream);
 /* forward direction: weight [C][1][3][3] + bias [C] (NULL = zeros) -> the tap-major table wtb [10][C] (9 tap rows + the bias row) */
 int npvp_dwtb_build(const float* w, const float* b, float* wtb, int C, npvp_stream_t stream);
-int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
+int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, int accumulate, npvp_stream_t stream);    /* accumulate = 1: out += */
 int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, npvp_stream_t stream);
 
 /* out[n] = sum_r x[r][n]: bias gradients of every Linear / Conv2d on the path */

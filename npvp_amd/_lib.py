@@ -53,7 +53,7 @@ SIGNATURES = {
     "npvp_ln_posfuse_fwd": (c_int, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f,
                                     c_p, c_p, c_p]),
     "npvp_posfuse_bwd_fused": (c_int, [c_int, c_int, c_int]),
-    "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_ll, c_p]),
+    "npvp_posfuse_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_ll, c_p]),
     "npvp_frameln_act_fwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int, c_p, c_p, c_p]),
     "npvp_frameln_act_bwd_workspace_bytes": (c_ll, [c_int, c_int]),
     "npvp_frameln_act_bwd": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f, c_u, c_f, c_u, c_int,
@@ -84,7 +84,7 @@ SIGNATURES = {
     "npvp_transpose": (c_int, [c_p, c_p, c_int, c_int, c_int, c_p]),
     "npvp_dwtb_accumulate": (c_int, [c_p, c_p, c_p, c_int, c_p]),
     "npvp_dwtb_build": (c_int, [c_p, c_p, c_p, c_int, c_p]),
-    "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
+    "npvp_reduce_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_int, c_p]),
     "npvp_broadcast_mid": (c_int, [c_p, c_p, c_int, c_int, c_ll, c_f, c_p]),
     "npvp_colsum_workspace_bytes": (c_ll, [c_ll, c_int]),
     "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_int, c_p, c_ll, c_p]),

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // out[a][c] = scale * sum_b in[a][b][c]
 __global__ void reduce_mid_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int B, long long Cc,
-                                  float scale) {
+                                  float scale, int accum) {
   const long long c4n = Cc / 4, total4 = (long long)A * c4n;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const long long a = i / c4n, c = (i - a * c4n) * 4;
@@ -70,6 +70,7 @@ __global__ void reduce_mid_kernel(const float* __restrict__ in, float* __restric
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    if (accum) { const float4 o = ld4(out + a * Cc + c); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
     st4(out + a * Cc + c, s);
   }
 }
@@ -215,16 +216,17 @@ extern "C" int npvp_dwtb_accumulate(const float* dwtb, float* gw, float* gb, int
   return NPVP_OK;
 }
 
-int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
+int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream, int accumulate) {
   NPVP_CHECK_ARG(A > 0 && B > 0 && Cc > 0 && Cc % 4 == 0, "reduce_mid: bad shape");
   NPVP_LAUNCH(reduce_mid_kernel, dim3(ew_blocks((long long)A * Cc / 4, 256)), dim3(256), 0, stream, in, out, A, B, Cc,
-                     scale);
+                     scale, accumulate ? 1 : 0);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;
 }
 
-extern "C" int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {
-  return npvp_reduce_mid_launch(in, out, A, B, Cc, scale, stream);
+extern "C" int npvp_reduce_mid(const float* in, float* out, int A, int B, long long Cc, float scale, int accumulate,
+                               hipStream_t stream) {
+  return npvp_reduce_mid_launch(in, out, A, B, Cc, scale, stream, accumulate);
 }
 
 extern "C" int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream) {

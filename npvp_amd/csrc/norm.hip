@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void posfuse_bwd_apply_nsum_kernel(const float
                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                      const float* __restrict__ s1, const float* __restrict__ s2,
                                                                      float* __restrict__ du, float* __restrict__ dbeta,
-                                                                     float* __restrict__ dgamma, int N, int T, int per_frame) {
+                                                                     float* __restrict__ dgamma, int N, int T, int per_frame, int accum) {
   const int pf4 = per_frame / 4;
   const int t = blockIdx.x / (pf4 / 256), e = ((blockIdx.x % (pf4 / 256)) * 256 + threadIdx.x) * 4;
   float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -494,8 +494,14 @@ __global__ __launch_bounds__(256) void posfuse_bwd_apply_nsum_kernel(const float
     sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
     sg.x += d.x * uh.x; sg.y += d.y * uh.y; sg.z += d.z * uh.z; sg.w += d.w * uh.w;
   }
-  if (dbeta) st4(dbeta + (long long)t * per_frame + e, sb);
-  if (dgamma) st4(dgamma + (long long)t * per_frame + e, sg);
+  if (dbeta) {
+    if (accum) { const float4 o = ld4(dbeta + (long long)t * per_frame + e); sb.x += o.x; sb.y += o.y; sb.z += o.z; sb.w += o.w; }
+    st4(dbeta + (long long)t * per_frame + e, sb);
+  }
+  if (dgamma) {
+    if (accum) { const float4 o = ld4(dgamma + (long long)t * per_frame + e); sg.x += o.x; sg.y += o.y; sg.z += o.z; sg.w += o.w; }
+    st4(dgamma + (long long)t * per_frame + e, sg);
+  }
 }
 
 // ------------------------------------------------------------------ PosFeatFuser, param_free_norm_type = 'instance'
@@ -1004,13 +1010,13 @@ extern "C" int npvp_posfuse_bwd_fused(int N, int T, int per_frame) {
   return (blocks >= 128 || N <= 16) ? 1 : 0;
 }
 
-int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream);   // elementwise.hip
+int npvp_reduce_mid_launch(const float* in, float* out, int A, int B, long long Cc, float scale, hipStream_t stream, int accumulate = 0);   // elementwise.hip
 
 // du [N*T, per_frame]; dbeta / dgamma [T, per_frame] (nullable) = sum over the batch of dy / dy*uhat; dyxh (nullable) = scratch
 // for dy*uhat, needed only when npvp_posfuse_bwd_fused(N, T, per_frame) == 0 and dgamma is wanted; ws = 2*N*T floats
 extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* add, const float* gamma, const float* mean,
                                 const float* rstd, float* du, float* dyxh, float* dbeta, float* dgamma, int N, int T,
-                                int per_frame, void* workspace, long long ws_bytes, hipStream_t stream) {
+                                int per_frame, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
   const int frames = N * T;
   NPVP_CHECK_ARG(N > 0 && T > 0 && per_frame % 4 == 0, "posfuse_bwd: bad shape");
   NPVP_CHECK_ARG(workspace && ws_bytes >= (long long)frames * 2 * 4, "posfuse_bwd: workspace too small");
@@ -1021,7 +1027,7 @@ extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* ad
   NPVP_CHECK_LAUNCH();
   if (npvp_posfuse_bwd_fused(N, T, per_frame)) {
     NPVP_LAUNCH(posfuse_bwd_apply_nsum_kernel, dim3(T * (per_frame / 1024)), dim3(256), 0, stream, dy, x, add, gamma, mean,
-                       rstd, (const float*)s1, (const float*)s2, du, dbeta, dgamma, N, T, per_frame);
+                       rstd, (const float*)s1, (const float*)s2, du, dbeta, dgamma, N, T, per_frame, accumulate ? 1 : 0);
     NPVP_CHECK_LAUNCH();
     return NPVP_OK;
   }
@@ -1030,8 +1036,8 @@ extern "C" int npvp_posfuse_bwd(const float* dy, const float* x, const float* ad
   NPVP_LAUNCH(posfuse_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, stream, dy, x, add, gamma, mean,
                      rstd, (const float*)s1, (const float*)s2, du, dgamma ? dyxh : nullptr, T, per_frame, total4);
   NPVP_CHECK_LAUNCH();
-  if (dbeta) { const int rc = npvp_reduce_mid_launch(dy, dbeta, 1, N, (long long)T * per_frame, 1.f, stream); if (rc) return rc; }
-  if (dgamma) { const int rc = npvp_reduce_mid_launch(dyxh, dgamma, 1, N, (long long)T * per_frame, 1.f, stream); if (rc) return rc; }
+  if (dbeta) { const int rc = npvp_reduce_mid_launch(dy, dbeta, 1, N, (long long)T * per_frame, 1.f, stream, accumulate); if (rc) return rc; }
+  if (dgamma) { const int rc = npvp_reduce_mid_launch(dyxh, dgamma, 1, N, (long long)T * per_frame, 1.f, stream, accumulate); if (rc) return rc; }
   return NPVP_OK;
 }
 
@@ -1089,7 +1095,15 @@ extern "C" int npvp_frameln_act_fwd_parts(const float* h, const float* part, int
 // frame chunks (grid.y) of the one-pass backward: 32 x 128 = 4096 workgroups.  With 8 (1024 workgroups, each walking 224 frames
 // at c2) the kernel was as fast stand-alone (921 vs 923 us for statistics + apply) but lost CU slots to the co-resident
 // weight-gradient GEMM: c2 step 342.7 -> 338.3 ms (three A/B pairs on one box; 64 chunks: 338.1).
-static int fln_chunks(int frames) { return frames < 32 ? frames : 32; }
+// frame chunks of the backward kernels' parameter-gradient partials ([chunks][2 * per_frame] floats, summed later).  32 for the
+// large workloads (with 8 the kernels lost their CU share to a co-resident weight-gradient GEMM); for fewer
+// than 512 frames at most 16 chunks of at least two frames: an 8-clip shard's 160 frames in 32 chunks left partials 40 % the size
+// of the tensor itself behind every frame LayerNorm (33 MB per site, written and read again: 1.2 ms of a 33 ms step).
+static int fln_chunks(int frames) {
+  if (frames >= 512) return 32;
+  const int c = frames / 2 < 16 ? frames / 2 : 16;
+  return c < 1 ? 1 : c;
+}
 
 extern "C" long long npvp_frameln_act_bwd_workspace_bytes(int frames, int per_frame) {
   return ((long long)frames * 2 * FLN_PARTS + (long long)fln_chunks(frames) * 2 * per_frame) * 4;

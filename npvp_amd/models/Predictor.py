@@ -55,7 +55,8 @@ class Predictor(nn.Module):
         """(beta, gamma) tables; for fuse_method 'Add' gamma is identically zero (ref submodules.py:309-312) and
         x*(1+0) is exact, so the fuser kernel is told to skip it."""
         beta, gamma = self.nrmlp(coor)
-        return (beta, gamma if self.nrmlp.fuse_method == 'SPADE' else None)
+        # (fan_out: the tables feed every sub-layer - their gradient is summed in place by the consumers, ops.ActSink)
+        return (ops.fan_out(beta), ops.fan_out(gamma) if self.nrmlp.fuse_method == 'SPADE' else None)
 
     # -- helpers on the canonical layout -------------------------------------------------------------
     def _encode(self, feats, pos):
@@ -69,7 +70,7 @@ class Predictor(nn.Module):
     def _decode(self, z, memory, op, pp):
         """z [N, H*W, C] canonical"""
         N, T1, H, W, C = memory.shape
-        zc = z.view(N, H, W, C)
+        zc = ops.fan_out(z.view(N, H, W, C))           # (16 consumers in the decoder: summed in place, ops.ActSink)
         return self.transformer.forward_canonical(zc, memory, op, pp, self.fuser, self.TP, nchw=True)
 
     def _nchw(self, t):

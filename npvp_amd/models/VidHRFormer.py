@@ -419,7 +419,10 @@ class VidHRformerDecoderNAR(nn.Module):
         (nchw=True: the reference's (N,T2,C,H,W) layout instead)."""
         N, H, W, C = qe.shape
         out = torch.zeros(N, T2, H, W, C, dtype=torch.float32, device=qe.device)
-        fused_memory = pos_fuser(memory, *memory_pos)
+        # memory and its fused form are the key / value sources of all the layers' encoder-decoder attention: fan_out lets the
+        # layers' dgrad GEMMs sum their gradients in place (ops.ActSink)
+        fused_memory = ops.fan_out(pos_fuser(memory, *memory_pos))
+        memory = ops.fan_out(memory)
         for layer in self.layers:
             out = layer(out, qe, memory, memory_pos, tgt_pos, pos_fuser, fused_memory)
         if nchw and self.norm is not None and ops.layernorm_nchw_supported(out, H, W):

@@ -409,13 +409,14 @@ def linear_frame_stats_supported(R, N):
     return GEMM_PRECISION in (4, 6) and R % 64 == 0 and N % 128 == 0
 
 
-def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None, a_drop=NO_DROP):
-    """dx[R,K] = epilogue((a_drop mask on the rows of dy) dy[R,N] w[N,K])"""
+def linear_dgrad(dy, w, act=0, aux_in=None, drop=NO_DROP, residual=None, dy_amax=None, dx_amax=None, a_drop=NO_DROP, out=None,
+                 accumulate=False):
+    """dx[R,K] = epilogue((a_drop mask on the rows of dy) dy[R,N] w[N,K]); out / accumulate: into (added to) an existing [R,K] buffer"""
     R, N = dy.shape
     K = w.shape[1]
-    dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(R, K, dtype=torch.float32, device=dy.device) if out is None else out
     return gemm(1, 0, R, K, N, dy, dy.stride(0), w, w.stride(0), dx, act=act, aux_in=aux_in, drop=drop, residual=residual,
-                b_pre=_planes(w, "D", R), replay=True, a_amax=dy_amax, c_amax=dx_amax, a_drop=a_drop)
+                b_pre=_planes(w, "D", R), replay=True, a_amax=dy_amax, c_amax=dx_amax, a_drop=a_drop, accumulate=accumulate)
 
 
 def masked_grad(dy2, drop, w):
@@ -580,13 +581,66 @@ def transpose(x):
     return out
 
 
-def reduce_mid(x, scale=1.0):
-    """[A,B,C] -> [A,C]: scale * sum over B"""
+def reduce_mid(x, scale=1.0, out=None, accumulate=False):
+    """[A,B,C] -> [A,C]: scale * sum over B (into `out`, added to it with accumulate)"""
     _chk(x)
     x = _c(x)
     A, B, C = x.shape
-    out = torch.empty(A, C, dtype=torch.float32, device=x.device)
-    check(lib().npvp_reduce_mid(_ptr(x), _ptr(out), A, B, C, scale, _stream()), "npvp_reduce_mid")
+    if out is None:
+        out = torch.empty(A, C, dtype=torch.float32, device=x.device)
+    check(lib().npvp_reduce_mid(_ptr(x), _ptr(out), A, B, C, scale, 1 if accumulate else 0, _stream()), "npvp_reduce_mid")
+    return out
+
+
+class ActSink:
+    """The gradient of an activation that feeds MANY sub-layers - a positional table (~30 per step), the event latent (16), the
+    decoder's memory and its fused key (8 each) - summed IN PLACE by its consumers' backward kernels (the `accumulate` flag of
+    npvp_posfuse_bwd / npvp_reduce_mid / the dgrad GEMM) instead of by one autograd add kernel per consumer (75 launches per
+    step).  `fan_out(t)` returns t as seen through an identity node that owns a sink; a consumer that finds `t._npvp_sink` writes
+    its share into `sink.target(...)` and returns None for that input; the identity node's backward hands the buffer on (plus
+    whatever consumers without the in-place route returned the usual way)."""
+    __slots__ = ("buf",)
+    enabled = True
+
+    def __init__(self):
+        self.buf = None
+
+    def target(self, shape, dev):
+        """-> (buffer, accumulate): the first contribution of a backward pass writes, the others add"""
+        if self.buf is None:
+            self.buf = torch.empty(shape, dtype=torch.float32, device=dev)
+            return self.buf, False
+        return self.buf, True
+
+    @staticmethod
+    def of(t):
+        return None if t is None else getattr(t, "_npvp_sink", None)
+
+
+class _FanOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, sink):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.sink.buf = ctx.sink.buf, None
+        if buf is None:
+            return g, None
+        if g is not None:
+            buf.add_(g.reshape(buf.shape))
+        return buf, None
+
+
+def fan_out(t):
+    """t for consumers that can sum their gradient contributions in place (ActSink); anything else sees a plain tensor"""
+    if t is None or not (ActSink.enabled and t.is_cuda and t.requires_grad and torch.is_grad_enabled()):
+        return t
+    sink = ActSink()
+    out = _FanOut.apply(t, sink)
+    out._npvp_sink = sink
     return out
 
 
@@ -852,19 +906,27 @@ class _PosFuse(torch.autograd.Function):
         return du, dadd, dbeta, dgamma, None, None
 
 
-def _posfuse_bwd_call(dy, x, add, gamma, mean, rstd, N, T, PF, beta_shape, want_beta, want_gamma):
+def _posfuse_bwd_call(dy, x, add, gamma, mean, rstd, N, T, PF, beta_shape, want_beta, want_gamma, beta_sink=None, gamma_sink=None):
     """-> du, dbeta, dgamma: one entry point; the sums over the batch come out of the apply pass when the shape allows
-    (npvp_posfuse_bwd_fused), else through a dy*uhat scratch and two reductions inside the library"""
+    (npvp_posfuse_bwd_fused), else through a dy*uhat scratch and two reductions inside the library.  With sinks (ActSink) the
+    table gradients are accumulated in place and None is returned for them."""
     L = lib()
     du = torch.empty_like(x)
-    dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device) if want_beta else None
-    dgamma = torch.empty(gamma.shape, dtype=torch.float32, device=x.device) if want_gamma else None
+    acc = False
+    sunk = beta_sink is not None and want_beta and (not want_gamma or gamma_sink is not None)
+    if sunk:
+        # (one accumulate flag for both tables: they are sunk together - a fresh pair is written, an existing pair added to)
+        dbeta, acc = beta_sink.target(beta_shape, x.device)
+        dgamma = gamma_sink.target(gamma.shape, x.device)[0] if want_gamma else None
+    else:
+        dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device) if want_beta else None
+        dgamma = torch.empty(gamma.shape, dtype=torch.float32, device=x.device) if want_gamma else None
     dyxh = torch.empty_like(x) if (want_gamma and not L.npvp_posfuse_bwd_fused(N, T, PF)) else None
     ws, wsn = _ws(8 * N * T, x.device)
     mp, rp = (mean, rstd) if isinstance(mean, int) else (_ptr(mean), _ptr(rstd))        # (tensors or device addresses)
     check(L.npvp_posfuse_bwd(_ptr(dy), _ptr(x), _ptr(add), _ptr(gamma), mp, rp, _ptr(du), _ptr(dyxh), _ptr(dbeta),
-                             _ptr(dgamma), N, T, PF, _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
-    return du, dbeta, dgamma
+                             _ptr(dgamma), N, T, PF, 1 if acc else 0, _ptr(ws), wsn, _stream()), "npvp_posfuse_bwd")
+    return (du, None, None) if sunk else (du, dbeta, dgamma)
 
 
 def posfuse(x, add, beta, gamma, N, T):
@@ -1527,11 +1589,19 @@ def _raw_ln_posfuse_fwd(x2, lw, lb, eps, add, beta, gamma, N, T):
     return tag_amax(x1, s1), lst, tag_amax(fused, s2), pst
 
 
-def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add):
-    """-> du [like x], dadd, dbeta, dgamma"""
+def _raw_posfuse_bwd(dy, x, add, beta_shape, gamma, st, N, T, want_add, sinks=(None, None, None)):
+    """-> du [like x], dadd, dbeta, dgamma; sinks = the ActSinks of (beta, gamma, add) where the caller found them: those gradients
+    are accumulated in place and come back as None"""
     PF = x.numel() // (N * T)
-    du, dbeta, dgamma = _posfuse_bwd_call(dy, x, add, gamma, _row(st, 0), _row(st, 1), N, T, PF, beta_shape, True, gamma is not None)
-    dadd = reduce_mid(du.view(N, T, PF)).view(add.shape) if (add is not None and want_add) else None
+    du, dbeta, dgamma = _posfuse_bwd_call(dy, x, add, gamma, _row(st, 0), _row(st, 1), N, T, PF, beta_shape, True, gamma is not None,
+                                          sinks[0], sinks[1])
+    dadd = None
+    if add is not None and want_add:
+        if sinks[2] is not None:
+            buf, acc = sinks[2].target(add.shape, x.device)
+            reduce_mid(du.view(N, T, PF), out=buf.view(N, PF), accumulate=acc)
+        else:
+            dadd = reduce_mid(du.view(N, T, PF)).view(add.shape)
     return du, dadd, dbeta, dgamma
 
 
@@ -1568,6 +1638,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
         _attn_fwd(qk[:, :C], qk[:, C:], v, o, cfg)
         y = linear_fwd(o, wo, bo, residual=x2, drop=drop)
         ctx.save_for_backward(x2, x1, lst, fused, pst, qk, v, o, lw, lb, gamma_c, add_c, wqk, bqk, wv, bv, wo, bo)
+        ctx.act_sinks = (ActSink.of(beta), ActSink.of(gamma), ActSink.of(add))
         ctx.cfg = (cfg, drop, N, T, x.shape, beta.shape)
         ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wqk, bqk), _wb_sink(wv, bv), _wb_sink(wo, bo))
         return y.view(x.shape)
@@ -1584,7 +1655,7 @@ class _SelfAttnSublayer(torch.autograd.Function):
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
         _attn_bwd(qk[:, :C], qk[:, C:], v, do, dqk[:, :C], dqk[:, C:], dv, cfg, packed=dqk)
         dfused, gwqk, gbqk = linear_bwd(dqk, fused, wqk, bqk, s_qk)
-        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dfused, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
+        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dfused, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6], ctx.act_sinks)
         # dx1 = dv Wv + du: the second consumer's gradient rides in as the dgrad GEMM's residual input (no separate add)
         dx1, gwv, gbv = linear_bwd(dv, x1, wv, bv, s_v, residual=du)
         dx, glw, glb = _raw_ln_bwd(dx1, x2, lw, lb, lst, dy2, s_ln)
@@ -1613,6 +1684,8 @@ class _CrossAttnSublayer(torch.autograd.Function):
         _attn_fwd(q, k, v, o, cfg)
         y = linear_fwd(o, wo, bo, residual=x2, drop=drop)
         ctx.save_for_backward(x2, x1, lst, query, pst, q, k, v, o, k2, m2, lw, lb, gamma_c, add_c, wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.act_sinks = (ActSink.of(beta), ActSink.of(gamma), ActSink.of(add))
+        ctx.km_sinks = (ActSink.of(key), ActSink.of(memory))
         ctx.cfg = (cfg, drop, N, T, x.shape, beta.shape, key.shape, memory.shape)
         ctx.sinks = (_ln_sink(lw, lb), _wb_sink(wq, bq), _wb_sink(wk, bk), _wb_sink(wv, bv), _wb_sink(wo, bo))
         return y.view(x.shape)
@@ -1629,10 +1702,20 @@ class _CrossAttnSublayer(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _attn_bwd(q, k, v, do, dq, dk, dv, cfg)
         dquery, *gq = linear_bwd(dq, query, wq, bq, s_q)
-        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dquery, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6])
-        dkey = linear_dgrad(dk, wk).view(kshape) if ctx.needs_input_grad[7] else None
+        du, dadd, dbeta, dgamma = _raw_posfuse_bwd(dquery, x1, add, beta_shape, gamma, pst, N, T, ctx.needs_input_grad[6], ctx.act_sinks)
+        dkey = dmem = None
+        for need, g_, w_, sink, shape, which in ((ctx.needs_input_grad[7], dk, wk, ctx.km_sinks[0], kshape, 0),
+                                                 (ctx.needs_input_grad[8], dv, wv, ctx.km_sinks[1], mshape, 1)):
+            if not need:
+                continue
+            if sink is not None:        # the decoder's 8 layers share key / memory: their gradients are summed by the dgrad GEMMs' epilogues
+                buf, acc = sink.target(shape, g_.device)
+                linear_dgrad(g_, w_, out=buf.view(g_.shape[0], C), accumulate=acc)
+            elif which == 0:
+                dkey = linear_dgrad(g_, w_).view(shape)
+            else:
+                dmem = linear_dgrad(g_, w_).view(shape)
         gk = _lin_grads(dk, k2, wk, bk, s_k)
-        dmem = linear_dgrad(dv, wv).view(mshape) if ctx.needs_input_grad[8] else None
         gv = _lin_grads(dv, m2, wv, bv, s_v)
         dx, glw, glb = _raw_ln_bwd(du, x2, lw, lb, lst, dy2, s_ln)
         return (dx.view(xshape), glw, glb, None, dbeta, dgamma, dadd, dkey, dmem, gq[0], gq[1], gk[0], gk[1], gv[0], gv[1], gwo, gbo,

@@ -333,6 +333,46 @@ def test_two_trainers_in_one_process_do_not_share_state(impl):
     assert "BATCH" not in a[1].ctx.wgrad.__dict__
 
 
+@pytest.mark.parametrize("variant", ["D", "S"])
+def test_activation_gradients_summed_in_place(impl, variant):
+    """ops.ActSink / ops.fan_out: the gradients of the positional tables, of the event latent and of the decoder's memory / fused
+    key - each the sum over 8 ... 30 consumers - accumulated in place by the consumers' backward kernels against autograd's add
+    kernels: same gradients (summation order differs: equal to rounding), ~60 launches fewer per step."""
+    from npvp_amd import ops
+    N, To, Tp = 2, 3, 4
+    past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
+    fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
+    old = ops.ActSink.enabled
+    res, launches = {}, {}
+    try:
+        for on in (True, False):
+            ops.ActSink.enabled = on
+            m = GC._small_predictor(impl, variant == "S", 101, DEV, To=To, Tp=Tp, dropout=0.0, drop_path=0.0)
+            m.train()
+            opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+            ops.rng.manual_seed(777, torch.device(DEV))
+            ops.rng.begin_step(torch.device(DEV))
+            opt.zero_grad()
+            torch.manual_seed(5)
+            p_in = past.clone().requires_grad_(True)
+            torch.cuda.synchronize()
+            k0 = torch.cuda.memory_stats()["num_alloc_retries"]          # (any cheap counter: the launch count below is what is compared)
+            n0 = impl._lib.lib().npvp_launch_count()
+            out = m(p_in, fut) if variant == "S" else m(p_in)
+            y = out[0] if variant == "S" else out
+            (y - fut).abs().mean().backward()
+            ops.WgradStream.join()
+            torch.cuda.synchronize()
+            launches[on] = impl._lib.lib().npvp_launch_count() - n0
+            res[on] = (opt.flat_g.clone(), p_in.grad.clone())
+        for a, b, what in ((res[True][0], res[False][0], "parameter gradients"), (res[True][1], res[False][1], "input gradient")):
+            assert GC.rel_err(a, b) < 1e-6, f"{what}: {GC.rel_err(a, b):.3e}"
+        n = res[True][0].numel() // 1024 * 1024
+        assert GC.max_row_rel_err(res[True][0][:n].view(-1, 1024), res[False][0][:n].view(-1, 1024), 1e-9) < 1e-4
+    finally:
+        ops.ActSink.enabled = old
+
+
 def test_deferred_parameter_gradient_reductions(impl):
     """ops.ReduceQueue: the LayerNorm / frame-LayerNorm / depthwise parameter-gradient partials summed by a few npvp_sum_rows_multi
     launches when the backward pass ends, against one reduction launch per site (same partials, a different split of the partial

@@ -344,7 +344,7 @@ def test_dropout_statistics_and_replay(K):
     assert torch.equal(gx != 0, yy != 0)
 
 
-@pytest.mark.parametrize("R,g1,g2", [(4096, 512, 8), (8192, 64, 16)])
+@pytest.mark.parametrize("R,g1,g2", [(4096, 512, 8), (8192, 64, 16), (2048, 64, 32)])
 def test_drop_path_mask_rides_in_the_gemms(K, R, g1, g2):
     """The backward of a DropPath site: the row-group mask folded into the dgrad and weight-gradient GEMMs (a_drop: the scale of
     the staged rows / of the K-step, bias gradient included) against the masked copy of dy (npvp_drop_apply) + plain GEMMs."""
