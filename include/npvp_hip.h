@@ -329,7 +329,9 @@ int npvp_dwconv3x3_wgrad(const float* a, const float* dout, float* dwt_db, int f
  * :298-300 (spatial window; window gather = ref :447-475 as index math)).
  *   mode 0 spatial: dim0 = N*T frames, groups = frames x windows, L = S = ws*ws
  *   mode 1 temporal: dim0 = N, groups = N x P pixels, L = Tq, S = Tk (rows (n*T + t)*P + p)
- *   mask_mode 1 = encoder quirk ref :100-102.  q NOT pre-scaled; head_dim must be 64; L,S <= 32. */
+ *   mask_mode 1 = encoder quirk ref :100-102.  q NOT pre-scaled; head_dim must be 64; L, S <= 128 (up to 32: the MFMA kernels every shipped
+ *   configuration runs on; 33 .. 128: generic kernels - one workgroup per (group, head), operands in LDS, scalar fp32 arithmetic:
+ *   the reference's nn.MultiheadAttention has no length limit, ref VidHRFormer.py:94-107). */
 int npvp_attn_fwd(const float* q, long long ld_q, const float* k, long long ld_k, const float* v, long long ld_v, float* o,
                   long long ld_o, int mode, int dim0, int P, int W, int ws, int Tq, int Tk, int heads, int head_dim,
                   int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, float* o_amax,

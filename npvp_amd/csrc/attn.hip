@@ -485,6 +485,165 @@ __global__ __launch_bounds__(64, 2) void attn_bwd_staged1_kernel(AttnParams p) {
   amax_slot_commit(p.dv_amax, am_v, pk_v);
 }
 
+// =====================================================================================================
+// Generic form: sequence lengths 33 .. 128 (round 5).  The reference has no limit on the sequence length (ref
+// VidHRFormer.py:94-107: nn.MultiheadAttention over T frames); every shipped configuration has T <= 30 and runs on the MFMA
+// kernels above, whose operand layouts are written for one or two 16-row blocks per side.  Longer sequences - a clip of 40 frames,
+// an 8 x 8 window - take these kernels instead of being refused: one workgroup per (group, head), K / V (backward: Q, K, V, dO) of
+// that head staged in LDS, one thread per query row (backward: per query row, then per key row), scalar fp32 arithmetic, the
+// softmax statistics recomputed per pass instead of stored.  Same mask function, same dropout keys, same amax commits as the MFMA
+// kernels.  Correct, deterministic, not fast (O(L S d) scalar multiply-adds per pass): a correctness route, not a tuned one.
+constexpr int GEN_MAX = 128, GEN_THREADS = 128;
+
+__device__ __forceinline__ void gen_stage(float* dst, const float* src, long long ld, const AttnParams& p, const AttnRows& g, int rows_n,
+                                          int Tn, int head) {
+  for (int i = threadIdx.x; i < rows_n * (HD / 4); i += GEN_THREADS) {
+    const int j = i / (HD / 4), c4 = i - j * (HD / 4);
+    *reinterpret_cast<float4*>(dst + j * HD + 4 * c4) = ld4(src + attn_row(g, j, Tn) * ld + head * HD + 4 * c4);
+  }
+}
+__device__ __forceinline__ float gen_dot(const float* a, const float* b) {        // a in registers / LDS, b in LDS: 64-term dot product
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(a + d), y = *reinterpret_cast<const float4*>(b + d);
+    s += x.x * y.x; s += x.y * y.y; s += x.z * y.z; s += x.w * y.w;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(GEN_THREADS) void attn_fwd_generic_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const long long wid = blockIdx.x;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  float* Ks = gsm; float* Vs = gsm + S * HD;
+  gen_stage(Ks, p.k, p.ld_k, p, g, S, Tk, head);
+  gen_stage(Vs, p.v, p.ld_v, p, g, S, Tk, head);
+  __syncthreads();
+  float am_o = 0.f;
+  const unsigned int pk_o = amax_peek_wave(p.o_amax);
+  for (int q = threadIdx.x; q < L; q += GEN_THREADS) {
+    float qr[HD];
+    const float* qp = p.q + attn_row(g, q, Tq) * p.ld_q + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) { const float4 t = ld4(qp + d); qr[d] = t.x; qr[d + 1] = t.y; qr[d + 2] = t.z; qr[d + 3] = t.w; }
+    float mx = -INFINITY;
+    for (int j = 0; j < S; ++j) {
+      if (p.mask_mode == 1 && j == S - 1 && q < L - 1) continue;
+      mx = fmaxf(mx, gen_dot(qr, Ks + j * HD) * p.scale);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < S; ++j) {
+      if (p.mask_mode == 1 && j == S - 1 && q < L - 1) continue;
+      sum += __expf(gen_dot(qr, Ks + j * HD) * p.scale - mx);
+    }
+    const float inv = 1.f / sum;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int j = 0; j < S; ++j) {
+      if (p.mask_mode == 1 && j == S - 1 && q < L - 1) continue;
+      float pj = __expf(gen_dot(qr, Ks + j * HD) * p.scale - mx) * inv;
+      if (p.drop_thresh) pj *= drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + j, p.drop_thresh, p.drop_inv_keep);
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] += pj * Vs[j * HD + d];
+    }
+    float* op = p.o + attn_row(g, q, Tq) * p.ld_o + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      st4(op + d, make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]));
+      am_o = fmaxf(fmaxf(am_o, fmaxf(fabsf(o[d]), fabsf(o[d + 1]))), fmaxf(fabsf(o[d + 2]), fabsf(o[d + 3])));
+    }
+  }
+  amax_slot_commit(p.o_amax, am_o, pk_o);
+}
+
+__global__ __launch_bounds__(GEN_THREADS) void attn_bwd_generic_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const long long wid = blockIdx.x;
+  const int head = (int)((unsigned int)wid % (unsigned int)p.heads);
+  const AttnRows g = attn_rows(p, (unsigned int)wid / (unsigned int)p.heads);
+  const int L = p.L, S = p.S;
+  const int Tq = p.mode == 1 ? p.Tq : 0, Tk = p.mode == 1 ? p.Tk : 0;
+  const unsigned long long seed = (p.seed && p.drop_thresh) ? *p.seed : 0ull;
+  float* Qs = gsm; float* Gs = Qs + L * HD; float* Ks = Gs + L * HD; float* Vs = Ks + S * HD; float* st = Vs + S * HD;   // st [L][3]
+  gen_stage(Qs, p.q, p.ld_q, p, g, L, Tq, head);
+  gen_stage(Gs, p.go, p.ld_o, p, g, L, Tq, head);
+  gen_stage(Ks, p.k, p.ld_k, p, g, S, Tk, head);
+  gen_stage(Vs, p.v, p.ld_v, p, g, S, Tk, head);
+  __syncthreads();
+  float am_q = 0.f, am_k = 0.f, am_v = 0.f;
+  const unsigned int pk_q = amax_peek_wave(p.dq_amax), pk_k = amax_peek_wave(p.dk_amax), pk_v = amax_peek_wave(p.dv_amax);
+  auto dead = [&](int q, int j) { return p.mask_mode == 1 && j == S - 1 && q < L - 1; };
+  auto mask = [&](int q, int j) {
+    return p.drop_thresh ? drop_scale(seed, p.salt, ((unsigned long long)wid * L + q) * S + j, p.drop_thresh, p.drop_inv_keep) : 1.f;
+  };
+  // phase A: one thread per query row - softmax statistics, delta = sum_j P dP, dQ = scale * sum_j dS K
+  for (int q = threadIdx.x; q < L; q += GEN_THREADS) {
+    const float* qr = Qs + q * HD; const float* gr = Gs + q * HD;
+    float mx = -INFINITY;
+    for (int j = 0; j < S; ++j) if (!dead(q, j)) mx = fmaxf(mx, gen_dot(qr, Ks + j * HD) * p.scale);
+    float sum = 0.f;
+    for (int j = 0; j < S; ++j) if (!dead(q, j)) sum += __expf(gen_dot(qr, Ks + j * HD) * p.scale - mx);
+    const float inv = 1.f / sum;
+    float delta = 0.f;
+    for (int j = 0; j < S; ++j) {
+      if (dead(q, j)) continue;
+      const float pj = __expf(gen_dot(qr, Ks + j * HD) * p.scale - mx) * inv;
+      delta += pj * gen_dot(gr, Vs + j * HD) * mask(q, j);
+    }
+    float dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    for (int j = 0; j < S; ++j) {
+      if (dead(q, j)) continue;
+      const float pj = __expf(gen_dot(qr, Ks + j * HD) * p.scale - mx) * inv;
+      const float ds = pj * (gen_dot(gr, Vs + j * HD) * mask(q, j) - delta) * p.scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dq[d] += ds * Ks[j * HD + d];
+    }
+    st[q * 3] = mx; st[q * 3 + 1] = inv; st[q * 3 + 2] = delta;
+    float* dp = p.dq + attn_row(g, q, Tq) * p.ld_dq + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      st4(dp + d, make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]));
+      am_q = fmaxf(fmaxf(am_q, fmaxf(fabsf(dq[d]), fabsf(dq[d + 1]))), fmaxf(fabsf(dq[d + 2]), fabsf(dq[d + 3])));
+    }
+  }
+  __syncthreads();
+  // phase B: one thread per key row - dV = sum_q (P mask) dO, dK = scale * sum_q dS Q
+  for (int j = threadIdx.x; j < S; j += GEN_THREADS) {
+    const float* kr = Ks + j * HD; const float* vr = Vs + j * HD;
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int q = 0; q < L; ++q) {
+      if (dead(q, j)) continue;
+      const float pj = __expf(gen_dot(Qs + q * HD, kr) * p.scale - st[q * 3]) * st[q * 3 + 1];
+      const float m = mask(q, j);
+      const float ds = pj * (gen_dot(Gs + q * HD, vr) * m - st[q * 3 + 2]) * p.scale, pd = pj * m;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { dv[d] += pd * Gs[q * HD + d]; dk[d] += ds * Qs[q * HD + d]; }
+    }
+    float* kp = p.dk + attn_row(g, j, Tk) * p.ld_dk + head * HD;
+    float* vp = p.dv + attn_row(g, j, Tk) * p.ld_dv + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      st4(kp + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));
+      st4(vp + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+      am_k = fmaxf(fmaxf(am_k, fmaxf(fabsf(dk[d]), fabsf(dk[d + 1]))), fmaxf(fabsf(dk[d + 2]), fabsf(dk[d + 3])));
+      am_v = fmaxf(fmaxf(am_v, fmaxf(fabsf(dv[d]), fabsf(dv[d + 1]))), fmaxf(fabsf(dv[d + 2]), fabsf(dv[d + 3])));
+    }
+  }
+  amax_slot_commit(p.dq_amax, am_q, pk_q);
+  amax_slot_commit(p.dk_amax, am_k, pk_k);
+  amax_slot_commit(p.dv_amax, am_v, pk_v);
+}
+
 static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int frames_or_N, int P, int W, int ws, int Tq,
                       int Tk, int mask_mode, float drop_p, const unsigned long long* seed, unsigned int salt, bool bwd) {
   if (head_dim != HD) { npvp_set_error("attn: head_dim must be 64"); return NPVP_ERR_ARG; }
@@ -499,7 +658,7 @@ static int attn_setup(AttnParams& p, int mode, int heads, int head_dim, int fram
     p.nww = p.nwin = 1; p.L = Tq; p.S = Tk;
     groups = (long long)frames_or_N * P;
   }
-  if (p.L < 1 || p.S < 1 || p.L > 32 || p.S > 32) { npvp_set_error("attn: sequence length must be in [1,32]"); return NPVP_ERR_ARG; }
+  if (p.L < 1 || p.S < 1 || p.L > GEN_MAX || p.S > GEN_MAX) { npvp_set_error("attn: sequence length must be in [1,128]"); return NPVP_ERR_ARG; }
   p.scale = 0.125f;   // 1/sqrt(64)
   p.drop_thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -530,6 +689,15 @@ extern "C" int npvp_attn_fwd(const float* q, long long ld_q, const float* k, lon
   p.q = q; p.k = k; p.v = v; p.o = o; p.ld_q = ld_q; p.ld_k = ld_k; p.ld_v = ld_v; p.ld_o = ld_o;
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
+  if (nq > 2 || nk > 2) {                  // 33 .. 128: the generic kernels (K, V of one head in LDS)
+    const size_t lds = (size_t)2 * p.S * HD * sizeof(float);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attn_fwd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      npvp_set_error("attn: could not reserve LDS for the generic kernel"); return NPVP_ERR_LAUNCH;
+    }
+    NPVP_LAUNCH(attn_fwd_generic_kernel, dim3((unsigned)p.total), dim3(GEN_THREADS), lds, stream, p);
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
+  }
   if (nq == 1 && nk == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<1, 1>), mg, mb, 0, stream, p);
   else if (nq == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<1, 2>), mg, mb, 0, stream, p);
   else if (nk == 1) NPVP_LAUNCH((attn_fwd_mfma_kernel<2, 1>), mg, mb, 0, stream, p);
@@ -555,6 +723,15 @@ extern "C" int npvp_attn_bwd(const float* q, long long ld_q, const float* k, lon
   const size_t staged1_lds = (size_t)(2 * p.L + p.S) * LDT * sizeof(float) + 2 * 16 * LDX * sizeof(float);
   const dim3 mg((unsigned)((p.total + 3) / 4)), mb(256);
   const int nq = (p.L + 15) / 16, nk = (p.S + 15) / 16;
+  if (nq > 2 || nk > 2) {                  // 33 .. 128: the generic kernels (Q, dO, K, V of one head + the row statistics in LDS)
+    const size_t lds = ((size_t)2 * (p.L + p.S) * HD + 3 * (size_t)p.L) * sizeof(float);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attn_bwd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      npvp_set_error("attn_bwd: could not reserve LDS for the generic kernel"); return NPVP_ERR_LAUNCH;
+    }
+    NPVP_LAUNCH(attn_bwd_generic_kernel, dim3((unsigned)p.total), dim3(GEN_THREADS), lds, stream, p);
+    NPVP_CHECK_LAUNCH();
+    return NPVP_OK;
+  }
   // up to 16 query rows: operands straight from global memory; 17 .. 32: Q / dO / K staged once in LDS, one score orientation
   // (tools/attn_bench.py at the c2 size: T = 28 478 us, 28 x 2 205 us, T = 18 293 us - the two-orientation kernel that used to
   // take 17 .. 24 rows needed 382 us there once the address arithmetic was out of the way, and is gone)

@@ -34,7 +34,7 @@ class Predictor(nn.Module):
         else:
             # unified model (ref :281-284): the caller picks the context / target time-steps per batch and points
             # observed_coor / predict_coor / TP at rows of `all_coor` (trainer.rand_context_batch_process); the kernels
-            # take the sequence lengths at run time (any To, Tp <= 32)
+            # take the sequence lengths at run time (any To, Tp <= 128; up to 32 on the MFMA attention kernels)
             self.observed_coor = None
             self.predict_coor = None
             self.register_buffer("all_coor", self.coor_generator(torch.cat([to_list, tp_list]), h_list, w_list)

@@ -11,6 +11,7 @@ import torch
 from ._lib import lib, check
 # scheduling state (per trainer: sched.StepContext) and the process-wide pieces beside it; re-exported here because the rest of the
 # package, the tests and the tools reach them as ops.<name>
+from . import sched as _S            # (hot paths read the current context as _S._cur.<field>: one global + two attribute loads)
 from .sched import (_p, _ptr, _stream, _ws, AmaxSlot, GemmProbe, HbmProbe, AuxStream, StepContext, current, use, scoped,
                     remember, rng, GradSink, WgradStream, WgradChain, ReduceQueue, RangeGuard)
 
@@ -67,7 +68,7 @@ class Drop:
 
     def __init__(self, p=0.0, mode=0, g1=1, g2=1):
         self.p, self.mode, self.g1, self.g2 = float(p), mode, g1, g2
-        self.salt = rng.next_salt() if p > 0 else 0
+        self.salt = _S._cur.rng.next_salt() if p > 0 else 0
 
     @property
     def on(self):
@@ -336,7 +337,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
     if wsb > 0:
         ws, wsn = _ws(wsb, A.device)
     masked = drop.p > 0.0 or a_drop.p > 0.0
-    seed = rng.seed_tensor(A.device) if masked else None
+    seed = _S._cur.rng.seed_tensor(A.device) if masked else None
     if DropRecorder.sites is not None and not replay:
         DropRecorder.note(drop, "elem" if drop.mode == 0 else "group", M * N if drop.mode == 0 else drop.g2)
     # every launch is timed on the stream it runs on, also those that share the device with a kernel of another stream:
@@ -452,16 +453,16 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
     db = (into_b if acc else torch.empty(N, dtype=torch.float32, device=dy.device)) if with_bias_grad else None
     prec = WGRAD_PRECISION if GEMM_PRECISION == 4 else None
     watch = GEMM_PRECISION == 6 and _gemm_kernel_id(0, 0, N, K, R, 6, False) == 6
-    if watch and RangeGuard.fallback and not a_drop.on:
+    if watch and _S._cur.range_guard.fallback and not a_drop.on:
         prec, watch = 4, False                     # (a launch that carries a row-group mask needs the fp16 kernel: it stays there)
-    if watch and RangeGuard.strict and not a_drop.on:
+    if watch and _S._cur.range_guard.strict and not a_drop.on:
         # strict: into a scratch result first, so that a flagged launch leaves the accumulation target untouched
-        flag = RangeGuard.flag(dy.device)
+        flag = _S._cur.range_guard.flag(dy.device)
         tw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
         tb = torch.empty(N, dtype=torch.float32, device=dy.device) if with_bias_grad else None
         gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), tw, colsum_a=tb, a_amax=dy_amax, b_amax=x_amax, range_flag=flag)
-        if RangeGuard.poll(dy.device):
-            RangeGuard.fallback = False             # (strict mode repairs launch by launch)
+        if _S._cur.range_guard.poll(dy.device):
+            _S._cur.range_guard.fallback = False             # (strict mode repairs launch by launch)
             gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), tw, colsum_a=tb, precision=4)
         if acc:
             dw.add_(tw)
@@ -470,10 +471,10 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
         else:
             dw, db = tw, tb
         return (dw, db) if with_bias_grad else dw
-    flag = RangeGuard.flag(dy.device) if watch else None
-    if (watch and acc and prec is None and WgradChain.enabled and WgradStream.in_flush and WgradChain.takes(N, K, R)
+    flag = _S._cur.range_guard.flag(dy.device) if watch else None
+    if (watch and acc and prec is None and _S._cur.chain.enabled and _S._cur.wgrad.in_flush and _S._cur.chain.takes(N, K, R)
             and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1):
-        WgradChain.launch(dy, x, dw, db, amax_of(dy, dy_amax), amax_of(x, x_amax), a_drop, flag)
+        _S._cur.chain.launch(dy, x, dw, db, amax_of(dy, dy_amax), amax_of(x, x_amax), a_drop, flag)
         return (dw, db) if with_bias_grad else dw
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc, precision=prec, a_amax=dy_amax, b_amax=x_amax,
          a_drop=a_drop, range_flag=flag)
@@ -496,7 +497,7 @@ class FusedLinearBwd:
         key = (R, N, K)
         v = cls._ok.get(key)
         if v is None:
-            v = cls._ok[key] = bool(lib().npvp_linear_bwd_f16_takes(R, N, K)) and WgradChain.takes(N, K, R)
+            v = cls._ok[key] = bool(lib().npvp_linear_bwd_f16_takes(R, N, K)) and _S._cur.chain.takes(N, K, R)
         return v and R <= cls.MAX_ROWS
 
 
@@ -508,7 +509,7 @@ def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None,
     K = w.shape[1]
     has_b = b is not None
     if (FusedLinearBwd.enabled and GEMM_PRECISION == 6 and sk and has_b == (sk[1] is not None) and FusedLinearBwd.takes(R, N, K)
-            and not RangeGuard.fallback and not RangeGuard.strict and dy.stride(1) == 1 and x.stride(1) == 1):
+            and not _S._cur.range_guard.fallback and not _S._cur.range_guard.strict and dy.stride(1) == 1 and x.stride(1) == 1):
         pl = _planes(w, "D", R)
         gw = sk[0][0]
         if pl is not None and gw.stride(1) == 1:
@@ -517,17 +518,17 @@ def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None,
             dev = dy.device
             dy_amax, x_amax = amax_of(dy, dy_amax), amax_of(x)
             dx = torch.empty(R, K, dtype=torch.float32, device=dev)
-            ws, wsn = _ws(WgradChain._wsb[(N, K, R)], dev)
+            ws, wsn = _ws(_S._cur.chain._wsb[(N, K, R)], dev)
             st = _stream()
-            seed = rng.seed_tensor(dev) if (drop.on or a_drop.on) else None
+            seed = _S._cur.rng.seed_tensor(dev) if (drop.on or a_drop.on) else None
             outs = (gw.data_ptr(),) if gb is None else (gw.data_ptr(), gb.data_ptr())
-            chain = not WgradStream.enabled
+            chain = not _S._cur.wgrad.enabled
             if chain:
                 job = ctypes.create_string_buffer(64)
-                prev = WgradChain._pending.pop(st, None)
+                prev = _S._cur.chain._pending.pop(st, None)
                 job_addr, prev_addr = ctypes.addressof(job), (ctypes.addressof(prev[0]) if prev is not None else None)
             else:
-                job_addr, prev_addr = ReduceQueue.splitk_slot(outs), None
+                job_addr, prev_addr = _S._cur.reduce.splitk_slot(outs), None
             probe = GemmProbe.armed and (GemmProbe.only is None or 8 in GemmProbe.only)
             if probe:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -536,18 +537,18 @@ def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None,
                                             dx.data_ptr(), dx.stride(0), act, _ptr(aux_in), _ptr(residual),
                                             0 if residual is None else residual.stride(0), drop.p, drop.mode, drop.g1, drop.g2, drop.salt,
                                             _ptr(dx_amax), x.data_ptr(), x.stride(0), x_amax.data_ptr(), gw.data_ptr(), gw.stride(0),
-                                            _ptr(gb), _ptr(RangeGuard.flag(dev)), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(seed),
+                                            _ptr(gb), _ptr(_S._cur.range_guard.flag(dev)), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt, _ptr(seed),
                                             prev_addr, job_addr, ws.data_ptr(), wsn, st), "npvp_linear_bwd_f16")
             if probe:
                 e1.record()
                 GemmProbe.records.append((e0, e1, 4.0 * R * N * K, 4.0 * (2 * R * N + 2 * R * K + 2 * N * K), ((1, 0), 8)))
             if chain:
                 if prev is not None and prev[4] is not None:
-                    GradSink.wrote(*prev[4])            # (its reduction rode in the launch just enqueued)
-                WgradChain._pending[st] = (job, ws, gw, gb, sk)
-                ReduceQueue._arm()                      # (the backward pass's end runs the last one: ReduceQueue.finish)
+                    _S._cur.grad_sink.wrote(*prev[4])            # (its reduction rode in the launch just enqueued)
+                _S._cur.chain._pending[st] = (job, ws, gw, gb, sk)
+                _S._cur.reduce._arm()                      # (the backward pass's end runs the last one: ReduceQueue.finish)
             else:
-                ReduceQueue.splitk_added(outs, ws, sk)
+                _S._cur.reduce.splitk_added(outs, ws, sk)
             return dx, None, None
     dx = linear_dgrad(dy, w, act=act, aux_in=aux_in, drop=drop, residual=residual, dy_amax=dy_amax, dx_amax=dx_amax, a_drop=a_drop)
     gw, gb = _lin_grads(dy, x, w, b, sk, a_drop=a_drop)
@@ -567,7 +568,7 @@ def drop_apply(x2d, drop):
     out = torch.empty_like(x2d)
     slot = _new_slot(x2d.device)
     check(lib().npvp_drop_apply(_ptr(x2d), _ptr(out), x2d.shape[0], x2d.shape[1], drop.p, drop.mode, drop.g1, drop.g2,
-                                _ptr(rng.seed_tensor(x2d.device)), drop.salt, _ptr(slot), _stream()), "npvp_drop_apply")
+                                _ptr(_S._cur.rng.seed_tensor(x2d.device)), drop.salt, _ptr(slot), _stream()), "npvp_drop_apply")
     return tag_amax(out, slot)
 
 
@@ -722,7 +723,7 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def _ln_sink(w, b):
-    sw, sb = GradSink.slot(w), GradSink.slot(b)
+    sw, sb = _S._cur.grad_sink.slot(w), _S._cur.grad_sink.slot(b)
     return (sw, sb) if (sw is not None and sb is not None) else None
 
 
@@ -730,33 +731,33 @@ def _sink_mode(sk):
     """`accumulate` argument of the norm backward entry points: 0 plain outputs, 1 accumulate into the gradient slots
     on this stream, 2 leave the partial sums in the workspace - their reduction into the slots then runs on the
     gradient stream (WgradStream), where EVERY in-place gradient write is serialised."""
-    return 0 if not sk else (2 if (WgradStream.enabled or ReduceQueue.enabled) else 1)
+    return 0 if not sk else (2 if (_S._cur.wgrad.enabled or _S._cur.reduce.enabled) else 1)
 
 
 def _sunk_ln_reduce(sk, ws, rows, C):
     gw, gb = sk[0][0], sk[1][0]
-    if ReduceQueue.enabled:
-        ReduceQueue.add(lib().npvp_layernorm_bwd_reduce_job, "npvp_layernorm_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1),
+    if _S._cur.reduce.enabled:
+        _S._cur.reduce.add(lib().npvp_layernorm_bwd_reduce_job, "npvp_layernorm_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1),
                         (gw.data_ptr(), gb.data_ptr()), ws, sk)
-    elif WgradStream.enabled:
+    elif _S._cur.wgrad.enabled:
         # (deferred: every value is bound NOW, the closure runs a few launches later)
-        WgradStream.run(lambda ws=ws, gw=gw, gb=gb, rows=rows, C=C: check(
+        _S._cur.wgrad.run(lambda ws=ws, gw=gw, gb=gb, rows=rows, C=C: check(
             lib().npvp_layernorm_bwd_reduce(_ptr(ws), _ptr(gw), _ptr(gb), rows, C, 1, _stream()), "npvp_layernorm_bwd_reduce"), ws, wrote=sk)
     else:
-        GradSink.wrote(*sk)
+        _S._cur.grad_sink.wrote(*sk)
 
 
 def _sunk_fln_reduce(sk, ws, dw, db, frames, PF):
     """the frame-LayerNorm parameter-gradient partials left in `ws` (accumulate mode 2) -> the gradient slices"""
-    if ReduceQueue.enabled:
-        ReduceQueue.add(lib().npvp_frameln_act_bwd_reduce_job, "npvp_frameln_act_bwd_reduce_job", (_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1),
+    if _S._cur.reduce.enabled:
+        _S._cur.reduce.add(lib().npvp_frameln_act_bwd_reduce_job, "npvp_frameln_act_bwd_reduce_job", (_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1),
                         (dw.data_ptr(), db.data_ptr()), ws, sk)
-    elif WgradStream.enabled:
-        WgradStream.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
+    elif _S._cur.wgrad.enabled:
+        _S._cur.wgrad.run(lambda ws=ws, dw=dw, db=db, frames=frames, PF=PF: check(
             lib().npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, 1, _stream()), "npvp_frameln_act_bwd_reduce"),
             ws, wrote=sk)
     else:
-        GradSink.wrote(*sk)
+        _S._cur.grad_sink.wrote(*sk)
 
 
 def layernorm(x, w, b, eps=1e-5, relu=False):
@@ -1049,21 +1050,21 @@ def _sunk_wgrad(dy, x, with_b, sk, dy_amax=None, x_amax=None, a_drop=NO_DROP):
     dy_amax, x_amax = _wgrad_slots(dy, x, dy_amax, x_amax)
     fn = lambda dy=dy, x=x, gw=sk[0][0], gb=(sk[1][0] if with_b else None), a1=dy_amax, a2=x_amax, ad=a_drop: \
         linear_wgrad(dy, x, with_b, into=gw, into_b=gb, dy_amax=a1, x_amax=a2, a_drop=ad)
-    if WgradStream.enabled:
-        WgradStream.run(fn, dy, x, wrote=sk, urgent=2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] >= 3e10)
+    if _S._cur.wgrad.enabled:
+        _S._cur.wgrad.run(fn, dy, x, wrote=sk, urgent=2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] >= 3e10)
     else:
         fn()
-        GradSink.wrote(*sk)
+        _S._cur.grad_sink.wrote(*sk)
 
 
 def _wb_sink(w, b):
     """(weight slot, bias slot or None) when BOTH gradients can be accumulated in place, else None"""
-    sw = GradSink.slot(w)
+    sw = _S._cur.grad_sink.slot(w)
     if sw is None:
         return None
     if b is None or not b.requires_grad:
         return (sw, None)
-    sb = GradSink.slot(b)
+    sb = _S._cur.grad_sink.slot(b)
     return (sw, sb) if sb is not None else None
 
 
@@ -1133,7 +1134,7 @@ class AttnCfg:
 
 def _attn_fwd(q, k, v, o, cfg):
     hd = o.shape[1] // cfg.heads
-    seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    seed = _S._cur.rng.seed_tensor(q.device) if cfg.drop.on else None
     if DropRecorder.sites is not None and cfg.drop.on:      # weights tensor [groups, heads, L, S]
         L_, S_ = (cfg.ws * cfg.ws, cfg.ws * cfg.ws) if cfg.mode == 0 else (cfg.Tq, cfg.Tk)
         groups = cfg.dim0 * (cfg.P // (cfg.ws * cfg.ws)) if cfg.mode == 0 else cfg.dim0 * cfg.P
@@ -1148,7 +1149,7 @@ def _attn_fwd(q, k, v, o, cfg):
 def _attn_bwd(q, k, v, go, dq, dk, dv, cfg, packed=None):
     """packed: the [R, 2C] tensor dq and dk are the halves of (one amax slot for both, tagged on it)"""
     hd = go.shape[1] // cfg.heads
-    seed = rng.seed_tensor(q.device) if cfg.drop.on else None
+    seed = _S._cur.rng.seed_tensor(q.device) if cfg.drop.on else None
     sq = _new_slot(q.device)
     sk = sq if packed is not None else _new_slot(q.device)
     sv = _new_slot(q.device)
@@ -1237,7 +1238,7 @@ class _FrameLnAct(torch.autograd.Function):
         DropRecorder.note(d, "elem", h.numel())
         DropRecorder.note(dp, "group", frames // max(1, frames_per_sample))
         out = torch.empty_like(h)
-        seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        seed = _S._cur.rng.seed_tensor(h.device) if (d.on or dp.on) else None
         slot = _new_slot(h.device)
         check(L.npvp_frameln_act_fwd(_ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(res_c), _ptr(out), frames,
                                      PF, d.p, d.salt, dp.p, dp.salt, frames_per_sample, _ptr(seed), _ptr(slot), _stream()),
@@ -1258,7 +1259,7 @@ class _FrameLnAct(torch.autograd.Function):
         sk = ctx.sink
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w_cl), torch.empty_like(b_cl))
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), h.device)
-        seed = rng.seed_tensor(h.device) if (d.on or dp.on) else None
+        seed = _S._cur.rng.seed_tensor(h.device) if (d.on or dp.on) else None
         slot = _new_slot(h.device)
         check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w_cl), _ptr(b_cl), _ptr(dh), _ptr(dw),
                                      _ptr(db), frames, PF, d.p, d.salt, dp.p, dp.salt, fps, _ptr(seed), _sink_mode(sk), _ptr(slot),
@@ -1366,7 +1367,7 @@ class _MlpDwbn(torch.autograd.Function):
               "npvp_mlpdw_mid_fwd_parts")
         d2, d3, dp = Drop(p_drop), Drop(p_drop), Drop(p_dp, 1)
         DropRecorder.note(d2, "elem", R * hid)
-        seed = rng.seed_tensor(dev) if (d2.on or dp.on) else None
+        seed = _S._cur.rng.seed_tensor(dev) if (d2.on or dp.on) else None
         a2 = torch.empty(R, hid, dtype=f32, device=dev)
         a2_slot = _new_slot(dev)
         check(L.npvp_frameln_act_fwd_parts(_ptr(h2), _ptr(part2), hid // 512, 32768.0, 1e-5, _row(stats, 2), _row(stats, 3), _ptr(n2w),
@@ -1403,7 +1404,7 @@ class _MlpDwbn(torch.autograd.Function):
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), dev)
         mode = _sink_mode(sk)
         if psum is None:
-            seed = rng.seed_tensor(dev) if (d.on or dp.on) else None
+            seed = _S._cur.rng.seed_tensor(dev) if (d.on or dp.on) else None
             check(L.npvp_frameln_act_bwd(_ptr(dout), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(dh), _ptr(dw), _ptr(db),
                                          frames, PF, d.p, d.salt, dp.p, dp.salt, T, _ptr(seed), mode, _ptr(slot), _ptr(ws), wsn,
                                          _stream()), "npvp_frameln_act_bwd")
@@ -1426,7 +1427,7 @@ class _MlpDwbn(torch.autograd.Function):
         psum = torch.empty(frames * (PF // 1024) * 2, dtype=torch.float32, device=dev)
         dw, db = (sk[0][0], sk[1][0]) if sk else (torch.empty_like(w), torch.empty_like(b))
         ws, wsn = _ws(L.npvp_frameln_act_bwd_workspace_bytes(frames, PF), dev)
-        seed = rng.seed_tensor(dev) if d.on else None
+        seed = _S._cur.rng.seed_tensor(dev) if d.on else None
         check(L.npvp_frameln_act_bwd_pgrad(_ptr(dout), _ptr(h), mean, rstd, _ptr(w), _ptr(b), _ptr(psum), _ptr(dw), _ptr(db),
                                            frames, PF, d.p, d.salt, 0.0, 0, 1, _ptr(seed), _sink_mode(sk), _ptr(ws), wsn, _stream()),
               "npvp_frameln_act_bwd_pgrad")
@@ -1471,7 +1472,7 @@ class _MlpDwbn(torch.autograd.Function):
         sk_dw = ctx.sink_dw if ctx.needs_input_grad[6] and ctx.needs_input_grad[7] else None
         wmode = 2 if sk_dw else 0          # 2: the depthwise gradient partials stay in `ws` for the gradient stream (below)
         if fuse_n2:
-            seed = rng.seed_tensor(dev) if d2.on else None
+            seed = _S._cur.rng.seed_tensor(dev) if d2.on else None
             pe = HbmProbe.begin()
             check(L.npvp_mlpdw_mid_bwd_n2(_ptr(da2), _ptr(h2), _row(stats, 2), _row(stats, 3), _ptr(n2w), _ptr(n2b), _ptr(psum2),
                                           hid // 16, d2.p, d2.salt, _ptr(seed), _ptr(h1), _row(stats, 0), _row(stats, 1), _ptr(n1w),
@@ -1489,15 +1490,15 @@ class _MlpDwbn(torch.autograd.Function):
             # autograd's accumulate adds
             fn = lambda ws=ws, gw=sk_dw[0][0], gb=sk_dw[1][0], F=frames, C=hid: check(
                 L.npvp_mlpdw_mid_bwd_reduce_into(_ptr(ws), _ptr(gw), _ptr(gb), F, C, _stream()), "npvp_mlpdw_mid_bwd_reduce_into")
-            if ReduceQueue.enabled:
+            if _S._cur.reduce.enabled:
                 gw, gb = sk_dw[0][0], sk_dw[1][0]
-                ReduceQueue.add(L.npvp_mlpdw_mid_bwd_reduce_job, "npvp_mlpdw_mid_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), frames, hid),
+                _S._cur.reduce.add(L.npvp_mlpdw_mid_bwd_reduce_job, "npvp_mlpdw_mid_bwd_reduce_job", (_ptr(ws), _ptr(gw), _ptr(gb), frames, hid),
                                 (gw.data_ptr(), gb.data_ptr()), ws, sk_dw)
-            elif WgradStream.enabled:
-                WgradStream.run(fn, ws, wrote=sk_dw)
+            elif _S._cur.wgrad.enabled:
+                _S._cur.wgrad.run(fn, ws, wrote=sk_dw)
             else:
                 fn()
-                GradSink.wrote(*sk_dw)
+                _S._cur.grad_sink.wrote(*sk_dw)
             gdww = gdwb = None
         else:
             gdww = torch.empty(hid, 1, 3, 3, dtype=torch.float32, device=dev)

@@ -4,8 +4,9 @@ where gradients are accumulated, the dropout seed, the range guard of the fp16 a
 All of it is PER TRAINER: a `StepContext` owns one instance of every stateful piece (`rng`, `grad_sink`, `wgrad`, `chain`, `reduce`,
 `range_guard`); a trainer holds one (`FlatAdamW(ctx=StepContext())`; without the argument it adopts the context current at its
 construction - the process's default one in a single-trainer process), the training step runs under `with use(opt.ctx)`, and every
-autograd node remembers the context its forward ran under and re-enters it in backward (the autograd engine runs backward in its
-own thread).  Two predictors with their own contexts in one process therefore do not share a dropout stream, a gradient listener, a
+autograd node remembers the context its forward ran under and re-enters it in backward.  The current context is a global of the
+PROCESS (the autograd engine's thread must see what the thread waiting in backward() set): steps of different trainers can be
+interleaved, not run concurrently from two threads.  Two predictors with their own contexts in one process therefore do not share a dropout stream, a gradient listener, a
 pending join or a sticky fallback (round 4 kept all of that in class attributes: one backward pass, one data-parallel listener,
 one seed per PROCESS); bench.py runs every workload under a context of its own.  Code that uses the ops without a trainer (the op
 tests, tools) runs under the process's default context.
@@ -19,7 +20,6 @@ on the tensors they mirror), the gradient stream of a device, bench.py's probes,
 import contextlib
 import ctypes
 import os
-import threading
 
 import torch
 
@@ -332,7 +332,7 @@ class WgradStreamState:
         dev, side = self._pending
         c = self.ctx
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), use(c):
+        with torch.cuda.stream(side), use(c):       # (a closure made under this trainer's context runs under it)
             self.in_flush = True
             try:
                 for fn, _, _ in q:
@@ -650,48 +650,52 @@ class StepContext:
 
 
 _default = StepContext()
-_tls = threading.local()
+_cur = _default          # the CURRENT context: a plain module global (npvp_amd.ops reads it as sched._cur.<field> on every launch)
 
 
 def current():
-    """the calling thread's context (the process's default one outside `use`)"""
-    return getattr(_tls, "ctx", _default)
+    """the current context (the process's default one outside `use`)"""
+    return _cur
 
 
 @contextlib.contextmanager
 def use(ctx):
-    """run the enclosed launches under `ctx` (None = leave the current one in place)"""
-    if ctx is None or ctx is getattr(_tls, "ctx", _default):
+    """Run the enclosed launches under `ctx` (None = leave the current one in place).  The current context is one global of the
+    process, not of the thread: the autograd engine runs backward nodes in a thread of its own while the thread that called
+    backward() waits inside its `use` block, and both must see the same context.  Steps of different trainers may therefore be
+    INTERLEAVED in one process (each enters its context), not run concurrently from two Python threads."""
+    global _cur
+    if ctx is None or ctx is _cur:
         yield
         return
-    prev = getattr(_tls, "ctx", _default)
-    _tls.ctx = ctx
+    prev, _cur = _cur, ctx
     try:
         yield
     finally:
-        _tls.ctx = prev
+        _cur = prev
 
 
 def scoped(backward):
     """decorator of an autograd Function's backward: run it under the context the node's forward ran under (`ctx.scope`, set by
-    `remember`): the autograd engine calls backward from its own thread, where nothing else says whose step this is"""
+    `remember`) - a backward pass started outside the trainer's `use` block (a caller's own loss.backward()) still queues its
+    weight gradients, reductions and mask replays on the right trainer"""
     def wrapper(ctx, *grads):
+        global _cur
         sc = getattr(ctx, "scope", None)
-        if sc is None or sc is getattr(_tls, "ctx", _default):
+        if sc is None or sc is _cur:
             return backward(ctx, *grads)
-        prev = getattr(_tls, "ctx", _default)
-        _tls.ctx = sc
+        prev, _cur = _cur, sc
         try:
             return backward(ctx, *grads)
         finally:
-            _tls.ctx = prev
+            _cur = prev
     wrapper.__doc__ = backward.__doc__
     return staticmethod(wrapper)
 
 
 def remember(ctx):
     """forward of an autograd Function: note the step context on the node"""
-    ctx.scope = getattr(_tls, "ctx", _default)
+    ctx.scope = _cur
 
 
 class _Scoped:
@@ -703,10 +707,10 @@ class _Scoped:
         object.__setattr__(self, "_cls", cls)
 
     def __getattr__(self, name):
-        return getattr(getattr(getattr(_tls, "ctx", _default), self._field), name)
+        return getattr(getattr(_cur, self._field), name)
 
     def __setattr__(self, name, value):
-        inst = getattr(getattr(_tls, "ctx", _default), self._field)
+        inst = getattr(_cur, self._field)
         if name in inst.__dict__:
             setattr(inst, name, value)              # run state of the current trainer
         else:

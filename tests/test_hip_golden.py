@@ -689,13 +689,14 @@ _LARGER_ORACLE = {}
 
 @pytest.mark.parametrize("variant,N,To,Tp,seed0,depth", [("S", 2, 5, 15, 11, (4, 8)), ("D", 2, 2, 18, 91, (4, 8)), ("D", 1, 2, 28, 91, (4, 8)),
                                                          ("S", 1, 2, 12, 11, (4, 8)), ("D", 2, 4, 16, 91, (4, 8)), ("S", 1, 10, 10, 11, (4, 8)),
-                                                         ("D", 8, 4, 16, 91, (1, 2))])
+                                                         ("D", 8, 4, 16, 91, (1, 2)), ("D", 1, 3, 40, 91, (1, 1))])
 def test_against_oracle_larger(impl, variant, N, To, Tp, seed0, depth):
     """Full depth (4+8), every BASELINE config's clip shape - c0 (S, 5+15), c2' (D, 2+18), c2 (D, 2+28), c3 (S, 2+12),
     c4 (D, 4+16), c1 (S, 10+10) - and (round 4) the WHOLE per-GPU shard of the 8-GPU configuration c4 (8 clips of 4 + 16:
     8 192 decoder token rows, i.e. the shapes and kernel variants the data-parallel benchmark line runs; at depth 1 + 2 - every
-    layer has the same shapes, and at full depth the CPU oracle needed 4.5 minutes for this one case): HIP vs oracle on the same
-    seeded inputs, forward (train mode, dropout 0) and gradients."""
+    layer has the same shapes, and at full depth the CPU oracle needed 4.5 minutes for this one case); round 5: a clip of 3 + 40
+    frames - longer than any shipped configuration, the temporal (40 x 40) and encoder-decoder (40 x 3) attention on the generic
+    kernels: HIP vs oracle on the same seeded inputs, forward (train mode, dropout 0) and gradients."""
     import oracle
     stochastic = variant == "S"
     h = torch.linspace(0, 7, 8)

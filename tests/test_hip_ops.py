@@ -264,17 +264,18 @@ def _attn_ref(q, k, v, rows_q, rows_k, mask):
     return O.attn_core(q, k, v, rows_q, rows_k, 8, mask)
 
 
-@pytest.mark.parametrize("frames", [1, 3])
-def test_attn_spatial(K, frames):
+@pytest.mark.parametrize("frames,ws", [(1, 4), (3, 4), (2, 8)])
+def test_attn_spatial(K, frames, ws):
+    """ws = 8: one 64-token window per frame (sequence length 64: the generic kernels)"""
     from npvp_amd.ops import AttnCfg
     R, C = frames * 64, 512
     qk = O.seeded_randn((R, 2 * C), 71).requires_grad_(); v = O.seeded_randn((R, C), 72).requires_grad_()
     cot = O.seeded_randn((R, C), 73)
-    rows = O.spatial_groups(frames, 8, 8, 4)
+    rows = O.spatial_groups(frames, 8, 8, ws)
     y = _attn_ref(qk[:, :C], qk[:, C:], v, rows, rows, None)
     rqk, rv = torch.autograd.grad((y * cot).sum(), [qk, v])
     qkg, vg = g(qk.detach().requires_grad_()), g(v.detach().requires_grad_())
-    yg = K.attn_packed(qkg, vg, AttnCfg(0, frames, 64, 8, 4, 0, 0, 8, 0, 0.0))
+    yg = K.attn_packed(qkg, vg, AttnCfg(0, frames, 64, 8, ws, 0, 0, 8, 0, 0.0))
     gqk, gv = torch.autograd.grad((yg * cot.to(DEV)).sum(), [qkg, vg])
     close(yg, y); close(gqk, rqk, what="dqk"); close(gv, rv, what="dv")
 
@@ -282,7 +283,9 @@ def test_attn_spatial(K, frames):
 @pytest.mark.parametrize("Tq,Tk,mask", [(1, 1, 0), (2, 2, 1), (3, 3, 1), (10, 10, 1), (10, 10, 0), (17, 17, 1), (28, 28, 0),
                                         (32, 32, 1), (4, 2, 0), (18, 2, 0), (10, 28, 0), (28, 10, 0),
                                         # the BASELINE configs' decoder / cross shapes: c2 (28,28),(28,2); c3 (12,12),(12,2); c4 (16,16),(16,4)
-                                        (28, 2, 0), (12, 12, 0), (12, 2, 0), (16, 16, 0), (16, 4, 0), (4, 4, 1), (18, 18, 0)])
+                                        (28, 2, 0), (12, 12, 0), (12, 2, 0), (16, 16, 0), (16, 4, 0), (4, 4, 1), (18, 18, 0),
+                                        # longer than any shipped configuration (the reference has no limit): the generic kernels
+                                        (40, 40, 1), (33, 33, 0), (48, 5, 0), (5, 40, 0), (128, 128, 1)])
 def test_attn_temporal_and_cross(K, Tq, Tk, mask):
     from npvp_amd.ops import AttnCfg
     N, P, C = 2, 64, 512

@@ -68,6 +68,11 @@ tiles)      # shard-sized GEMMs: the forward / dgrad tiles and the fused dgrad +
 mid)        # MlpDWBN layer backward at the c2 decoder size and at an 8-clip shard's
   for F in 1792 160; do python3 $ROOT/tools/mlpdw_bench.py $F >> "$OUT/mlpdw_bench.txt" 2>/dev/null; done
   cat "$OUT/mlpdw_bench.txt" ;;
+posfuse)    # positional-fuse backward at the c2 decoder / encoder size and at an 8-clip shard's
+  python3 $ROOT/tools/posfuse_bench.py 64 28 > "$OUT/posfuse_bench.txt" 2>/dev/null
+  python3 $ROOT/tools/posfuse_bench.py 64 2 >> "$OUT/posfuse_bench.txt" 2>/dev/null
+  python3 $ROOT/tools/posfuse_bench.py 8 16 >> "$OUT/posfuse_bench.txt" 2>/dev/null
+  cat "$OUT/posfuse_bench.txt" ;;
 *) echo "unknown step $STEP"; exit 2 ;;
 esac
 done
