@@ -240,14 +240,21 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         e_ms, e_host = trial(eager_step)
         trial_ms = {"eager": round(e_ms, 2), "eager_host": round(e_host, 2)}
         if e_host >= 0.6 * e_ms:
-            gstep, gfn = graphed()
-            g_ms, _ = trial(gfn)
-            trial_ms["graph"] = round(g_ms, 2)
-            if g_ms < e_ms:
-                step, used, probe = gfn, "graph", False
+            try:
+                gstep, gfn = graphed()
+                g_ms, _ = trial(gfn)
+            except Exception as e:          # (a capture that fails on some box must not take the whole record down: stay eager)
+                log(f"[{key}] graph capture / replay failed ({type(e).__name__}: {e}); staying eager")
+                trial_ms["graph"] = None
+                gstep = gfn = None
+                torch.cuda.synchronize()
             else:
-                del gstep, gfn
-                gc.collect()
+                trial_ms["graph"] = round(g_ms, 2)
+                if g_ms < e_ms:
+                    step, used, probe = gfn, "graph", False
+                else:
+                    del gstep, gfn
+                    gc.collect()
         log(f"[{key}] mode trial: {trial_ms} -> {used}")
 
     def fence():
@@ -339,10 +346,10 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
             kname = ops.GemmProbe.KERNELS[kid]
             ach = pfl / (pms * 1e-3) / 1e12
             traffic = None
-            tj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r_}_hbm_traffic_{key}.json") for r_ in (4, 3)) if os.path.exists(q)), "")
+            tj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r_}_hbm_traffic_{key}.json") for r_ in (5, 4, 3)) if os.path.exists(q)), "")
             if os.path.exists(tj) and not full:
                 # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command (separate
-                # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r03_hbm_traffic_<key>.*
+                # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r0N_hbm_traffic_<key>.* (newest round)
                 ent = json.load(open(tj)).get("pooled", {}).get(kname)
                 traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
             f16 = kid in (5, 6, 7, 8)
