@@ -227,9 +227,34 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     if args.graph:
         mode = "graph"
     used, trial_ms = "eager", None
+    ops.FusedLinearBwd.with_gradient_stream = False
     if mode in ("graph", "auto") and (dp_on or full):
         assert mode == "auto", "--graph: single process, predictor-only flavour"
         mode = "eager"
+    if dp_on and not full:
+        # A data-parallel step cannot be replayed from a graph (the collective and the bucket hand-over are host driven), but a
+        # host-bound one can still shed launches: the dgrad + weight-gradient pair of a layer as ONE launch beside the gradient stream
+        # (934 instead of 1 160 launches per c4 step; 0.8 ms slower than two launches where the GPU is the bound).  Same trial on every
+        # rank, the decision from the slowest rank's numbers so that all ranks take the same one.
+        for i in range(warmup):
+            eager_step(i)
+
+        def agreed(*v):
+            t = torch.tensor(v, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.tolist()
+
+        e_ms, e_host = agreed(*trial(eager_step))
+        trial_ms = {"eager": round(e_ms, 2), "eager_host": round(e_host, 2)}
+        if e_host >= 0.6 * e_ms:
+            ops.FusedLinearBwd.with_gradient_stream = True
+            f_ms, f_host = agreed(*trial(eager_step))
+            trial_ms["eager_fused"] = round(f_ms, 2)
+            if f_ms < e_ms:
+                used = "eager_fused"
+            else:
+                ops.FusedLinearBwd.with_gradient_stream = False
+        log(f"[{key}] mode trial: {trial_ms} -> {used}")
     if mode == "graph":
         probe = False
         gstep, step = graphed()
@@ -311,7 +336,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         f"{frames / (ms * 1e-3):.0f} frames/s; host ms per step: " + " ".join(f"{1000.0 * h:.0f}" for h in host_all))
 
     roof, roof_hbm = None, None
-    if probe and used == "eager":
+    if probe and used != "graph":
         # the HBM-bound family, timed in two EXTRA steps after the clock stopped (the event packets fence their neighbours)
         ops.HbmProbe.armed, ops.HbmProbe.records = True, []
         for i in range(2):

@@ -436,10 +436,12 @@ def masked_grad(dy2, drop, w):
     return drop_apply(dy2, drop), NO_DROP
 
 
-# Up to this many token rows (the launch-bound shards: c4 36.4 -> 35.1 ms).  On the large workloads the step does not change
-# (c2: 245.6 vs 246.2 ms) and the only effect is on what shares the device with what: without the masking pass in front of it the
-# weight-gradient GEMM of the site starts earlier and runs beside its dgrad GEMM (event-pair time of the dgrad launches +10 %).
-DROP_PATH_IN_GEMM_ROWS = 32768
+# Up to this many token rows.  Rounds 3 - 4 limited it to 32 768 (the launch-bound shards: c4 36.4 -> 35.1 ms; on c2 the step did
+# not change then, 245.6 vs 246.2 ms, while the dgrad launches' event-pair rate fell - the masked epilogues still divided per
+# element).  With the multiply-shift group index (round 4, end) the masked launch costs what the unmasked one does, and round 5's
+# in-process A/B at c2 (tools/ab_bench.py: A, B, A, B on one box) reads 233.4 / 232.8 ms with the limit against 232.4 / 232.2
+# without: no limit any more (20 drop_apply passes over [114 688 x 512] per step gone).
+DROP_PATH_IN_GEMM_ROWS = 1 << 30
 
 
 def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=None, x_amax=None, a_drop=NO_DROP):
@@ -490,6 +492,13 @@ class FusedLinearBwd:
     launch on the same stream (WgradChain)."""
     enabled = True
     MAX_ROWS = 16384
+    # Beside a gradient stream the two launches on two streams are the better schedule wherever the GPU is the bound (in-process
+    # A/Bs, profiles/r05_ab_knobs.txt: c4 shard eager 30.5 ms unfused / 31.3 fused, c2 233.3 / 234.3, c1 with 20 480-row layers
+    # fused 89.8 against 86.2): the fused launch is for the step WITHOUT a gradient stream - the single-stream capture that is
+    # replayed from a graph.  with_gradient_stream = True takes it in the eager two-stream step too: fewer launches (934 instead of
+    # 1 160 per c4 step), which is what a host-bound step wants (bench.py tries both under data parallelism, where the step
+    # cannot be replayed from a graph).
+    with_gradient_stream = False
     _ok = {}
 
     @classmethod
@@ -509,7 +518,7 @@ def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None,
     K = w.shape[1]
     has_b = b is not None
     if (FusedLinearBwd.enabled and GEMM_PRECISION == 6 and sk and has_b == (sk[1] is not None) and FusedLinearBwd.takes(R, N, K)
-            and not _S._cur.range_guard.fallback and not _S._cur.range_guard.strict and dy.stride(1) == 1 and x.stride(1) == 1):
+            and (FusedLinearBwd.with_gradient_stream or not _S._cur.wgrad.enabled) and not _S._cur.range_guard.fallback and not _S._cur.range_guard.strict and dy.stride(1) == 1 and x.stride(1) == 1):
         pl = _planes(w, "D", R)
         gw = sk[0][0]
         if pl is not None and gw.stride(1) == 1:

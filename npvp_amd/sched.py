@@ -318,12 +318,18 @@ class WgradStreamState:
         concurrently with later main-stream kernels), so starting it a few launches later changes no result.  fn runs under this
         trainer's context (a closure made in one context is never run in another)."""
         self._queue.append((fn, keep_alive, wrote))
-        if self._pending is None:
-            dev = keep_alive[0].device
-            self._pending = (dev, self.stream(dev))
-            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        self.begin(keep_alive[0].device)
         if urgent or len(self._queue) >= self.BATCH:
             self.flush()
+
+    def begin(self, dev):
+        """this backward pass has (or is about to have) work on the gradient stream: note it and have the pass's end re-join"""
+        if self._pending is None:
+            self._pending = (dev, self.stream(dev))
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            except RuntimeError:                    # not inside a backward pass: the caller joins (FlatAdamW.step / zero_grad do)
+                pass
 
     def flush(self):
         if not self._queue:
@@ -409,11 +415,14 @@ class ReduceQueueState:
     enabled = True            # (False: one reduction launch per site, as in round 4 - the tests compare the two)
     JOB, CAP, LAUNCH = 48, 480, 40
     SKJOB, SKCAP, SKLAUNCH = 64, 256, 16      # split-K reductions of fused dgrad + weight-gradient launches: 64-byte records
+    DP_LAUNCH = 8                             # data parallel: run the queue every so many jobs (see _dp_progress)
+    LAUNCH_BYTES = 192 << 20                  # ... or once this many bytes of partials wait (see due)
 
     def __init__(self, ctx):
         self.ctx = ctx
         self._buf = self._addr = self._skbuf = self._skaddr = None
         self._n = self._skn = 0
+        self._bytes = 0
         self._keep, self._wrote, self._outs = [], [], set()
         self._armed = False
 
@@ -421,8 +430,10 @@ class ReduceQueueState:
         return self._n + self._skn
 
     def due(self):
-        """a launch's worth has gathered (WgradStream.flush runs the queue then, so that the reductions keep overlapping the pass)"""
-        return self._n >= self.LAUNCH or self._skn >= self.SKLAUNCH
+        """a launch's worth has gathered - by count, or by the bytes of partials waiting (WgradStream.flush runs the queue then, so
+        that the reductions keep overlapping the pass and a large workload's partials - 33 MB per frame LayerNorm at c2 - are not
+        read back 1.3 GB at a time: with the count alone the c2 step lost 0.9 ms to the queue, profiles/r05_ab_knobs.txt)"""
+        return self._n >= self.LAUNCH or self._skn >= self.SKLAUNCH or self._bytes >= self.LAUNCH_BYTES
 
     def splitk_slot(self, out_ptrs):
         """host address for the next 64-byte split-K job record (the C call that leaves the partial slabs writes it)"""
@@ -435,11 +446,21 @@ class ReduceQueueState:
 
     def splitk_added(self, out_ptrs, keep, wrote):
         self._skn += 1
+        self._bytes += keep.numel() * 4
         self._keep.append(keep)
         self._outs.update(out_ptrs)
         if wrote is not None:
             self._wrote.append(wrote)
         self._arm()
+        self._dp_progress()
+
+    def _dp_progress(self):
+        """Data parallel: a gradient slot is reported to the listener (GradSync) when its reduction has been enqueued, and a bucket's
+        all-reduce starts when all its slots are reported - so the queue must not sit on them until the pass ends (on an 8-clip
+        shard nearly every gradient goes through this queue: the all-reduce would start after backward).  Every DP_LAUNCH jobs the
+        queue is run; always on the gradient stream, where every in-place gradient write is serialised."""
+        if self.ctx.grad_sink.listener is not None and self._n + self._skn >= self.DP_LAUNCH:
+            self.run_pending()
 
     def _arm(self):
         if not self._armed:
@@ -458,28 +479,32 @@ class ReduceQueueState:
             self.run_pending()
         check(filler(*args, self._addr + self.JOB * self._n), name)
         self._n += 1
+        self._bytes += keep.numel() * 4
         self._keep.append(keep)
         self._outs.update(out_ptrs)
         if wrote is not None:
             self._wrote.append(wrote)
         self._arm()
+        self._dp_progress()
 
     def run_pending(self):
-        """the queued jobs, now, on the stream where in-place gradient writes belong"""
+        """the queued jobs, now, on the stream where in-place gradient writes belong: the gradient stream whenever there is one
+        (also before the pass's first weight gradient has gone there), else the current stream"""
         if self._n + self._skn == 0:
             return
         w = self.ctx.wgrad
-        if w.enabled and w._pending is not None and not w.in_flush:
+        if w.enabled and not w.in_flush:
+            w.begin(torch.device("cuda", torch.cuda.current_device()))
             dev, side = w._pending
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 self._launch(side)
         else:
-            self._launch(None)
+            self._launch(None)              # (inside WgradStream.flush the current stream IS the gradient stream)
 
     def _launch(self, side):
         n, skn, keep, wrote = self._n, self._skn, self._keep, self._wrote
-        self._n, self._skn, self._keep, self._wrote, self._outs = 0, 0, [], [], set()
+        self._n, self._skn, self._bytes, self._keep, self._wrote, self._outs = 0, 0, 0, [], [], set()
         if n:
             check(lib().npvp_sum_rows_multi(self._addr, n, _stream()), "npvp_sum_rows_multi")
         if skn:
@@ -499,7 +524,8 @@ class ReduceQueueState:
             self.ctx.chain.flush()                  # (single stream: the last fused launch's split-K reduction has no launch to ride in)
         if self._n + self._skn == 0:
             return
-        if w.enabled and w._pending is not None:
+        if w.enabled:
+            w.begin(torch.device("cuda", torch.cuda.current_device()))
             w.join()                                # (runs the queue on the gradient stream before the streams re-join)
         else:
             self._launch(None)

@@ -499,8 +499,8 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self.out = predictor_train_step(*self._args, sync=False)
             self.launches = lib().npvp_launch_count() - n0          # library launches of one step (what a replay enqueues on the device)
-            ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code)
         finally:
+            ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code - also after a failed capture)
             ops.WgradStream.enabled = two_streams
 
     def _poll_range(self):

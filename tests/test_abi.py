@@ -37,7 +37,8 @@ def test_argument_errors_do_not_need_a_gpu(built):
                          None, 0, 1.0, 0, None, None, 0, None, None, None, None, None, 0.0, 1, 1, 0, None, 0, None)
     assert rc == -1 and b"multiple of 32" in L.npvp_last_error()
     assert L.npvp_layernorm_fwd(None, None, None, None, None, None, 4, 500, 1e-5, 0, None, None) == -1
-    assert L.npvp_attn_fwd(None, 512, None, 512, None, 512, None, 512, 1, 1, 64, 8, 0, 40, 40, 8, 64, 0, 0.0, None, 0, None, None) == -1
+    assert L.npvp_attn_fwd(None, 512, None, 512, None, 512, None, 512, 1, 1, 64, 8, 0, 200, 200, 8, 64, 0, 0.0, None, 0, None, None) == -1
+    assert b"[1,128]" in L.npvp_last_error()            # (sequence lengths 33 .. 128 are legal since round 5: the generic kernels)
     assert L.npvp_gemm_workspace_bytes(2048, 512, 20480) > 0 and L.npvp_gemm_workspace_bytes(20480, 512, 512) == 0
 
 

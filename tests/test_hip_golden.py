@@ -258,11 +258,12 @@ def test_fused_linear_backward_is_bit_identical(impl, two_streams):
     N, To, Tp = 8, 2, 8
     past = O.synth_features((N, To, 512, 8, 8), 92).to(DEV)
     fut = O.synth_features((N, Tp, 512, 8, 8), 93).to(DEV)
-    old = (ops.FusedLinearBwd.enabled, ops.WgradStream.enabled)
+    old = (ops.FusedLinearBwd.enabled, ops.WgradStream.enabled, ops.FusedLinearBwd.with_gradient_stream)
     flat, launches = {}, {}
     try:
         ops.WgradStream.join()
         ops.WgradStream.enabled = two_streams
+        ops.FusedLinearBwd.with_gradient_stream = True      # by default only the step without a gradient stream fuses
         for on in (True, False):
             ops.FusedLinearBwd.enabled = on
             m = GC._small_predictor(impl, False, 101, DEV, To=To, Tp=Tp, dropout=0.1, drop_path=0.1)
@@ -282,7 +283,7 @@ def test_fused_linear_backward_is_bit_identical(impl, two_streams):
         assert launches[True] < launches[False], launches
         assert torch.equal(flat[True], flat[False]), f"fused vs two launches: {GC.rel_err(flat[True], flat[False]):.3e}"
     finally:
-        ops.FusedLinearBwd.enabled, ops.WgradStream.enabled = old
+        ops.FusedLinearBwd.enabled, ops.WgradStream.enabled, ops.FusedLinearBwd.with_gradient_stream = old
 
 
 def test_two_trainers_in_one_process_do_not_share_state(impl):

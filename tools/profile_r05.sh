@@ -73,6 +73,26 @@ posfuse)    # positional-fuse backward at the c2 decoder / encoder size and at a
   python3 $ROOT/tools/posfuse_bench.py 64 2 >> "$OUT/posfuse_bench.txt" 2>/dev/null
   python3 $ROOT/tools/posfuse_bench.py 8 16 >> "$OUT/posfuse_bench.txt" 2>/dev/null
   cat "$OUT/posfuse_bench.txt" ;;
+ab_droppath) # DropPath masks inside the dgrad / weight-gradient GEMMs at every size (round 4 limited it to <= 32 768 rows)
+  python3 $ROOT/tools/ab_bench.py c2 ops.DROP_PATH_IN_GEMM_ROWS 32768 1000000000 8 2>/dev/null | grep -v "^\[bench" > "$OUT/ab_droppath_c2.txt"
+  cat "$OUT/ab_droppath_c2.txt" ;;
+ab)         # in-process A/Bs of scheduling knobs (tools/ab_bench.py: A, B, A, B on one box)
+  : > "$OUT/ab_knobs.txt"
+  for SPEC in "c2 ops.FusedLinearBwd.enabled True False" "c1 ops.FusedLinearBwd.MAX_ROWS 16384 32768" "c2 sched.WgradStreamState.enabled True False" \
+              "c1 sched.WgradStreamState.enabled True False" "c2 sched.ReduceQueueState.enabled True False" "c4 ops.FusedLinearBwd.enabled True False" \
+              "c4 ops.ActSink.enabled True False" "c2 ops.ActSink.enabled True False"; do
+    echo "== $SPEC" >> "$OUT/ab_knobs.txt"
+    python3 $ROOT/tools/ab_bench.py $SPEC 8 2>/dev/null | grep "^{" >> "$OUT/ab_knobs.txt"
+  done
+  cat "$OUT/ab_knobs.txt" ;;
+ab2)        # second sweep: the deferred reductions in the eager two-stream step of the small workloads (fused launches off)
+  : > "$OUT/ab_knobs2.txt"
+  for SPEC in "c4 sched.ReduceQueueState.enabled True False" "c3 sched.ReduceQueueState.enabled True False" "c0 sched.ReduceQueueState.enabled True False" \
+              "c1 sched.ReduceQueueState.enabled True False" "c0 ops.ActSink.enabled True False"; do
+    echo "== $SPEC (FusedLinearBwd off)" >> "$OUT/ab_knobs2.txt"
+    python3 $ROOT/tools/ab_bench.py $SPEC 8 --set=ops.FusedLinearBwd.enabled=False 2>/dev/null | grep "^{" >> "$OUT/ab_knobs2.txt"
+  done
+  cat "$OUT/ab_knobs2.txt" ;;
 *) echo "unknown step $STEP"; exit 2 ;;
 esac
 done
