@@ -130,23 +130,46 @@ __global__ void clip_coef_kernel(const float* __restrict__ part, int nb, float m
 
 // torch.optim.AdamW (decoupled weight decay, bias-corrected), hyper = {lr, step} in device memory so a
 // captured graph sees the scheduler's value; elements in [clip_begin, clip_end) are scaled by clip[1].
-__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__device__ __forceinline__ void adamw_one(float& pi, float& gi, float& mi, float& vi, const bool clipped, const float coef,
+                                          const float decay, const float beta1, const float beta2, const float step_size,
+                                          const float inv_sqrt_bc2, const float eps) {
+  if (clipped) gi *= coef;
+  pi *= decay;
+  mi = beta1 * mi + (1.f - beta1) * gi;
+  vi = beta2 * vi + (1.f - beta2) * gi * gi;
+  pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+}
+// Four elements per thread and trip (float4 loads / stores of p, g, m, v: 28 - 32 bytes of traffic per element is all this kernel
+// is; the scalar form ran at 2.7 TB/s, 617 us of an 8-clip step); the arithmetic per element is the scalar form's, operation for
+// operation.  n4 = n / 4 vector elements (the buffers are allocations: 256-byte aligned), the last n % 4 by one thread.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd,
                              const float* __restrict__ clip, long long clip_begin, long long clip_end, int write_back_grad) {
   const float lr = hyper[0], step = hyper[1];
   const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
   const float coef = clip ? clip[1] : 1.f;
-  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (i >= clip_begin && i < clip_end) { gi *= coef; if (write_back_grad) g[i] = gi; }
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    p[i] = pi;
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  const long long n4 = n >> 2;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
+    const long long i = i4 << 2;
+    float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
+    const bool c0 = i >= clip_begin && i < clip_end, c1 = i + 1 >= clip_begin && i + 1 < clip_end;
+    const bool c2 = i + 2 >= clip_begin && i + 2 < clip_end, c3 = i + 3 >= clip_begin && i + 3 < clip_end;
+    adamw_one(pp.x, gg.x, mm.x, vv.x, c0, coef, decay, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+    adamw_one(pp.y, gg.y, mm.y, vv.y, c1, coef, decay, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+    adamw_one(pp.z, gg.z, mm.z, vv.z, c2, coef, decay, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+    adamw_one(pp.w, gg.w, mm.w, vv.w, c3, coef, decay, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+    if (write_back_grad && (c0 || c1 || c2 || c3)) st4(g + i, gg);
+    st4(m + i, mm); st4(v + i, vv); st4(p + i, pp);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 << 2; i < n; ++i) {
+      float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+      const bool c = i >= clip_begin && i < clip_end;
+      adamw_one(pi, gi, mi, vi, c, coef, decay, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+      if (write_back_grad && c) g[i] = gi;
+      m[i] = mi; v[i] = vi; p[i] = pi;
+    }
 }
 
 static inline int ew_blocks(long long total, int threads) {
@@ -273,7 +296,8 @@ extern "C" int npvp_adamw_step(float* p, float* g, float* m, float* v, long long
                                float beta2, float eps, float weight_decay, const float* clip, long long clip_begin,
                                long long clip_end, int write_back_grad, hipStream_t stream) {
   NPVP_CHECK_ARG(n > 0 && hyper, "adamw: bad arguments");
-  NPVP_LAUNCH(adamw_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps,
+  NPVP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: the flat buffers must be 16-byte aligned");
+  NPVP_LAUNCH(adamw_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, stream, p, g, m, v, n, hyper, beta1, beta2, eps,
                      weight_decay, clip, clip_begin, clip_end, write_back_grad);
   NPVP_CHECK_LAUNCH();
   return NPVP_OK;

@@ -29,20 +29,28 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// x (already scaled) -> (hi, lo).  Written on PAIRS so that the compiler emits, per two elements, one v_cvt_pk_f16_f32 (hi), two
-// v_cvt_f32_f16 (back), one v_pk_add_f32 (x - hi) and one v_cvt_pk_f16_f32 (lo): 5 VALU per pair - the scalar form came out as 8-9
-// (it converted one pair to fp16 twice, once packed for the store and once element by element for the subtraction).  Every VALU
-// instruction of the K loop costs its 4 cycles on top of the MFMAs' (profiles/r03_gemm_f16_latency.txt): the split is 28 of the
-// loop's 36 per step.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_f16(const f32x4 v, f16x4& hi, f16x4& lo) {
-  const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
-  const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
-  const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
-  const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
-  hi[0] = ha[0]; hi[1] = ha[1]; hi[2] = hb[0]; hi[3] = hb[1];
-  lo[0] = la[0]; lo[1] = la[1]; lo[2] = lb[0]; lo[3] = lb[1];
+// x, s -> (hi, lo) of x s:  hi = rne_f16(x s),  lo = rne_f16(x s - hi).  TWO VALU instructions per element, the mixed-precision FMAs
+// (v_fma_mixlo_f16 / v_fma_mixhi_f16: an fp32 FMA whose operands may be fp16 halves and whose result is rounded into one half of the
+// destination): hi = mix(x, s, 0), lo = mix(x, s, -hi).  Both FMAs are exact before the conversion (s is a power of two; x s - hi
+// has at most 13 significant bits), so the halves are bit for bit those of "scale, convert, convert back, subtract, convert"
+// (tools/f16_split_check.hip runs both forms over random and edge-case words on the GPU) - which cost 3 VALU per element as the
+// compiler's best (pk_mul, cvt_pk, 2 cvt back, pk_fma, cvt_pk per pair; 8 - 9 in the scalar form of round 3).  Every VALU
+// instruction of the K loop costs its 4 cycles on top of the MFMAs' (profiles/r03_gemm_f16_latency.txt); the split was 28 of the
+// forward loop's 36 per step and ~76 of the weight-gradient loop's.
+__device__ __forceinline__ void split_f16_scaled(const f32x4 v, const float s, f16x4& hi, f16x4& lo) {
+  unsigned int h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v[0]), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v[2]), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v[1]), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v[3]), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(v[0]), "v"(s), "v"(h01));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(v[2]), "v"(s), "v"(h23));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v[1]), "v"(s), "v"(h01));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v[3]), "v"(s), "v"(h23));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 hp = {h01, h23}, lp = {l01, l23};
+  hi = __builtin_bit_cast(f16x4, hp);
+  lo = __builtin_bit_cast(f16x4, lp);
 }
 
 // workgroup-wide OR of a per-thread predicate (every thread calls it; NW waves; `flags` = NW ints of LDS nobody else uses)
@@ -153,7 +161,7 @@ __device__ __forceinline__ void gemm_f16_body(const GemmParams& p, char* lds, co
 #define NPVP_H_ASTORE(ST, V, ROWOFF)                                                     \
   { if (ROWOFF) rm1 = fmaxf(fmaxf(rm1, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));  \
     else rm0 = fmaxf(fmaxf(rm0, fmaxf(fabsf((V)[0]), fabsf((V)[1]))), fmaxf(fabsf((V)[2]), fabsf((V)[3])));         \
-    f16x4 hi_, lo_; split_f16((V) * ((ROWOFF) ? sa1 : sa0), hi_, lo_);                   \
+    f16x4 hi_, lo_; split_f16_scaled((V), (ROWOFF) ? sa1 : sa0, hi_, lo_);               \
     *reinterpret_cast<f16x4*>((ST) + a_dst + (ROWOFF)) = hi_;                            \
     *reinterpret_cast<f16x4*>((ST) + A_PLANE + a_dst + (ROWOFF)) = lo_; }
   // LDS-DMA with a scalar base + 32-bit lane offset, M0 = the piece's LDS address (the builtin takes a 64-bit per-lane pointer
@@ -454,7 +462,7 @@ __device__ __forceinline__ void gemm_wgrad_f16_body(const GemmParams& p, char* l
   // the loads are inline asm (scalar base + lane offset): waits by hand - issue order A0 A1 B0 B1 B2 B3
 #define NPVP_G_WAIT(N, ...) asm volatile("s_waitcnt vmcnt(" #N ")" : __VA_ARGS__ :: "memory");
 #define NPVP_G_STORE(DST, V, SC, PLANE)                                                                     \
-  { f16x4 hi_, lo_; split_f16((V) * (SC), hi_, lo_);                                                        \
+  { f16x4 hi_, lo_; split_f16_scaled((V), (SC), hi_, lo_);                                                  \
     *reinterpret_cast<f16x4*>(DST) = hi_; *reinterpret_cast<f16x4*>((DST) + (PLANE)) = lo_; }
   // a row-group mask on A = dy [K][M]: the 16 rows of a K-step belong to ONE group (g1 % 16 == 0, checked by the launcher), so the
   // step's mask is one wave-uniform factor folded into the scale (and into the bias-gradient sums); am_ = mask of the tile in ra

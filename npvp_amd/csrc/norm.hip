@@ -204,6 +204,30 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict_
   }
 }
 
+// WIDE sets: few partial rows over very many columns (the frame-LN parameter gradients: 16 - 32 rows x 262 144 columns, 17 - 34 MB
+// per layer).  One float per thread and row lane read them at 0.4 - 0.7 TB/s (profiles/r05_streams_c4shard_graph.md: 1.0 ms of a
+// replayed 8-clip step for 0.67 GB); here a thread owns FOUR consecutive columns and walks the rows itself: float4 loads, eight in
+// flight, no LDS.  Rows are added in order 0 .. nb-1 - the same order wherever this function is called from.
+__host__ __device__ constexpr int sum_rows_wide_cols() { return 4096; }          // columns per 1024-thread block
+__device__ __forceinline__ void sum_rows_wide(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out_b, int nb,
+                                              int stride, int ncols, int split, int accum, int c) {
+  if (c >= ncols) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* q = in + c;
+#pragma unroll 8
+  for (int r = 0; r < nb; ++r) {
+    const float4 v = ld4(q + (long long)r * stride);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  float* o = (out_b && c >= split) ? out_b + (c - split) : out + c;       // (split % 4 == 0: the four columns go to one buffer)
+  if (accum) { o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+  else { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+}
+__global__ __launch_bounds__(1024) void sum_rows_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int nb, int stride,
+                                                             int ncols, int accum, float* __restrict__ out_b, int split) {
+  sum_rows_wide(in, out, out_b, nb, stride, ncols, split, accum, (blockIdx.x * 1024 + threadIdx.x) * 4);
+}
+
 // ------------------------------------------------------------------ per-frame statistics
 // One 512-thread block per frame; frame f = n*T + t; u = x[f] (+ add[n]).  Two-pass
 // (mean, then centred second moment): the frame (128 KiB .. 512 KiB) is L2 resident.
@@ -774,7 +798,10 @@ int launch_sum_rows(const float* in, float* out, int nb, int stride, int ncols, 
                     int split) {
   // few partial rows (frame-LN params: 32 x 262144) -> 4 row lanes of 64 columns; many partial rows over few columns
   // (bias / LayerNorm / split-K column sums: 512 x 1024) -> 16-column blocks with 64 row lanes: 4x the blocks
-  if (nb >= 64 && ncols <= 8192)
+  if (nb < 64 && ncols >= 4096 && ncols % 4 == 0 && stride % 4 == 0 && (!out_b || split % 4 == 0) && ((uintptr_t)in & 15) == 0)
+    NPVP_LAUNCH(sum_rows_wide_kernel, dim3((ncols + sum_rows_wide_cols() - 1) / sum_rows_wide_cols()), dim3(1024), 0, stream, in, out,
+                nb, stride, ncols, accum, out_b, out_b ? split : 0);
+  else if (nb >= 64 && ncols <= 8192)
     NPVP_LAUNCH(sum_rows_kernel<16>, dim3((ncols + 15) / 16), dim3(1024), 0, stream, in, out, nb, stride, ncols, accum,
                        out_b, split);
   else
@@ -806,6 +833,11 @@ __global__ __launch_bounds__(1024) void sum_rows_multi_kernel(SumRowsBatch b) {
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
   const SumRowsJob& J = b.j[lo];
   const int CW = b.cw[lo], sh = CW == 16 ? 4 : 6;
+  if (CW == sum_rows_wide_cols()) {              // (block-uniform; the wide path has no barrier)
+    sum_rows_wide(J.in, J.out, J.out_b, J.nb, J.stride, J.ncols, J.out_b ? J.split : 0, J.accum,
+                  (((int)blockIdx.x - b.first[lo]) * 1024 + (int)threadIdx.x) * 4);
+    return;
+  }
   const int cx = threadIdx.x & (CW - 1), rl = threadIdx.x >> sh, nrl = 1024 >> sh;
   const int c = ((int)blockIdx.x - b.first[lo]) * CW + cx;
   float s = 0.f;
@@ -936,7 +968,10 @@ extern "C" int npvp_sum_rows_multi(const void* jobs, int n, hipStream_t stream) 
     for (int i = 0; i < b.n; ++i) {
       b.j[i] = J[at + i];
       NPVP_CHECK_ARG(b.j[i].in && b.j[i].out && b.j[i].nb > 0 && b.j[i].ncols > 0, "sum_rows_multi: bad job");
-      b.cw[i] = (b.j[i].nb >= 64 && b.j[i].ncols <= 8192) ? 16 : 64;         // (launch_sum_rows' choice)
+      const SumRowsJob& q = b.j[i];                                            // (launch_sum_rows' choice)
+      const bool wide = q.mode == 0 && q.nb < 64 && q.ncols >= 4096 && q.ncols % 4 == 0 && q.stride % 4 == 0
+                        && (!q.out_b || q.split % 4 == 0) && ((uintptr_t)q.in & 15) == 0;
+      b.cw[i] = wide ? sum_rows_wide_cols() : (q.nb >= 64 && q.ncols <= 8192) ? 16 : 64;
       b.first[i] = blocks;
       blocks += (b.j[i].ncols + b.cw[i] - 1) / b.cw[i];
     }

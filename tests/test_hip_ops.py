@@ -459,6 +459,39 @@ def test_attention_dropout_bwd_matches_finite_structure(K):
     assert abs(lhs - rhs) < 1e-3 * abs(lhs) + 1e-3, (lhs, rhs)
 
 
+@pytest.mark.parametrize("frames", [160, 24, 1792])
+def test_frame_ln_parameter_gradient_reduction_wide_sets(K, frames):
+    """The second stage of the frame-LN parameter gradients: few partial rows (12 - 32 chunks) over 2 x 131 072 columns - the sets
+    the float4 path of sum_rows takes (csrc/norm.hip sum_rows_wide).  The single launch against an fp64 sum, accumulate on and
+    off, and the queued form (npvp_frameln_act_bwd_reduce_job + npvp_sum_rows_multi) bit-identical to it."""
+    import ctypes
+    from npvp_amd import ops
+    from npvp_amd.sched import _ptr, _stream
+    L = ops.lib()
+    PF = 64 * 2048
+    nbytes = L.npvp_frameln_act_bwd_workspace_bytes(frames, PF)
+    head = frames * 8                                             # psum [frames][4 parts][2]
+    nchunks = (nbytes // 4 - head) // (2 * PF)
+    assert 2 <= nchunks <= 32 and head + nchunks * 2 * PF == nbytes // 4
+    ws = torch.zeros(nbytes // 4, device=DEV)
+    part = O.seeded_randn((nchunks, 2 * PF), 311 + frames).to(DEV)
+    ws[head:] = part.reshape(-1)
+    want = part.double().sum(0)
+    base_w, base_b = O.seeded_randn((PF,), 5).to(DEV), O.seeded_randn((PF,), 6).to(DEV)
+    for accumulate in (0, 1):
+        dw, db = base_w.clone(), base_b.clone()
+        assert L.npvp_frameln_act_bwd_reduce(_ptr(ws), _ptr(dw), _ptr(db), frames, PF, accumulate, _stream()) == 0
+        ew = want[:PF] + (base_w.double() if accumulate else 0)
+        eb = want[PF:] + (base_b.double() if accumulate else 0)
+        assert float((dw.double() - ew).abs().max()) < 2e-5 and float((db.double() - eb).abs().max()) < 2e-5
+        dw2, db2 = base_w.clone(), base_b.clone()
+        job = ctypes.create_string_buffer(48)
+        assert L.npvp_frameln_act_bwd_reduce_job(_ptr(ws), _ptr(dw2), _ptr(db2), frames, PF, accumulate, ctypes.addressof(job)) == 0
+        assert L.npvp_sum_rows_multi(ctypes.addressof(job), 1, _stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), "queued form differs from the single launch"
+
+
 # ------------------------------------------------------------------------------- optimiser
 def test_flat_adamw_matches_torch(K):
     import npvp_amd

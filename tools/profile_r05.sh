@@ -85,6 +85,15 @@ ab)         # in-process A/Bs of scheduling knobs (tools/ab_bench.py: A, B, A, B
     python3 $ROOT/tools/ab_bench.py $SPEC 8 2>/dev/null | grep "^{" >> "$OUT/ab_knobs.txt"
   done
   cat "$OUT/ab_knobs.txt" ;;
+ablib)      # A/B of two BUILDS on one box: the tree against a copy of the package built from other sources under .ab/old (made by hand:
+            # stash the change, build, cp -r bench.py npvp_amd configs .ab/old/, pop, build); new, old, new, old per workload
+  for W in ${ABLIB_WORKLOADS:-c2 c4}; do
+    for T in new old new old; do
+      B=$ROOT/bench.py; [ $T = old ] && B=$ROOT/.ab/old/bench.py
+      MS=$(python3 $B --workload $W --steps 12 --warmup 4 --mode ${ABLIB_MODE:-eager} --no-cpu-baseline --no-probe --no-secondary 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])") || exit 1
+      echo "$W ${ABLIB_MODE:-eager} $T $MS" | tee -a "$OUT/ab_lib.txt"
+    done
+  done ;;
 ab2)        # second sweep: the deferred reductions in the eager two-stream step of the small workloads (fused launches off)
   : > "$OUT/ab_knobs2.txt"
   for SPEC in "c4 sched.ReduceQueueState.enabled True False" "c3 sched.ReduceQueueState.enabled True False" "c0 sched.ReduceQueueState.enabled True False" \
