@@ -207,7 +207,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
 
     def graphed():
         opt.set_lr(P["predictor_lr"])
-        two = os.environ.get("NPVP_GRAPH_STREAMS", "1") == "2"      # experiment: the gradient stream inside the capture
+        two = args.graph_streams == 2                # (measurement: the gradient stream inside the capture, profiles/r05_graph_modes.txt)
         gs = npvp_amd.GraphedTrainStep(model, opt, past, fut, P["lam_PF_L1"], P["KL_beta"], P["max_grad_norm"], single_stream=not two)
         log(f"[{key}] step captured into a HIP graph ({'two streams' if two else 'single stream'}, {gs.launches} library launches)")
         return gs, (lambda i: gs(lr=lr_at(i)))
@@ -406,7 +406,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
            "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "roof_hbm": roof_hbm, "steps": steps,
            "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms}
     if gsync is not None:
-        res["dp"] = {"backend": dist.get_backend(), "buckets": len(gsync.buckets), "last_bucket_mb": round((gsync.buckets[0]["hi"] - gsync.buckets[0]["lo"]) * 4 / 2 ** 20, 1),
+        res["dp"] = {"backend": dist.get_backend(), "comm": gsync.comm, "buckets": len(gsync.buckets), "last_bucket_mb": round((gsync.buckets[0]["hi"] - gsync.buckets[0]["lo"]) * 4 / 2 ** 20, 1),
                      "allreduces_launched": gsync.launched, "exposed_allreduce_ms_per_step": round(gsync.exposed_ms(), 3)}
         log(f"[{key}] data parallel: " + json.dumps(res["dp"]))
         gsync.remove()
@@ -437,6 +437,8 @@ def main():
                          "flavour, pixels -> frozen encoder -> predictor -> frozen decoder -> image L1 (AE = stock PyTorch-ROCm)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (N=1, predictor flavour; no per-kernel probe: roofline null)")
+    ap.add_argument("--graph-streams", type=int, default=1, choices=[1, 2],
+                    help="streams inside a captured step: 1 (default: one chain of nodes, what replays fast) or 2 (measurement only)")
     ap.add_argument("--mode", default="eager", choices=["eager", "graph", "auto"],
                     help="primary workload: eager (default; the roofline probes need it), graph, or auto = the faster of the two in a short trial")
     ap.add_argument("--no-cpu-baseline", action="store_true")

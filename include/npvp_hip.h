@@ -18,17 +18,17 @@
  *     device uint64 (so a captured graph sees a new value per replay), `salt` identifies the call
  *     site; backward entry points replay the forward mask from the same (seed, salt).
  *
- * What is deliberately NOT in this ABI (this header is authoritative where it differs from SURVEY 8(b)'s sketch):
- *   - `npvp_dp_init / npvp_dp_allreduce_async / npvp_dp_wait`: the data-parallel layer stays in torch.distributed
- *     (backend "nccl" = RCCL over xGMI), npvp_amd/dp.py - bucketed all-reduce of the flat gradient buffer on a side HIP
- *     stream, SyncBatchNorm on its own communicator.  PyTorch already owns one RCCL communicator set per process; a second
- *     collective runtime under this library would have to share streams and memory registration with it and would buy
- *     nothing the Python layer does not already do with three calls (all_reduce(async_op=True), work.wait(), wait_stream).
+ * Where this header differs from SURVEY 8(b)'s sketch it is authoritative:
+ *   - the data-parallel exchange (`npvp_dp_*`, at the end of this header) is the one part of the library WITH process state (one
+ *     RCCL communicator per process); RCCL is looked up at the first npvp_dp_* call, not linked.  npvp_amd/dp.py drives either
+ *     these entry points (NPVP_DP_COMM=c) or torch.distributed's ProcessGroupNCCL (default - the same RCCL; a PyTorch host
+ *     already owns a communicator set, SyncBatchNorm's statistics travel on it either way).
  *   - `npvp_<op>_workspace_bytes` exists for the entry points that NEED a workspace (GEMM split-K, LayerNorm / frame-LN /
  *     fused-middle parameter-gradient partials, colsum, metrics); the others take none.
  */
 #ifndef NPVP_HIP_H
 #define NPVP_HIP_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -398,6 +398,23 @@ int npvp_u8hwc_to_f32chw(const void* src_u8, float* dst, long long frames, int H
 int npvp_bias_act(const float* x, const float* bias, const float* residual, float* out, long long outer, long long inner, int C,
                   int layout, int act, npvp_stream_t stream);
 int npvp_act_bwd(const float* g, const float* y, float* dx, long long n, int act, npvp_stream_t stream);
+
+/* ---- the data-parallel exchange: all-reduce(mean) of the parameter gradients, RCCL over xGMI, one process per GPU.
+ * Replaces what the reference gets from Lightning's DDP strategy (ref/train_Predictor_lightning.py:40-42: strategy = 'ddp' over
+ * `devices` GPUs) for a host without torch.distributed.  Protocol: rank 0 calls npvp_dp_unique_id and carries the 128
+ * bytes to every rank (file, socket, MPI, a torch.distributed store ...); every rank, with its device current, calls npvp_dp_init
+ * (collective).  Per step: order `side` after the producers of a bucket of the flat gradient buffer, npvp_dp_allreduce_async(bucket,
+ * n, side) - in place, mean over the ranks, same buckets in the same order on every rank, the host never blocks - and before the
+ * optimiser npvp_dp_wait(compute): the compute stream waits on the device for every reduction enqueued so far.  npvp_dp_finalize
+ * drains and releases the communicator.  RCCL is found at run time (the copy already loaded in the process, else librccl.so.1 on
+ * the loader's path, else $NPVP_RCCL_LIB); a process that never calls these never loads it.  One communicator per process. */
+int npvp_dp_unique_id(void* id_out_128_bytes);
+int npvp_dp_init(int rank, int world, const void* unique_id_128_bytes);
+int npvp_dp_world(void); /* 0 before npvp_dp_init */
+int npvp_dp_rank(void);  /* -1 before npvp_dp_init */
+int npvp_dp_allreduce_async(float* bucket, size_t n, npvp_stream_t side);
+int npvp_dp_wait(npvp_stream_t compute);
+int npvp_dp_finalize(void);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,13 @@ SIGNATURES = {
     "npvp_version": (c_int, []),
     "npvp_last_error": (ctypes.c_char_p, []),
     "npvp_launch_count": (c_ll, []),
+    "npvp_dp_unique_id": (c_int, [c_p]),
+    "npvp_dp_init": (c_int, [c_int, c_int, c_p]),
+    "npvp_dp_world": (c_int, []),
+    "npvp_dp_rank": (c_int, []),
+    "npvp_dp_allreduce_async": (c_int, [c_p, c_ll, c_p]),          # (size_t n: LP64)
+    "npvp_dp_wait": (c_int, [c_p]),
+    "npvp_dp_finalize": (c_int, []),
     "npvp_stream_create_low_priority": (c_p, [c_p, c_p]),
     "npvp_stream_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),

@@ -33,6 +33,36 @@ import torch.nn as nn
 FORCE = os.environ.get("NPVP_DP_FORCE", "0") == "1"
 
 
+# NPVP_DP_COMM=c: the gradient buckets travel through the library's own exchange (include/npvp_hip.h npvp_dp_*: one RCCL communicator
+# per process, created here from an id that rank 0 draws and the process group carries) instead of ProcessGroupNCCL's
+# all_reduce(async_op=True).  Same buckets, same order, same side stream; the mean is RCCL's ncclAvg instead of a pre-scale + sum.
+# What it is for: the proof that the C ABI alone carries a data-parallel step (a host without torch.distributed calls the same
+# four functions).  SyncBatchNorm's statistics, the model broadcast and the barrier stay on the process group either way.
+COMM = os.environ.get("NPVP_DP_COMM", "torch")
+
+
+def c_comm_init(group=None):
+    """one library communicator over the ranks of `group` (idempotent); the 128-byte id travels by a broadcast on the group"""
+    from ._lib import lib, check
+    L = lib()
+    if L.npvp_dp_world() > 0:
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        import ctypes
+        raw = ctypes.create_string_buffer(128)
+        check(L.npvp_dp_unique_id(ctypes.addressof(raw)), "npvp_dp_unique_id")
+        idt = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    if on_gpu:
+        idt = idt.cuda()
+    dist.broadcast(idt, 0, group=group)
+    import ctypes
+    raw = ctypes.create_string_buffer(bytes(idt.cpu().tolist()), 128)
+    check(L.npvp_dp_init(rank, world, ctypes.addressof(raw)), "npvp_dp_init")
+
+
 def active(group=None):
     """the data-parallel machinery is on: more than one rank, or one rank with NPVP_DP_FORCE=1"""
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE)
@@ -74,12 +104,21 @@ def broadcast_module(module, src=0):
 class GradSync:
     """Bucketed, overlapped all-reduce(mean) of a FlatBuffers gradient buffer."""
 
-    def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20, ctx=None):
+    def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20, ctx=None, comm=None):
         """ctx: the trainer's sched.StepContext (FlatAdamW.ctx) whose gradient sink reports contributions to this object and whose
-        gradient stream the bucket all-reduces are ordered after; default: the context current at construction"""
+        gradient stream the bucket all-reduces are ordered after; default: the context current at construction.
+        comm: "torch" (ProcessGroupNCCL / gloo) or "c" (the library's npvp_dp_* exchange; GPU buffers only); default NPVP_DP_COMM"""
         self.buf, self.group = buf, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on = active(group)                 # (one rank with NPVP_DP_FORCE=1 runs the whole machinery on a group of one)
+        self.comm = comm or COMM
+        assert self.comm in ("torch", "c"), self.comm
+        if self.comm == "c" and self.on:
+            if not buf.flat_g.is_cuda:
+                raise RuntimeError("GradSync(comm='c'): the library's exchange is RCCL - it needs the gradient buffer on a GPU")
+            c_comm_init(group)
+            from ._lib import lib
+            self._L = lib()
         from . import ops
         self.ctx = ctx if ctx is not None else ops.current()
         if self.on and ops.AuxStream.enabled:
@@ -147,9 +186,14 @@ class GradSync:
             gs = self.ctx.wgrad.pending_stream()            # weight gradients are accumulated on their own stream
             if gs is not None:
                 self.side.wait_stream(gs)
-            with torch.cuda.stream(self.side):
-                g.mul_(1.0 / self.world)
-                b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.comm == "c":
+                from ._lib import check
+                check(self._L.npvp_dp_allreduce_async(g.data_ptr(), g.numel(), self.side.cuda_stream), "npvp_dp_allreduce_async")
+                b["work"] = True
+            else:
+                with torch.cuda.stream(self.side):
+                    g.mul_(1.0 / self.world)
+                    b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             g.mul_(1.0 / self.world)
             b["work"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -172,7 +216,7 @@ class GradSync:
             # have been reduced before their last contribution.  Drain what is in flight and reset so that the NEXT step
             # re-learns the counts, then fail loudly - this step's gradients are not trustworthy.
             for b in self.buckets:
-                if b["work"] is not None:
+                if b["work"] is not None and b["work"] is not True:
                     if self.cuda:
                         with torch.cuda.stream(self.side):
                             b["work"].wait()
@@ -193,7 +237,9 @@ class GradSync:
             if b["work"] is None:
                 self._launch(b)
         for b in self.buckets:
-            if self.cuda:
+            if b["work"] is True:                       # (the library's exchange: stream-ordered on `side`, nothing to wait for here)
+                pass
+            elif self.cuda:
                 with torch.cuda.stream(self.side):
                     b["work"].wait()
             else:
@@ -203,7 +249,11 @@ class GradSync:
             # what the compute stream waits here is the EXPOSED part of the step's all-reduces (the tail of the last bucket)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            torch.cuda.current_stream().wait_stream(self.side)
+            if self.comm == "c":
+                from ._lib import check
+                check(self._L.npvp_dp_wait(torch.cuda.current_stream().cuda_stream), "npvp_dp_wait")
+            else:
+                torch.cuda.current_stream().wait_stream(self.side)
             e1.record()
             self._exposed.append((e0, e1))
             del self._exposed[:-64]

@@ -63,3 +63,22 @@ def test_rccl_one_rank(request):
     # (2 warm-up + 3 timed steps + the 2 extra steps of the HBM probe)
     assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
     assert d["exposed_allreduce_ms_per_step"] >= 0.0
+
+
+def test_library_exchange_one_rank(request):
+    """include/npvp_hip.h npvp_dp_*: the same one-rank RCCL step with NPVP_DP_COMM=c - rank 0 draws the communicator id
+    (npvp_dp_unique_id), the process group carries it, npvp_dp_init joins, every gradient bucket is reduced by
+    npvp_dp_allreduce_async on GradSync's side stream and the compute stream is ordered behind them by npvp_dp_wait."""
+    rc, read = _jobs(request)
+    log = read("rccl1c")
+    lines = [l for l in log.splitlines() if l.startswith("{")]
+    assert lines, f"bench.py on one rank with NPVP_DP_COMM=c printed no JSON line (rc={rc}):\n{log[-3000:]}"
+    r = json.loads(lines[-1])
+    d = r["dp"]
+    assert d["comm"] == "c" and d["backend"] == "nccl" and d["buckets"] >= 6
+    assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
+    assert r["value"] > 0 and r["config"]["final_loss"] == r["config"]["final_loss"]
+    ref = [l for l in read("rccl1").splitlines() if l.startswith("{")]
+    if ref:     # a group of one: both exchanges are the identity.  (The two runs may differ by the mode trial's few extra steps, so
+        r0 = json.loads(ref[-1])            # the final losses are compared loosely.)
+        assert abs(r0["config"]["final_loss"] - r["config"]["final_loss"]) <= 0.05 * abs(r0["config"]["final_loss"])

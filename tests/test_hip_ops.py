@@ -492,6 +492,39 @@ def test_frame_ln_parameter_gradient_reduction_wide_sets(K, frames):
         assert torch.equal(dw, dw2) and torch.equal(db, db2), "queued form differs from the single launch"
 
 
+def test_library_exchange_entry_points(K):
+    """include/npvp_hip.h npvp_dp_*: a communicator of ONE rank on this card (all a one-GPU box allows): id, init, an in-place
+    all-reduce(mean) on a side stream, the compute stream ordered behind it by npvp_dp_wait, finalize - and the error returns
+    around them.  The mean over one rank is the bucket itself."""
+    import ctypes
+    from npvp_amd import ops
+    L = ops.lib()
+    assert L.npvp_dp_world() == 0 and L.npvp_dp_rank() == -1
+    x = O.seeded_randn((1 << 20,), 77).to(DEV)
+    assert L.npvp_dp_allreduce_async(x.data_ptr(), x.numel(), None) == -1 and b"npvp_dp_init" in L.npvp_last_error()
+    idb = ctypes.create_string_buffer(128)
+    assert L.npvp_dp_unique_id(ctypes.addressof(idb)) == 0, L.npvp_last_error()
+    assert any(idb.raw), "an all-zero communicator id"
+    assert L.npvp_dp_init(1, 1, ctypes.addressof(idb)) == -1                   # rank out of range
+    assert L.npvp_dp_init(0, 1, ctypes.addressof(idb)) == 0, L.npvp_last_error()
+    try:
+        assert L.npvp_dp_world() == 1 and L.npvp_dp_rank() == 0
+        assert L.npvp_dp_init(0, 1, ctypes.addressof(idb)) == -1 and b"already" in L.npvp_last_error()
+        side = torch.cuda.Stream()
+        want = x.clone()
+        y = x * 2.0                                                                 # produced on the compute stream ...
+        side.wait_stream(torch.cuda.current_stream())                               # ... which the side stream is ordered after
+        assert L.npvp_dp_allreduce_async(y.data_ptr(), y.numel(), side.cuda_stream) == 0, L.npvp_last_error()
+        assert L.npvp_dp_wait(torch.cuda.current_stream().cuda_stream) == 0
+        z = y * 0.5                                                                 # reads the reduced bucket on the compute stream
+        torch.cuda.synchronize()
+        assert torch.equal(z, want)
+    finally:
+        assert L.npvp_dp_finalize() == 0
+    assert L.npvp_dp_world() == 0
+    assert L.npvp_dp_wait(None) == -1
+
+
 # ------------------------------------------------------------------------------- optimiser
 def test_flat_adamw_matches_torch(K):
     import npvp_amd

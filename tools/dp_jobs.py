@@ -4,6 +4,7 @@ tests/conftest.py before the test process touches the GPU; this wrapper itself n
   2. bench.py --gpus 2        - the N > 1 branch of the benchmark itself (rank-strided model build, GradSync, SyncBatchNorm,
                                 MAX-over-ranks timing, the JSON line) on the BASELINE multi-GPU shard workload (c4: 8 clips)
   3. bench.py --gpus 1 on RCCL - one rank, backend nccl, NPVP_DP_FORCE=1: the data-parallel path on real RCCL (see below)
+  4. the same with NPVP_DP_COMM=c - the gradient buckets through the library's own npvp_dp_* exchange
 Each job's output goes to <log>.<name>; the wrapper's exit code is the first failure's."""
 import os, subprocess, sys
 
@@ -20,7 +21,12 @@ jobs = [("dp_check", run + ["--master-port", "29531", os.path.join(ROOT, "tools"
 run1 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
 jobs.append(("rccl1", run1 + ["--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
-envs = {"rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1")}
+# 4. the same one-rank RCCL step with the gradient buckets on the LIBRARY's exchange (NPVP_DP_COMM=c: npvp_dp_unique_id / npvp_dp_init /
+#    npvp_dp_allreduce_async / npvp_dp_wait of include/npvp_hip.h) instead of ProcessGroupNCCL's all_reduce
+jobs.append(("rccl1c", run1 + ["--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
+                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
+envs = {"rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
+        "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
 rc = 0
 for name, cmd in jobs:
     with open(f"{log}.{name}", "w") as f:

@@ -29,9 +29,9 @@ graphs)     # the 8-clip shards and c0: eager / single-stream graph / two-stream
     cat "$OUT/g_${W}_eager.txt" "$OUT/g_${W}_graph1.txt" | grep "timed steps"
   done
   W=c4
-  NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2.txt"
-  DEBUG_HIP_FORCE_GRAPH_QUEUES=2 NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q2.txt"
-  DEBUG_HIP_FORCE_GRAPH_QUEUES=1 NPVP_GRAPH_STREAMS=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q1.txt"
+  python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph --graph-streams 2 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2.txt"
+  DEBUG_HIP_FORCE_GRAPH_QUEUES=2 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph --graph-streams 2 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q2.txt"
+  DEBUG_HIP_FORCE_GRAPH_QUEUES=1 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph --graph-streams 2 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph2_q1.txt"
   DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python3 $ROOT/bench.py --workload $W --steps 10 --warmup 3 $QUIET --graph 2>&1 | grep -E "timed steps|captured" | cut -c1-300 > "$OUT/g_${W}_graph1_nocap.txt"
   grep -H "timed steps" "$OUT"/g_${W}_graph*.txt ;;
 shard)      # kernel trace of the 8-clip shard (c4): eager and graph replay
