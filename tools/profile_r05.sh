@@ -68,6 +68,15 @@ tiles)      # shard-sized GEMMs: the forward / dgrad tiles and the fused dgrad +
 mid)        # MlpDWBN layer backward at the c2 decoder size and at an 8-clip shard's
   for F in 1792 160; do python3 $ROOT/tools/mlpdw_bench.py $F >> "$OUT/mlpdw_bench.txt" 2>/dev/null; done
   cat "$OUT/mlpdw_bench.txt" ;;
+midpmc)     # SQ counters of the fused MlpDWBN middle's backward at the c2 decoder size (what is it bound by?)
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_BUSY_CYCLES \
+    -d "$OUT/m1" -o mid -- python3 $ROOT/tools/mlpdw_bench.py 1792 > /dev/null 2> "$OUT/m1.err" || exit 1
+  rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC \
+    -d "$OUT/m2" -o mid -- python3 $ROOT/tools/mlpdw_bench.py 1792 > /dev/null 2> "$OUT/m2.err" || echo "pass 2 failed"
+  rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_WAIT_INST_ANY TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum \
+    -d "$OUT/m3" -o mid -- python3 $ROOT/tools/mlpdw_bench.py 1792 > /dev/null 2> "$OUT/m3.err" || echo "pass 3 failed"
+  python3 $ROOT/tools/rocpd_pmc.py $(ls "$OUT"/m1/*.db "$OUT"/m2/*.db "$OUT"/m3/*.db 2>/dev/null) --filter npvp::mlpdw_mid --out "$OUT/pmc_mid_table.md"
+  rm -rf "$OUT/m1" "$OUT/m2" "$OUT/m3" ;;
 posfuse)    # positional-fuse backward at the c2 decoder / encoder size and at an 8-clip shard's
   python3 $ROOT/tools/posfuse_bench.py 64 28 > "$OUT/posfuse_bench.txt" 2>/dev/null
   python3 $ROOT/tools/posfuse_bench.py 64 2 >> "$OUT/posfuse_bench.txt" 2>/dev/null
