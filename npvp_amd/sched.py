@@ -600,14 +600,25 @@ class RangeGuardState:
           of THIS trainer runs as bf16x6 (sticky; RangeGuard.reset() re-arms).  One step's smallest feature rows are then late by
           one step, never silently wrong for long.
     NPVP_RANGE_GUARD=off passes no counter (the kernel then skips the column maxima).
-    Per trainer: the counter, the sticky fallback and the event total (one trainer's event does not slow another's weight gradients)."""
+    Per trainer: the counter, the fallback and the event total (one trainer's event does not slow another's weight gradients).
+    The fallback is not for ever (the watch fires per K-chunk, so one chunk in which a feature was momentarily tiny
+    would cost the rest of the run): after `retry_after` polls in fallback the fp16 weight gradients are tried again, and the
+    interval doubles every time the event comes back within PROBATION polls of a retry (512, 1 024, ... polls, at most RETRY_MAX).  A replayed graph is not switched
+    back (it would have to be captured again for the try).
+    Under data parallelism each rank decides for itself (its own counter): ranks may run different weight-gradient kernels for a
+    while - slower by the slowest rank, never wrong.  Making the ranks agree needs a collective inside poll(), and a poll that one
+    rank takes alone (rank 0's single-GPU runs inside a multi-rank job; a reference trainer on the same context) would hang the
+    job: a hang is the worse failure, so there is none."""
     mode = os.environ.get("NPVP_RANGE_GUARD", "on")
     strict = mode == "strict"
+    RETRY_AFTER, RETRY_MAX, PROBATION = 512, 1 << 16, 64
 
     def __init__(self, ctx):
         self.ctx = ctx
-        self.fallback = False        # sticky: weight gradients run as bf16x6
+        self.fallback = False        # weight gradients run as bf16x6
         self.events = 0              # total raised so far (host view)
+        self.retry_after = self.RETRY_AFTER
+        self._polls_in_fallback = self._probation = 0
         self._flags = {}
         self._async = None           # (pinned host word, event) of a poll_async() in flight
 
@@ -625,11 +636,21 @@ class RangeGuardState:
         if n:
             f.zero_()
             self.events += n
-            self.fallback = True
+            if self._probation > 0:                 # the event came back soon after a retry: wait twice as long next time
+                self.retry_after = min(2 * self.retry_after, self.RETRY_MAX)
+            self.fallback, self._polls_in_fallback, self._probation = True, 0, 0
+        elif self.fallback:
+            self._polls_in_fallback += 1
+            if self._polls_in_fallback >= self.retry_after:
+                self.fallback, self._polls_in_fallback, self._probation = False, 0, self.PROBATION
+        elif self._probation > 0:
+            self._probation -= 1                    # a clean poll on fp16 again
+            if self._probation == 0:
+                self.retry_after = self.RETRY_AFTER
         return n
 
     def poll(self, dev):
-        """read and clear the device counter (synchronises); arms the sticky fallback if it was raised"""
+        """read and clear the device counter (synchronises); arms the fallback if it was raised"""
         f = self._flags.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
         if f is None:
             return 0
@@ -656,6 +677,7 @@ class RangeGuardState:
 
     def reset(self):
         self.fallback, self.events, self._async = False, 0, None
+        self.retry_after, self._polls_in_fallback, self._probation = self.RETRY_AFTER, 0, 0
         for f in self._flags.values():
             f.zero_()
 

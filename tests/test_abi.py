@@ -275,3 +275,32 @@ def test_lightning_checkpoint_wire_format(tmp_path):
     assert set(ck["state_dict"]) == set(sd) and ck["epoch"] == 13
     back = mk(oracle.Predictor)
     back.load_state_dict({k[len("predictor."):]: v for k, v in ck["state_dict"].items() if k.startswith("predictor.")})
+
+
+def test_range_guard_fallback_is_retried_and_backs_off():
+    """sched.RangeGuardState: a range event arms the bf16x6 fallback of THIS trainer; after `retry_after` clean polls
+    the fp16 weight gradients are tried again; an event within PROBATION polls of a retry doubles the interval, a clean probation
+    resets it.  Pure host logic: driven here with a CPU word in place of the device counter."""
+    from npvp_amd import sched
+    g = sched.RangeGuardState(None)
+    g.RETRY_AFTER, g.PROBATION = 4, 2
+    g.retry_after = 4
+    f = torch.zeros(1, dtype=torch.int32)
+    assert g._note(f, 0) == 0 and not g.fallback
+    f[0] = 3
+    assert g._note(f, 3) == 3 and g.fallback and g.events == 3 and int(f[0]) == 0
+    for _ in range(3):
+        g._note(f, 0)
+        assert g.fallback
+    g._note(f, 0)
+    assert not g.fallback and g._probation == 2                 # the retry
+    g._note(f, 1)                                               # ... and the event is back at once
+    assert g.fallback and g.retry_after == 8 and g.events == 4
+    for _ in range(8):
+        assert g.fallback
+        g._note(f, 0)
+    assert not g.fallback
+    g._note(f, 0); g._note(f, 0)                                # a clean probation
+    assert g._probation == 0 and g.retry_after == 4 and not g.fallback
+    g.reset()
+    assert g.events == 0 and g.retry_after == g.RETRY_AFTER
