@@ -246,7 +246,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
 
         e_ms, e_host = agreed(*trial(eager_step))
         trial_ms = {"eager": round(e_ms, 2), "eager_host": round(e_host, 2)}
-        if e_host >= 0.6 * e_ms:
+        if args.dp_fused_trial == "always" or (args.dp_fused_trial == "auto" and e_host >= 0.6 * e_ms):
             ops.FusedLinearBwd.with_gradient_stream = True
             f_ms, f_host = agreed(*trial(eager_step))
             trial_ms["eager_fused"] = round(f_ms, 2)
@@ -437,6 +437,9 @@ def main():
                          "flavour, pixels -> frozen encoder -> predictor -> frozen decoder -> image L1 (AE = stock PyTorch-ROCm)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from one captured HIP graph (N=1, predictor flavour; no per-kernel probe: roofline null)")
+    ap.add_argument("--dp-fused-trial", default="auto", choices=["auto", "always", "never"],
+                    help="data parallel: when to time the one-launch-per-layer-backward eager step against the two-launch one "
+                         "(auto: if the slowest rank's host enqueue time is >= 60 %% of its step; always: the rehearsals)")
     ap.add_argument("--graph-streams", type=int, default=1, choices=[1, 2],
                     help="streams inside a captured step: 1 (default: one chain of nodes, what replays fast) or 2 (measurement only)")
     ap.add_argument("--mode", default="eager", choices=["eager", "graph", "auto"],

@@ -76,9 +76,6 @@ def test_library_exchange_one_rank(request):
     r = json.loads(lines[-1])
     d = r["dp"]
     assert d["comm"] == "c" and d["backend"] == "nccl" and d["buckets"] >= 6
+    assert "'eager_fused'" in log, "the forced second leg of the mode trial (one launch per layer backward) did not run"
     assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
     assert r["value"] > 0 and r["config"]["final_loss"] == r["config"]["final_loss"]
-    ref = [l for l in read("rccl1").splitlines() if l.startswith("{")]
-    if ref:     # a group of one: both exchanges are the identity.  (The two runs may differ by the mode trial's few extra steps, so
-        r0 = json.loads(ref[-1])            # the final losses are compared loosely.)
-        assert abs(r0["config"]["final_loss"] - r["config"]["final_loss"]) <= 0.05 * abs(r0["config"]["final_loss"])

@@ -14,7 +14,7 @@ env = dict(os.environ, NPVP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
 run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
 jobs = [("dp_check", run + ["--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]),
         ("bench2", run + ["--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "3",
-                          "--warmup", "1", "--no-secondary"])]
+                          "--warmup", "1", "--no-secondary", "--dp-fused-trial", "always"])]
 # 3. RCCL itself, as far as one GPU allows: ONE rank, backend nccl, NPVP_DP_FORCE=1 = the whole data-parallel code path on a group
 #    of one (ProcessGroupNCCL init, model broadcast, SyncBatchNorm2d's all-reduces on their own communicator, GradSync's bucket
 #    all_reduce(async_op=True) on the side stream + work.wait() + finish()) inside the benchmark's own step
@@ -23,8 +23,10 @@ jobs.append(("rccl1", run1 + ["--master-port", "29533", os.path.join(ROOT, "benc
                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
 # 4. the same one-rank RCCL step with the gradient buckets on the LIBRARY's exchange (NPVP_DP_COMM=c: npvp_dp_unique_id / npvp_dp_init /
 #    npvp_dp_allreduce_async / npvp_dp_wait of include/npvp_hip.h) instead of ProcessGroupNCCL's all_reduce
+#    (and with the mode trial's second leg forced - one launch per layer backward beside the gradient stream: GradSync must see the
+#    same per-parameter contribution counts in both legs)
 jobs.append(("rccl1c", run1 + ["--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
-                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
+                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--dp-fused-trial", "always"]))
 envs = {"rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
 rc = 0
