@@ -30,7 +30,7 @@ for spec in fixed:
 wl, target, va, vb = argv[0:4]
 steps = int(argv[4]) if len(argv) > 4 else 8
 obj, attr = resolve(target)
-args = argparse.Namespace(flavour="predictor", graph=False, probe_all=False)
+args = argparse.Namespace(flavour="predictor", graph=False, probe_all=False, graph_streams=1, dp_fused_trial="auto")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 res = {va: [], vb: []}
