@@ -6,7 +6,8 @@
 // registers, no split, no LDS writes in the loop (and no row guard, no row-group mask: a forward GEMM of a tensor whose producer
 // wrote the planes).  The planes are made here by the library's weight splitter applied to A, with A's own amax slot, so both
 // kernels multiply the SAME halves: the outputs must be bit-identical, and are checked.
-// Timed: the five layer shapes of the path at M token rows (default 114 688 = c2's decoder), two and three LDS stages.
+// Timed: the five layer shapes of the path at M token rows (default 114 688 = c2's decoder), two and three LDS stages, in interleaved
+// rounds after a long warm-up (see main: timing the kernels one after the other misread them by 10 % either way).
 //
 // Build + run (on the GPU box, from the repo root):
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Inpvp_amd/csrc -Iinclude tools/gemm_aplanes_probe.hip -Lnpvp_amd -l:libnpvp_hip.so \
@@ -137,7 +138,7 @@ __device__ __forceinline__ void gemm_f16_aplanes_body(const GemmParams& p, const
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
   float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;
-  const unsigned long long seed = 0ull;
+  const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;      // (as in the product kernel: with a constant 0 the compiler drops the masked epilogue and the kernel is half the size)
   static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
     const float4 rowsc = epilogue_row_scales(p, seed, row_base + i * 32, lane);
     static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void gemm_f16_aplanes_body(const GemmParams& p, const
 // A wave splits the fragments it multiplies (16 elements per lane and K-step: 32 v_fma_mix + the row maxima), twice the split work
 // of the register path in total (both column waves split the same rows) - vector-ALU instructions are free beside the MFMAs.
 template <int TM, int TN, int WM, int WN, int NST>
-__device__ __forceinline__ void gemm_f16_adma_body(const GemmParams& p, char* lds, const int bid, const int nwg) {
+__device__ __forceinline__ void probe_adma_body(const GemmParams& p, char* lds, const int bid, const int nwg) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_BYTES = BM * 64;                                   // fp32: 16 k x 4 bytes per row
@@ -171,8 +172,23 @@ __device__ __forceinline__ void gemm_f16_adma_body(const GemmParams& p, char* ld
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   const int nk = p.K >> 4;
   const float sa = amax_scale(amax_slot_read(p.a_amax));
+#ifdef PROBE_AMAX
+  const unsigned int cpeek = amax_peek_block(p.c_amax);
+#endif
+#ifdef PROBE_GUARD
+  __shared__ int guard_flags[NW];
+  float rf[TM] = {1.f, 1.f};
+  bool rescued = false;
+#endif
+  float rm[TM], sa_row[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { rm[i] = 0.f; sa_row[i] = sa; if (p.adrop.thresh) sa_row[i] *= 2.f; }
 
   f32x16 acc[TM][TN];
+#ifdef PROBE_PASSLOOP
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -245,8 +261,19 @@ __device__ __forceinline__ void gemm_f16_adma_body(const GemmParams& p, char* ld
 #pragma unroll
     for (int i_ = 0; i_ < TM; ++i_) {
       f16x4 h0, l0, h1, l1;
+#ifdef PROBE_ROWMAX
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rm[i_]) : "v"(ra_[i_][0][0]), "v"(ra_[i_][0][1]));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rm[i_]) : "v"(ra_[i_][0][2]), "v"(ra_[i_][0][3]));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rm[i_]) : "v"(ra_[i_][1][0]), "v"(ra_[i_][1][1]));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rm[i_]) : "v"(ra_[i_][1][2]), "v"(ra_[i_][1][3]));
+#endif
+#ifdef PROBE_ROWSCALE
+      split_f16_scaled(ra_[i_][0], sa_row[i_], h0, l0);
+      split_f16_scaled(ra_[i_][1], sa_row[i_], h1, l1);
+#else
       split_f16_scaled(ra_[i_][0], sa, h0, l0);
       split_f16_scaled(ra_[i_][1], sa, h1, l1);
+#endif
       const f16x8 fa_hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), fa_lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, fb_[0][j_], acc[i_][j_], 0, 0, 0);
@@ -262,7 +289,40 @@ __device__ __forceinline__ void gemm_f16_adma_body(const GemmParams& p, char* ld
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef PROBE_PASSLOOP
+#ifdef PROBE_GUARD
+    if (pass == 1) break;
+    const int et = (int)((__float_as_uint(sa) >> 23) & 0xffu);
+    bool want = false;
+    int d_[TM]; bool ok_[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rm[i] = fmaxf(rm[i], __shfl_xor(rm[i], 32));
+      const int e = (int)((__float_as_uint(rm[i]) >> 23) & 0xffu);
+      d_[i] = 268 - et - e;
+      ok_[i] = e >= 16 && e != 255 && d_[i] > 0 && d_[i] <= 120;
+      want = want || (ok_[i] && d_[i] >= 18);
+    }
+    if (!block_any<NW>(want, guard_flags, wave)) break;
+    const float isa = pow2_recip(sa);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float g = sa_row[i] * isa;
+      rf[i] = ok_[i] ? __uint_as_float((unsigned int)(127 - d_[i]) << 23) : 1.f;
+      sa_row[i] = (ok_[i] ? amax_scale(rm[i]) : sa) * g;
+    }
+    rescued = true;
+  }
+#else
+    float mx = fmaxf(rm[0], rm[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (pass == 1 || !(mx > 3.0e38f)) break;          // (never taken twice: the structure is what is measured)
+    sa_row[0] *= 0.5f; sa_row[1] *= 0.5f;
+  }
+#endif
+#endif
 #undef PROBE_DMA2
+  if (rm[0] + rm[1] == -1.f) acc[0][0][0] += sa_row[0];   // (keeps the row maxima alive)
 
   const float ia = pow2_recip(sa), ib = pow2_recip(amax_scale(amax_slot_read(p.b_amax)));
   float alpha = p.alpha;
@@ -282,19 +342,40 @@ __device__ __forceinline__ void gemm_f16_adma_body(const GemmParams& p, char* ld
   const int row_base = m0 + wm * TM * 32, col_base = n0 + wn * TN * 32;
   float cmax = 0.f;
   float* scr = reinterpret_cast<float*>(lds) + 4 + wave * EPI_FLOATS;
-  const unsigned long long seed = 0ull;
+#if defined(PROBE_GUARD) && defined(PROBE_PASSLOOP)
+  if (rescued) {
+    float* rowfac = reinterpret_cast<float*>(lds) + 4 + NW * EPI_FLOATS;
+    if (h == 0 && wn == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rowfac[wm * TM * 32 + i * 32 + r] = rf[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float f = rowfac[wm * TM * 32 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][g] *= f;
+      }
+  }
+#endif
+  const unsigned long long seed = (p.seed && p.drop.thresh) ? *p.seed : 0ull;      // (as in the product kernel: with a constant 0 the compiler drops the masked epilogue and the kernel is half the size)
   static_for<0, TM>([&](auto i) __attribute__((always_inline)) {
     const float4 rowsc = epilogue_row_scales(p, seed, row_base + i * 32, lane);
     static_for<0, TN>([&](auto j) __attribute__((always_inline)) {
       epilogue_tile(p, acc[i][j], row_base + i * 32, col_base + j * 32, lane, scr, 0, seed, cmax, rowsc, alpha);
     });
   });
+#ifdef PROBE_AMAX
+  amax_slot_commit_block(p.c_amax, cmax, reinterpret_cast<float*>(lds), cpeek);
+#endif
 }
 
 template <int NST>
-__global__ __launch_bounds__(256, 2) void gemm_f16_adma_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void probe_adma_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) char lds[gemm_f16_lds_bytes<2, 4, 2, 2, NST>()];
-  gemm_f16_adma_body<2, 4, 2, 2, NST>(p, lds, blockIdx.x, gridDim.x);
+  probe_adma_body<2, 4, 2, 2, NST>(p, lds, blockIdx.x, gridDim.x);
 }
 
 template <int NST>
@@ -366,13 +447,9 @@ int main(int argc, char** argv) {
       HIPCHECK(hipMemcpy(h1.data(), C1 + r0 * N, h1.size() * 4, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
     }
-    const int iters = 20;
-    const float t0 = time_us([&] { GemmParams z = p; launch_gemm_f16(z, 0); }, iters);
-    const float t2 = time_us([&] { npvp::gemm_f16_aplanes_kernel<2><<<grid, block>>>(v, (const char*)PA, a_plane_bytes); }, iters);
-    const float t3 = time_us([&] { npvp::gemm_f16_aplanes_kernel<3><<<grid, block>>>(v, (const char*)PA, a_plane_bytes); }, iters);
-    // the fp32 operand by DMA, split at fragment time
+    // the fp32 operand by DMA, split at fragment time: bit-identical too?
     HIPCHECK(hipMemset(C1, 0, (size_t)M * N * 4));
-    npvp::gemm_f16_adma_kernel<3><<<grid, block>>>(v);
+    npvp::probe_adma_kernel<3><<<grid, block>>>(v);
     HIPCHECK(hipDeviceSynchronize());
     size_t bad2 = 0;
     for (long long r0 : {0ll, (long long)M / 2, (long long)M - RCHK}) {
@@ -380,8 +457,21 @@ int main(int argc, char** argv) {
       HIPCHECK(hipMemcpy(h1.data(), C1 + r0 * N, h1.size() * 4, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < h0.size(); ++i) bad2 += h0[i] != h1[i];
     }
-    const float t4 = time_us([&] { npvp::gemm_f16_adma_kernel<2><<<grid, block>>>(v); }, iters);
-    const float t5 = time_us([&] { npvp::gemm_f16_adma_kernel<3><<<grid, block>>>(v); }, iters);
+    // TIMING.  The first version of this program timed the kernels one after the other, the product kernel first - right after
+    // the host had been copying results, i.e. on a GPU that had just idled: it read 10 % slow and every variant after it 10 % fast.
+    // Now: a long warm-up, then three ROUNDS over all five kernels (10 launches each), the fastest round of each kernel counts.
+    auto k0 = [&] { npvp::gemm_f16_kernel<2, 4, 2, 2, false><<<grid, block>>>(v); };            // the product's kernel (register path)
+    auto k1 = [&] { npvp::gemm_f16_aplanes_kernel<2><<<grid, block>>>(v, (const char*)PA, a_plane_bytes); };
+    auto k2 = [&] { npvp::gemm_f16_aplanes_kernel<3><<<grid, block>>>(v, (const char*)PA, a_plane_bytes); };
+    auto k3 = [&] { npvp::probe_adma_kernel<2><<<grid, block>>>(v); };
+    auto k4 = [&] { npvp::probe_adma_kernel<3><<<grid, block>>>(v); };
+    for (int w = 0; w < 40; ++w) { k0(); k2(); }
+    float best[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    for (int round = 0; round < 3; ++round) {
+      best[0] = fminf(best[0], time_us(k0, 10)); best[1] = fminf(best[1], time_us(k1, 10)); best[2] = fminf(best[2], time_us(k2, 10));
+      best[3] = fminf(best[3], time_us(k3, 10)); best[4] = fminf(best[4], time_us(k4, 10));
+    }
+    const float t0 = best[0], t2 = best[1], t3 = best[2], t4 = best[3], t5 = best[4];
     const double fl = 2.0 * M * N * K;
     printf("R=%6d N=%5d K=%5d  product %7.1f us (%6.1f TF)   A planes by DMA, 2 stages %7.1f us (%6.1f TF)   3 stages %7.1f us (%6.1f TF)   "
            "mismatching outputs: %zu of %zu\n", M, N, K, t0, fl / t0 / 1e6, t2, fl / t2 / 1e6, t3, fl / t3 / 1e6, bad, 3 * h0.size());
