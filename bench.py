@@ -297,8 +297,21 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         step(i)
         log(f"[{key}] warm-up step {i} enqueued")
     torch.cuda.synchronize()
-    slack = torch.empty(max(1, int(0.2 * torch.cuda.memory_reserved(dev))), dtype=torch.uint8, device=dev)
+    # (never more than the device has free: an allocation the device cannot serve makes the caching allocator release its WHOLE pool
+    #  and retry - the pool that the warm-up had just grown: the timed steps then grew it again with fresh allocations, each of
+    #  which can block for seconds on a box whose memory an earlier process has just released; profiles/r05_back_to_back.txt)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    slack = torch.empty(max(1, min(int(0.2 * torch.cuda.memory_reserved(dev)), free_b - (8 << 30))), dtype=torch.uint8, device=dev)
+    # ... and touched before it goes back to the cache (its first use happens here, not in a timed step)
+    t_sl = time.perf_counter()
+    slack.zero_()
+    torch.cuda.synchronize()
+    log(f"[{key}] {slack.numel() / 2 ** 30:.1f} GiB of slack allocated and touched in {time.perf_counter() - t_sl:.2f} s")
     del slack
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    log(f"[{key}] before the timed steps: reserved {torch.cuda.memory_reserved(dev) / 2 ** 30:.1f} GiB, allocated "
+        f"{torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB, device free {free_b / 2 ** 30:.1f} of {total_b / 2 ** 30:.1f} GiB, "
+        f"allocator retries so far {torch.cuda.memory_stats(dev).get('num_alloc_retries', 0)}")
     if probe:
         # forward / dgrad kernels of either arithmetic (ids 2, 4, 5, 7: the candidates for the dominant kernel); --probe-all also
         # brackets the weight-gradient and small-shape launches (their event pairs cost the step ~1 %)
@@ -321,6 +334,8 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         launches = gstep.launches
     fence()
     dt = time.perf_counter() - t0
+    log(f"[{key}] after the timed steps: reserved {torch.cuda.memory_reserved(dev) / 2 ** 30:.1f} GiB, allocator retries "
+        f"{torch.cuda.memory_stats(dev).get('num_alloc_retries', 0)}")
     ops.GemmProbe.disarm()
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
