@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the data-parallel layer (npvp_amd.dp) is correct by construction -
+"""CPU, world_size 2 and 4, gloo: the data-parallel layer (npvp_amd.dp) is correct by construction -
 W ranks on shards of a global batch produce the gradients / BatchNorm statistics / parameters of one
 rank on the whole batch, with gradients reduced in place in the flat bucket buffer."""
 import os
@@ -74,10 +74,13 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_gloo_matches_single_process(tmp_path, world):
+    """(2 ranks, and 4: the shards of the 8-sample batch are then 2 samples each - SyncBatchNorm's statistics and the bucket means
+    must still be those of the whole batch)"""
     out = str(tmp_path / "r0.pt")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = torch.load(out)
     # single process, whole batch
     sys.path.insert(0, ROOT)
