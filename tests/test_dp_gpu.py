@@ -32,6 +32,14 @@ def test_two_ranks_equal_single_process(request):
     assert log.count("grad rel-L2") == 2, log[-2000:]
 
 
+def test_four_ranks_equal_single_process(request):
+    """the same check with four ranks sharing the card (an 8-sample global batch, 2 per rank)"""
+    rc, read = _jobs(request)
+    log = read("dp_check4")
+    assert "[dp_check] OK" in log, f"tools/dp_check.py with 4 ranks failed (rc={rc}):\n{log[-3000:]}"
+    assert log.count("grad rel-L2") == 2 and "world=4" in log, log[-2000:]
+
+
 def test_bench_two_ranks(request):
     """bench.py's own N > 1 branch (the one the driver's scaling runs take) with 2 ranks on this card over gloo: the BASELINE
     multi-GPU shard workload c4 (8 clips per rank), rank 0's JSON line."""

@@ -5,6 +5,7 @@ tests/conftest.py before the test process touches the GPU; this wrapper itself n
                                 MAX-over-ranks timing, the JSON line) on the BASELINE multi-GPU shard workload (c4: 8 clips)
   3. bench.py --gpus 1 on RCCL - one rank, backend nccl, NPVP_DP_FORCE=1: the data-parallel path on real RCCL (see below)
   4. the same with NPVP_DP_COMM=c - the gradient buckets through the library's own npvp_dp_* exchange
+  5. tools/dp_check.py with 4 ranks on the card
 Each job's output goes to <log>.<name>; the wrapper's exit code is the first failure's."""
 import os, subprocess, sys
 
@@ -27,7 +28,11 @@ jobs.append(("rccl1", run1 + ["--master-port", "29533", os.path.join(ROOT, "benc
 #    same per-parameter contribution counts in both legs)
 jobs.append(("rccl1c", run1 + ["--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
                                "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--dp-fused-trial", "always"]))
-envs = {"rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
+# 5. tools/dp_check.py once more with FOUR ranks on the card (gloo on device tensors; 8-sample global batch, 2 per rank)
+run4 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1"]
+jobs.append(("dp_check4", run4 + ["--master-port", "29535", os.path.join(ROOT, "tools", "dp_check.py")]))
+envs = {"dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts an activation of the 8-clip batch on a ReLU kink: tools/dp_check.py)
+        "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
 rc = 0
 for name, cmd in jobs:
