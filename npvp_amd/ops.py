@@ -474,9 +474,16 @@ def linear_wgrad(dy, x, with_bias_grad=False, into=None, into_b=None, dy_amax=No
             dw, db = tw, tb
         return (dw, db) if with_bias_grad else dw
     flag = _S._cur.range_guard.flag(dy.device) if watch else None
-    if (watch and acc and prec is None and _S._cur.chain.enabled and _S._cur.wgrad.in_flush and _S._cur.chain.takes(N, K, R)
+    # chained: on the gradient stream, or - without one (the single-stream step that is captured into a graph) - on the current stream,
+    # where the pending reduction rides in the next weight-gradient or fused launch and ReduceQueue.finish() runs the last one.  Not
+    # without a gradient stream under data parallelism: a bucket's all-reduce must not overtake a reduction that is not enqueued yet.
+    on_side = _S._cur.wgrad.in_flush
+    if (watch and acc and prec is None and _S._cur.chain.enabled and _S._cur.chain.takes(N, K, R)
+            and (on_side or (not _S._cur.wgrad.enabled and _S._cur.grad_sink.listener is None))
             and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1):
         _S._cur.chain.launch(dy, x, dw, db, amax_of(dy, dy_amax), amax_of(x, x_amax), a_drop, flag)
+        if not on_side:
+            _S._cur.reduce._arm()
         return (dw, db) if with_bias_grad else dw
     gemm(0, 0, N, K, R, dy, dy.stride(0), x, x.stride(0), dw, colsum_a=db, accumulate=acc, precision=prec, a_amax=dy_amax, b_amax=x_amax,
          a_drop=a_drop, range_flag=flag)
