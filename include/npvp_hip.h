@@ -44,6 +44,15 @@ long long npvp_launch_count(void);
  * weight-gradient writes); least / greatest receive the device's priority range (nullable). */
 void* npvp_stream_create_low_priority(int* least, int* greatest);
 int npvp_stream_destroy(void* stream);
+/* Timing events that survive a HIP-graph capture (the benchmark's live per-kernel probe; the reference has no counterpart - its
+ * timings are time.time() around a forward, ref/Inference.ipynb:463-467).  npvp_event_record on a CAPTURING stream becomes an
+ * external event-record node (hipEventRecordWithFlags / hipEventRecordExternal): every replay stamps the event, and after a
+ * synchronisation npvp_event_elapsed_ms(e0, e1) is the time between the two stamps of the LAST replay; on an ordinary stream it is a
+ * plain hipEventRecord.  elapsed < 0: an event was never recorded or has not completed. */
+void* npvp_event_create(void);
+int npvp_event_record(void* event, void* stream);
+float npvp_event_elapsed_ms(void* event0, void* event1);
+int npvp_event_destroy(void* event);
 
 /* ---- GEMM (every nn.Linear / 1x1 Conv2d / MHA in- and out-projection and their backward:
  * ref/models/VidHRFormer.py:71-72,111,184-185,225 (token FFN), :345,364,380,387 (MlpDWBN fc1/fc2),
@@ -406,8 +415,8 @@ int npvp_act_bwd(const float* g, const float* y, float* dx, long long n, int act
  * (collective).  Per step: order `side` after the producers of a bucket of the flat gradient buffer, npvp_dp_allreduce_async(bucket,
  * n, side) - in place, mean over the ranks, same buckets in the same order on every rank, the host never blocks - and before the
  * optimiser npvp_dp_wait(compute): the compute stream waits on the device for every reduction enqueued so far.  npvp_dp_finalize
- * drains and releases the communicator.  RCCL is found at run time (the copy already loaded in the process, else librccl.so.1 on
- * the loader's path, else $NPVP_RCCL_LIB); a process that never calls these never loads it.  One communicator per process. */
+ * drains and releases the communicator.  RCCL is found at run time (the copy already loaded in the process, else $NPVP_RCCL_LIB, else
+ * librccl.so.1 on the loader's path); a process that never calls these never loads it.  One communicator per process. */
 int npvp_dp_unique_id(void* id_out_128_bytes);
 int npvp_dp_init(int rank, int world, const void* unique_id_128_bytes);
 int npvp_dp_world(void); /* 0 before npvp_dp_init */

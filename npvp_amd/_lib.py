@@ -23,6 +23,10 @@ SIGNATURES = {
     "npvp_dp_finalize": (c_int, []),
     "npvp_stream_create_low_priority": (c_p, [c_p, c_p]),
     "npvp_stream_destroy": (c_int, [c_p]),
+    "npvp_event_create": (c_p, []),
+    "npvp_event_record": (c_int, [c_p, c_p]),
+    "npvp_event_elapsed_ms": (c_f, [c_p, c_p]),
+    "npvp_event_destroy": (c_int, [c_p]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,

@@ -34,3 +34,48 @@ extern "C" void* npvp_stream_create_low_priority(int* least, int* greatest) {
 extern "C" int npvp_stream_destroy(void* s) {
   return hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : -3;
 }
+
+// ---- timing events a HIP-graph capture can carry (bench.py's live roofline probe).  A plain hipEventRecord on a capturing stream
+// only orders work INSIDE the graph: after a replay the event holds no timestamp.  hipEventRecordWithFlags(hipEventRecordExternal)
+// makes the record a node of the graph that stamps the event at every replay, so a pair bracketing a kernel reads that kernel's
+// time in the LAST replay.  On a stream that is not capturing the record is an ordinary one.  (PyTorch-ROCm refuses external
+// events - "External events are disallowed in rocm" - hence these four entry points.)
+extern "C" void* npvp_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDefault) != hipSuccess) { npvp_set_error("event_create: hipEventCreate failed"); return nullptr; }
+  return (void*)e;
+}
+extern "C" int npvp_event_record(void* ev, void* stream) {
+  NPVP_CHECK_ARG(ev, "event_record: null event");
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+  if (cs != hipStreamCaptureStatusActive) {
+    const hipError_t r = hipEventRecord((hipEvent_t)ev, st);
+    if (r != hipSuccess) { npvp_set_error(hipGetErrorString(r)); return NPVP_ERR_LAUNCH; }
+    return NPVP_OK;
+  }
+  // capturing: an event-record NODE behind everything captured so far on this stream, and the stream's capture continues from it
+  // (hipEventRecordWithFlags(..., hipEventRecordExternal) is the one-call form; ROCm 7.2 answers it with "invalid argument", so
+  // the node is added by hand)
+  hipStreamCaptureStatus st2 = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t r = hipStreamGetCaptureInfo_v2(st, &st2, &id, &graph, &deps, &ndeps);
+  if (r != hipSuccess || !graph) { (void)hipGetLastError(); npvp_set_error("event_record: hipStreamGetCaptureInfo_v2 failed"); return NPVP_ERR_LAUNCH; }
+  hipGraphNode_t node = nullptr;
+  r = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, (hipEvent_t)ev);
+  if (r != hipSuccess) { (void)hipGetLastError(); npvp_set_error("event_record: hipGraphAddEventRecordNode failed"); return NPVP_ERR_LAUNCH; }
+  r = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+  if (r != hipSuccess) { (void)hipGetLastError(); npvp_set_error("event_record: hipStreamUpdateCaptureDependencies failed"); return NPVP_ERR_LAUNCH; }
+  return NPVP_OK;
+}
+// milliseconds between two recorded events, both complete (the caller has synchronised); < 0: not ready / not recorded
+extern "C" float npvp_event_elapsed_ms(void* e0, void* e1) {
+  float ms = -1.0f;
+  if (!e0 || !e1 || hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) { (void)hipGetLastError(); return -1.0f; }
+  return ms;
+}
+extern "C" int npvp_event_destroy(void* ev) { return ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess ? NPVP_OK : NPVP_ERR_ARG; }

@@ -8,8 +8,8 @@
 //
 // RCCL is NOT a link-time dependency of libnpvp_hip.so: it is looked up when npvp_dp_unique_id / npvp_dp_init is first called -
 // the copy already in the process if there is one (a PyTorch process has its own librccl.so loaded; two copies of a collective
-// library in one process must not be mixed on one communicator, and nothing here shares one), else librccl.so.1 from the loader's
-// path, else $NPVP_RCCL_LIB.  A process that never calls these entry points never loads it.
+// library in one process must not be mixed on one communicator, and nothing here shares one), else $NPVP_RCCL_LIB, else
+// librccl.so.1 from the loader's path.  A process that never calls these entry points never loads it.
 //
 // State: unlike the kernels' entry points this layer HAS process state - the communicator, its rank / world and the event of the
 // last reduction - guarded by a mutex; one communicator per process, npvp_dp_finalize releases it.
@@ -50,14 +50,17 @@ int fail(const char* what, const char* detail) {
   return NPVP_ERR_LAUNCH;
 }
 
-// the library, once: already-loaded copy first (RTLD_NOLOAD), then the loader's path, then $NPVP_RCCL_LIB
+// the library, once: already-loaded copy first (RTLD_NOLOAD), then $NPVP_RCCL_LIB, then the loader's path
 int load_rccl(Rccl& a) {
   if (a.so) return NPVP_OK;
+  // order (the header and INTEGRATION.md say the same): (1) the copy ALREADY in the process - a PyTorch host has loaded its own
+  // RCCL, and a second copy beside it would be a second set of communicator state and IPC handles; (2) $NPVP_RCCL_LIB; (3) the
+  // loader path
   const char* env = getenv("NPVP_RCCL_LIB");
   void* h = nullptr;
-  if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (int i = 0; i < 2 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  if (!h && env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
   for (int i = 1; i >= 0 && !h; --i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
   if (!h) return fail("npvp_dp: RCCL not found (set NPVP_RCCL_LIB to librccl.so)", dlerror());
   a.get_unique_id = (decltype(a.get_unique_id))dlsym(h, "ncclGetUniqueId");

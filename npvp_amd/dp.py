@@ -41,13 +41,37 @@ FORCE = os.environ.get("NPVP_DP_FORCE", "0") == "1"
 COMM = os.environ.get("NPVP_DP_COMM", "torch")
 
 
+# A segmented replay of the data-parallel step (trainer.GraphedTrainStep(grad_sync=...)): while a trainer.StepTape is RECORDING, every
+# collective of the step - a gradient bucket's all-reduce, SyncBatchNorm's statistics, the closing wait - is not issued but handed to
+# the tape as a host action that CUTS the HIP-graph capture in two; a replay then alternates graph launches and those actions.
+_TAPE = None
+
+
+def set_tape(tape):
+    global _TAPE
+    prev, _TAPE = _TAPE, tape
+    return prev
+
+
+def _collective(fn):
+    """issue fn() now, or - while a step tape records - make it the host action between two graph segments"""
+    if _TAPE is not None:
+        _TAPE.cut(fn)
+    else:
+        fn()
+
+
 def c_comm_init(group=None):
     """one library communicator over the ranks of `group` (idempotent); the 128-byte id travels by a broadcast on the group"""
     from ._lib import lib, check
     L = lib()
-    if L.npvp_dp_world() > 0:
-        return
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if L.npvp_dp_world() > 0:
+        # one communicator per process: a second GradSync on ANOTHER group must not silently reuse the first group's
+        if (L.npvp_dp_world(), L.npvp_dp_rank()) != (world, rank):
+            raise RuntimeError(f"npvp_dp: the library's communicator spans {L.npvp_dp_world()} ranks (this is rank {L.npvp_dp_rank()}), "
+                               f"the requested group has {world} (rank {rank}); npvp_dp_finalize() first")
+        return
     on_gpu = dist.get_backend(group) == "nccl"
     idt = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
@@ -105,9 +129,16 @@ class GradSync:
     """Bucketed, overlapped all-reduce(mean) of a FlatBuffers gradient buffer."""
 
     def __init__(self, buf, bucket_bytes=64 << 20, group=None, last_bucket_bytes=8 << 20, ctx=None, comm=None):
-        """ctx: the trainer's sched.StepContext (FlatAdamW.ctx) whose gradient sink reports contributions to this object and whose
-        gradient stream the bucket all-reduces are ordered after; default: the context current at construction.
+        """buf: the trainer's optimiser (FlatAdamW: its flat buffers AND its scheduling context are taken - the form to use) or a bare
+        FlatBuffers (CPU / gloo tests; then ctx = the trainer's sched.StepContext, default: the context current at construction).  The
+        context matters: its gradient sink reports the backward kernels' in-place contributions to this object and the bucket
+        all-reduces are ordered after its gradient stream - a GradSync listening on another context than the one the step runs
+        under would learn too few contributions and reduce buckets early (trainer.predictor_train_step refuses such a pair).
         comm: "torch" (ProcessGroupNCCL / gloo) or "c" (the library's npvp_dp_* exchange; GPU buffers only); default NPVP_DP_COMM"""
+        if hasattr(buf, "buf") and hasattr(buf, "ctx"):        # a FlatAdamW
+            if ctx is not None and ctx is not buf.ctx:
+                raise ValueError("GradSync: ctx differs from the optimiser's own scheduling context")
+            buf, ctx = buf.buf, buf.ctx
         self.buf, self.group = buf, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on = active(group)                 # (one rank with NPVP_DP_FORCE=1 runs the whole machinery on a group of one)
@@ -126,6 +157,9 @@ class GradSync:
             # produced on the auxiliary encoder stream (NPVP_DUAL_ENCODER=1) could land after it
             raise RuntimeError("GradSync: NPVP_DUAL_ENCODER=1 (two-stream encoder passes) is not supported under data parallelism")
         self.cuda = buf.flat_g.is_cuda
+        if self.on and self.cuda:
+            from .sched import WgradStreamState
+            WgradStreamState.use_normal_priority()      # (a low-priority queue beside RCCL's streams slows every eager dispatch)
         self.side = torch.cuda.Stream() if self.cuda else None
         # Contiguous buckets over the flat buffer, each owning whole parameters, cut in AUTOGRAD order: the buffer is laid out in
         # module order (coordinate MLP, encoder, event encoders, decoder last), backward fills it from the END, so the buckets are
@@ -178,6 +212,13 @@ class GradSync:
             self._launch(b)
 
     def _launch(self, b):
+        if _TAPE is not None:
+            b["work"] = "taped"                 # (finish() of the recording pass must not launch it again)
+            _TAPE.cut(lambda b=b: self._launch_now(b))
+            return
+        self._launch_now(b)
+
+    def _launch_now(self, b):
         g = self.buf.flat_g[b["lo"]:b["hi"]]
         if self.cuda:
             ev = torch.cuda.Event()
@@ -216,7 +257,7 @@ class GradSync:
             # have been reduced before their last contribution.  Drain what is in flight and reset so that the NEXT step
             # re-learns the counts, then fail loudly - this step's gradients are not trustworthy.
             for b in self.buckets:
-                if b["work"] is not None and b["work"] is not True:
+                if b["work"] is not None and b["work"] is not True and b["work"] != "taped":
                     if self.cuda:
                         with torch.cuda.stream(self.side):
                             b["work"].wait()
@@ -233,9 +274,20 @@ class GradSync:
                                "relearn() before changing the training graph on purpose")
         for k in self.count:
             self.count[k] = 0
-        for b in self.buckets:
-            if b["work"] is None:
-                self._launch(b)
+        if _TAPE is not None:
+            # recording: the buckets no hook launched and the closing wait are ONE host action of the replay
+            late = [b for b in self.buckets if b["work"] is None]
+            for b in self.buckets:
+                if b["work"] == "taped":            # (launched by an action of the replay, not now)
+                    b["work"] = None
+                b["ready"] = 0
+            _TAPE.cut(lambda late=late: self._finish_now(late))
+            return
+        self._finish_now([b for b in self.buckets if b["work"] is None])
+
+    def _finish_now(self, late):
+        for b in late:
+            self._launch_now(b)
         for b in self.buckets:
             if b["work"] is True:                       # (the library's exchange: stream-ordered on `side`, nothing to wait for here)
                 pass
@@ -301,9 +353,9 @@ class _SyncBNFn(torch.autograd.Function):
         C = x.shape[1]
         dims = [0] + list(range(2, x.dim()))
         if training:
-            cnt = torch.tensor([x.numel() / C], dtype=x.dtype, device=x.device)
+            cnt = x.new_full((1,), x.numel() / C)             # (a fill kernel, not a host-to-device copy: capturable)
             stat = torch.cat([x.sum(dims), (x * x).sum(dims), cnt])
-            dist.all_reduce(stat, group=group)
+            _collective(lambda: dist.all_reduce(stat, group=group))
             n = stat[-1]
             mean = stat[:C] / n
             var = stat[C:2 * C] / n - mean * mean
@@ -328,7 +380,7 @@ class _SyncBNFn(torch.autograd.Function):
         g = dy * weight.view(shape)
         if training:
             s = torch.cat([g.sum(dims), (g * xhat).sum(dims)])
-            dist.all_reduce(s, group=group)
+            _collective(lambda: dist.all_reduce(s, group=group))
             dx = rstd.view(shape) * (g - (s[:C] / n).view(shape) - xhat * (s[C:] / n).view(shape))
         else:
             dx = g * rstd.view(shape)

@@ -358,6 +358,8 @@ class VidHRFormerBlockDecNAR(nn.Module):
         N, T2, H, W, C = tgt.shape
         T1, P = memory.shape[1], H * W
         if query_evt.dim() == 5:
+            if query_evt.shape[1] > 1 and not torch.equal(query_evt[:, 1:], query_evt[:, :1].expand_as(query_evt[:, 1:])):
+                raise NotImplementedError("VidHRFormerBlockDecNAR: query_evt differs between time-steps (see VidHRformerDecoderNAR.forward)")
             query_evt = query_evt[:, 0]
         query_evt = query_evt.contiguous()
         tr = self.training
@@ -438,6 +440,13 @@ class VidHRformerDecoderNAR(nn.Module):
         """query_evt (N,T2,C,H,W), memory (N,T1,C,H,W) -> (N,T2,C,H,W)   (reference signature)"""
         N, T2, C, H, W = query_evt.shape
         T1 = memory.shape[1]
+        # The kernels add ONE (N,H,W,C) event latent to every time-step (what the predictor passes: z repeated over T2,
+        # ref Predictor.py:317).  The reference's signature would also take a query that differs from step to step; silently
+        # keeping step 0 of such a tensor would be a wrong answer, so it is refused (one device comparison at this API edge -
+        # Predictor.forward goes through forward_canonical and never pays it).
+        if T2 > 1 and not query_evt.is_meta and not torch.equal(query_evt[:, 1:], query_evt[:, :1].expand(-1, T2 - 1, -1, -1, -1)):
+            raise NotImplementedError("VidHRformerDecoderNAR.forward: query_evt differs between time-steps; this build adds one "
+                                      "(N,C,H,W) event latent to all T2 steps (the only form the predictor produces)")
         qe = ops.nchw_to_canonical(query_evt[:, :1]).view(N, H, W, C)
         mem = ops.nchw_to_canonical(memory).view(N, T1, H, W, C)
         return self.forward_canonical(qe, mem, memory_pos, tgt_pos, pos_fuser, T2, nchw=True)

@@ -90,11 +90,10 @@ def _bn_rows(x2, bn):
     """BatchNorm2d semantics on channels-last rows x2 [R, C] (statistics over the R = N*H*W rows per channel).
     Tiny tensors ((N*64) x 512): stock torch batch-norm kernels; under data parallelism `bn` has been swapped
     for npvp_amd.dp.SyncBatchNorm2d and the statistics span all ranks."""
-    from ..dp import SyncBatchNorm2d, _SyncBNFn
-    import torch.distributed as dist
+    from ..dp import SyncBatchNorm2d, _SyncBNFn, active
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    if isinstance(bn, SyncBatchNorm2d) and bn.training and dist.is_initialized() and dist.get_world_size() > 1:
+    if isinstance(bn, SyncBatchNorm2d) and bn.training and active():      # (more than one rank, or one rank with NPVP_DP_FORCE=1)
         from ..dp import syncbn_group
         return _SyncBNFn.apply(x2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, True, syncbn_group())
     return F.batch_norm(x2, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)

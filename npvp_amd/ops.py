@@ -12,7 +12,7 @@ from ._lib import lib, check
 # scheduling state (per trainer: sched.StepContext) and the process-wide pieces beside it; re-exported here because the rest of the
 # package, the tests and the tools reach them as ops.<name>
 from . import sched as _S            # (hot paths read the current context as _S._cur.<field>: one global + two attribute loads)
-from .sched import (_p, _ptr, _stream, _ws, AmaxSlot, GemmProbe, HbmProbe, AuxStream, StepContext, current, use, scoped,
+from .sched import (_p, _ptr, _stream, _ws, AmaxSlot, GemmProbe, HbmProbe, ProbeEvent, probe_pair, AuxStream, StepContext, current, use, scoped,
                     remember, rng, GradSink, WgradStream, WgradChain, ReduceQueue, RangeGuard)
 
 
@@ -347,8 +347,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, out, bias=None, act=0, aux_in=None
         kid = _gemm_kernel_id(a_kc, b_kc, M, N, K, prec, planes is not None)
         probe = GemmProbe.only is None or kid in GemmProbe.only
     if probe:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = probe_pair()
     rc = lib().npvp_gemm_f32(
         a_kc, b_kc, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), out.stride(0),
         None if bias is None else bias.data_ptr(), act, None if aux_in is None else aux_in.data_ptr(),
@@ -547,8 +546,7 @@ def linear_bwd(dy, x, w, b, sk, act=0, aux_in=None, drop=NO_DROP, residual=None,
                 job_addr, prev_addr = _S._cur.reduce.splitk_slot(outs), None
             probe = GemmProbe.armed and (GemmProbe.only is None or 8 in GemmProbe.only)
             if probe:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0, e1 = probe_pair()
             check(lib().npvp_linear_bwd_f16(R, N, K, dy.data_ptr(), dy.stride(0), dy_amax.data_ptr(), planes.data_ptr(), w_amax.data_ptr(),
                                             dx.data_ptr(), dx.stride(0), act, _ptr(aux_in), _ptr(residual),
                                             0 if residual is None else residual.stride(0), drop.p, drop.mode, drop.g1, drop.g2, drop.salt,
@@ -627,6 +625,8 @@ class ActSink:
         if self.buf is None:
             self.buf = torch.empty(shape, dtype=torch.float32, device=dev)
             return self.buf, False
+        if self.buf.numel() != torch.Size(shape).numel():
+            raise RuntimeError(f"ActSink: a consumer contributes a gradient of shape {tuple(shape)} to a buffer of shape {tuple(self.buf.shape)}")
         return self.buf, True
 
     @staticmethod
@@ -934,7 +934,14 @@ def _posfuse_bwd_call(dy, x, add, gamma, mean, rstd, N, T, PF, beta_shape, want_
     if sunk:
         # (one accumulate flag for both tables: they are sunk together - a fresh pair is written, an existing pair added to)
         dbeta, acc = beta_sink.target(beta_shape, x.device)
-        dgamma = gamma_sink.target(gamma.shape, x.device)[0] if want_gamma else None
+        dgamma = None
+        if want_gamma:
+            dgamma, acc_g = gamma_sink.target(gamma.shape, x.device)
+            if acc_g != acc:
+                # the kernel takes ONE accumulate flag: a pair out of step (one table sunk alone by some consumer) would have its
+                # second table accumulated into uninitialised memory - bring the fresh buffer to zero and accumulate into both
+                (dgamma if not acc_g else dbeta).zero_()
+                acc = True
     else:
         dbeta = torch.empty(beta_shape, dtype=torch.float32, device=x.device) if want_beta else None
         dgamma = torch.empty(gamma.shape, dtype=torch.float32, device=x.device) if want_gamma else None

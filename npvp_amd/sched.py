@@ -101,6 +101,41 @@ class AmaxSlot:
         return s
 
 
+class ProbeEvent:
+    """A timing event of the library (include/npvp_hip.h npvp_event_*): recorded on the calling thread's current stream; inside a
+    stream capture the record becomes an external event-record node, so the pair bracketing a launch reads that launch's time in
+    the LAST replay of the graph (torch.cuda.Event cannot: "External events are disallowed in rocm").  Same interface as the
+    torch event the probes used before (record / elapsed_time)."""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        self.h = lib().npvp_event_create()
+        if not self.h:
+            raise RuntimeError("npvp_event_create failed")
+
+    def record(self):
+        check(lib().npvp_event_record(self.h, _stream()), "npvp_event_record")
+
+    def elapsed_time(self, other):
+        """ms from this event to `other` (both complete); negative when one of them was never stamped"""
+        return float(lib().npvp_event_elapsed_ms(self.h, other.h))
+
+    def __del__(self):
+        h, self.h = self.h, None
+        if h:
+            try:
+                lib().npvp_event_destroy(h)
+            except Exception:
+                pass
+
+
+def probe_pair():
+    """two fresh timing events, the first already recorded"""
+    e0, e1 = ProbeEvent(), ProbeEvent()
+    e0.record()
+    return e0, e1
+
+
 class GemmProbe:
     """bench.py's live roofline probe: when armed, every GEMM launch is bracketed by a pair of HIP events on the stream
     it is launched on (no synchronisation; read after the timed region), keyed by (layout, kernel): layout (1,1) forward,
@@ -130,8 +165,11 @@ class GemmProbe:
         """{(layout, kernel id): (launches, total_ms, total_flops, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
         out = {}
         for e0, e1, fl, by, key in cls.records:
+            dt = e0.elapsed_time(e1)
+            if dt < 0.0:                # (a pair that was never stamped: recorded while capturing a graph that was not replayed)
+                continue
             n, ms, f, b = out.get(key, (0, 0.0, 0.0, 0.0))
-            out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+            out[key] = (n + 1, ms + dt, f + fl, b + by)
         return out
 
 
@@ -147,7 +185,7 @@ class HbmProbe:
     def begin(cls):
         if not cls.armed:
             return None
-        e0 = torch.cuda.Event(enable_timing=True)
+        e0 = ProbeEvent()
         e0.record()
         return e0
 
@@ -155,7 +193,7 @@ class HbmProbe:
     def end(cls, e0, name, nbytes):
         if e0 is None:
             return
-        e1 = torch.cuda.Event(enable_timing=True)
+        e1 = ProbeEvent()
         e1.record()
         cls.records.append((e0, e1, name, float(nbytes)))
 
@@ -164,8 +202,11 @@ class HbmProbe:
         """{kernel: (launches, total_ms, total_algorithmic_bytes)} - after torch.cuda.synchronize()"""
         out = {}
         for e0, e1, name, by in cls.records:
+            dt = e0.elapsed_time(e1)
+            if dt < 0.0:
+                continue
             n, ms, b = out.get(name, (0, 0.0, 0.0))
-            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + by)
+            out[name] = (n + 1, ms + dt, b + by)
         return out
 
 
@@ -192,6 +233,35 @@ class AuxStream:
             if quiet is not None:
                 quiet(False)
         return cls._streams[key]
+
+
+PRIME_GIB = float(os.environ.get("NPVP_PRIME_GIB", "24"))
+
+
+def prime_clocks(dev, gib=None):
+    """One long hipMemsetAsync before a busy period that starts from an idle device (round 6, profiles/r06_clock_priming.txt).
+    Measured on MI355X with the c2 step replayed from its graph: started cold, the replays run at sclk ~1.97 GHz (237 ms per step);
+    started right behind ONE memset over a >= 16 GiB buffer they run at ~2.27 GHz (214 ms; the MFMA GEMMs 19 % faster, the HBM-bound
+    kernels unchanged) and stay there for as long as the queue never drains (60 replays = 13 s checked; the next idle moment drops the
+    state again).  A fill KERNEL over the same bytes, several shorter memsets, or a device-to-device copy do nothing - it is the
+    firmware's clock decision for the busy period that follows a long pure-memory phase, not a cache or allocator effect.  The
+    memset is ~5 ms of device time once per busy period; the buffer comes from (and returns to) the caching allocator.
+    -> bytes zeroed (0: not enough free memory, nothing done)"""
+    gib = PRIME_GIB if gib is None else gib
+    if gib <= 0:
+        return 0
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    n = int(min(gib * (1 << 30), max(free_b - (8 << 30), cached // 2)))
+    if n < (8 << 30):
+        return 0
+    try:
+        buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    except RuntimeError:                    # (out of memory after all: priming is optional)
+        return 0
+    buf.zero_()                             # (a tensor that owns its whole storage: ONE hipMemsetAsync)
+    del buf
+    return n
 
 
 # --------------------------------------------------------------------------- per-trainer state
@@ -283,6 +353,12 @@ class WgradStreamState:
     Per trainer: the queue of deferred launches, the pending join, the tensors held for the gradient stream.  Process-wide: the
     gradient stream of a device (one low-priority stream, shared: work of two trainers is serialised on it) and the knobs."""
     enabled = os.environ.get("NPVP_WGRAD_STREAM", "1") == "1"
+    # Priority of the gradient stream.  Lowest device priority (critical-path kernels are dispatched first: -1 ms of a c2 step) - but
+    # NOT in a process that holds an RCCL communicator: with ProcessGroupNCCL's streams alive beside a low-priority queue every
+    # dispatch of the eager two-stream step takes ~50 us longer on the device (c4 shard 29 -> 64 - 72 ms, c2 233 -> 266 ms; a
+    # normal-priority gradient stream or GPU_MAX_HW_QUEUES <= 3 restores it: profiles/r06_dp_eager_bisect.txt).  npvp_amd.dp switches
+    # this off (`use_normal_priority`) when the data-parallel machinery comes up; NPVP_WGRAD_PRIORITY=low|normal overrides.
+    low_priority = os.environ.get("NPVP_WGRAD_PRIORITY", "low") != "normal"
     HOLD_BYTES = 2048 << 20
     BATCH = 16
     _side = {}               # (device type, index) -> the device's gradient stream
@@ -301,11 +377,22 @@ class WgradStreamState:
             st = None
             # lowest device priority (torch only offers normal / high): critical-path kernels are dispatched first
             with torch.cuda.device(dev):
-                h = lib().npvp_stream_create_low_priority(None, None)
+                h = lib().npvp_stream_create_low_priority(None, None) if cls.low_priority else None
             if h:
                 st = torch.cuda.ExternalStream(h, device=dev)
             cls._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return cls._side[key]
+
+    @classmethod
+    def use_normal_priority(cls):
+        """data parallel (an RCCL communicator in the process): gradient streams from now on at normal priority; the low-priority
+        ones created so far are retired once the device is idle (no trainer may be inside a backward pass)"""
+        if os.environ.get("NPVP_WGRAD_PRIORITY") == "low":
+            return
+        cls.low_priority = False
+        if cls._side:
+            torch.cuda.synchronize()
+            cls._side.clear()
 
     def run(self, fn, *keep_alive, wrote=None, urgent=False):
         """fn() on the side stream, after everything already enqueued on the current stream; keep_alive tensors are protected
@@ -564,8 +651,7 @@ class WgradChainState:
         seed = self.ctx.rng.seed_tensor(dy.device) if a_drop.on else None
         probe = GemmProbe.armed and (GemmProbe.only is None or 6 in GemmProbe.only)
         if probe:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = probe_pair()
         check(lib().npvp_wgrad_f16_chained(N, K, R, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), _ptr(db), 1,
                                            _ptr(dy_amax), _ptr(x_amax), _ptr(flag), a_drop.p, a_drop.g1, a_drop.g2, a_drop.salt,
                                            _ptr(seed), ctypes.addressof(prev[0]) if prev is not None else None, ctypes.addressof(job),

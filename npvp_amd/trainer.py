@@ -252,6 +252,11 @@ def predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1=0.0
 def _predictor_train_step(predictor, opt, past_feats, future_feats, lam_PF_L1, KL_beta, max_grad_norm, frozen_dec, future_frames, sync,
                           grad_sync):
     dev = past_feats.device
+    if grad_sync is not None and grad_sync.on and grad_sync.ctx is not opt.ctx:
+        # (its listener would sit on another context's gradient sink - the in-place contributions of this step would go
+        #  unreported and buckets would be all-reduced before their last write)
+        raise RuntimeError("predictor_train_step: grad_sync listens on another scheduling context than the optimiser's; build it as "
+                           "dp.GradSync(opt) (or pass ctx=opt.ctx)")
     ops.WgradStream.join()            # (a backward pass that raised leaves queued weight-gradient work and an open join behind)
     ops.rng.begin_step(dev)
     opt.max_grad_norm = max_grad_norm
@@ -444,6 +449,71 @@ def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, str
     return ck.get("epoch", 0), ck.get("global_step", 0)
 
 
+class StepTape:
+    """A training step as a CHAIN of HIP-graph segments with host actions between them - how a step with collectives in it is
+    replayed without the host enqueueing its ~1 000 launches: the kernels live in graphs, the collectives stay ordinary eager calls
+    (no collective is ever captured; RCCL and gloo both work), and the host touches the step once per segment and action (~30 times).
+
+    Recording: `begin()` starts a stream capture on the calling thread's current (non-default) stream; `cut(action)` - called from
+    wherever the step wants a collective, also from the autograd engine's worker thread (hence capture mode "relaxed") - ends the
+    current capture, notes the action, and begins the next capture on the same stream; `end()` closes the last one.  All segments
+    allocate from ONE private pool, which is valid because they are always replayed in recording order.  Nothing executes while
+    recording, so the actions are not run then either: the step's tensors hold garbage until the first replay.
+    Every segment starts with a one-element tick kernel: a cut right after a cut must not leave an empty graph behind."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.items = []                  # torch.cuda.CUDAGraph | callable, in replay order
+        self.pool = torch.cuda.graph_pool_handle()
+        self._g = None
+        self._tick = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @property
+    def recording(self):
+        return self._g is not None
+
+    @property
+    def segments(self):
+        return sum(1 for it in self.items if isinstance(it, torch.cuda.CUDAGraph))
+
+    def begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        self._g = g
+        self._tick.add_(1.0)
+
+    def cut(self, action):
+        g, self._g = self._g, None
+        g.capture_end()
+        self.items.append(g)
+        self.items.append(action)
+        self.begin()
+
+    def end(self):
+        g, self._g = self._g, None
+        if g is not None:
+            g.capture_end()
+            self.items.append(g)
+
+    def abort(self):
+        """after an exception inside a recording: close the open capture (its graph is dropped)"""
+        g, self._g = self._g, None
+        if g is not None:
+            try:
+                g.capture_end()
+            except Exception:
+                pass
+        self.items = []
+
+    def replay(self):
+        Graph = torch.cuda.CUDAGraph
+        for it in self.items:
+            if type(it) is Graph:
+                it.replay()
+            else:
+                it()
+
+
 class GraphedTrainStep:
     """The whole optimisation step (forward, losses, backward, clip, AdamW, weight-plane refresh) captured ONCE into a HIP graph and
     replayed per step: the host side of a step (1 000 - 3 000 launches and their Python at any batch size) shrinks to one graph
@@ -460,48 +530,108 @@ class GraphedTrainStep:
     From the first event on the step is captured again with the weight gradients in the bf16x6 arithmetic (`recaptures` counts them;
     `range_events` is the running total) - a replayed graph cannot be switched, only re-captured.
 
-    Single-process only: collectives are not captured (use the eager step with GradSync for N > 1)."""
+    Data parallel (grad_sync = the trainer's dp.GradSync): collectives are NOT captured.  The step is recorded as a StepTape - a
+    chain of single-stream graph segments cut wherever the eager step issues a collective (each gradient bucket's all-reduce, the
+    EventEncoder's SyncBatchNorm statistics forward and backward, the closing wait before the clip) - and a replay alternates graph
+    launches with those collectives, issued eagerly exactly as the eager step does (bucket all-reduces on GradSync's side stream
+    behind an event of the compute stream, so they still overlap the rest of the backward pass).  ~15 segments + ~15 collectives
+    per step instead of ~1 000 enqueued launches: the data-parallel shard step no longer depends on the host's speed.  The warm-up
+    (at least two eager steps, in the single-stream schedule the capture uses) teaches GradSync the contribution counts."""
 
     def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3,
-                 single_stream=True, poll_every=32):
+                 single_stream=True, poll_every=32, grad_sync=None, prime=True):
+        """warmup: eager optimiser steps taken on (past_feats, future_feats) BEFORE the capture - they are real steps (parameters,
+        Adam state, step count and dropout seed advance `warmup` times); pass warmup=0 when the caller has already stepped the model
+        eagerly on this device (then nothing but the capture itself happens, and the capture executes nothing)."""
         self.opt = opt
         self.past, self.fut = past_feats.clone(), future_feats.clone()
         self._args = (predictor, opt, self.past, self.fut, lam_PF_L1, KL_beta, max_grad_norm)
+        self.grad_sync = grad_sync if (grad_sync is not None and grad_sync.on) else None
+        if self.grad_sync is not None:
+            assert single_stream, "a data-parallel step is recorded single-stream (graph segments are chains)"
+            warmup = max(2, warmup)
+        self.tape = None
+        # prime: a replay that finds the stream DRAINED (the first one, or the first after the caller synchronised) is preceded by
+        # sched.prime_clocks - one long memset after which the device runs the busy period that follows at its higher engine clock
+        # (c2: 237 -> 214 ms per replayed step).  A loop that keeps the queue fed is primed once.
+        self.prime, self.primed = bool(prime), 0
         self.single_stream, self.poll_every, self.warmup = single_stream, max(1, int(poll_every)), warmup
         self.replays = self.recaptures = self.range_events = 0
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._flag_event = None
-        self._capture()
+        self._capture(self.warmup)
 
-    def _capture(self):
+    def _capture(self, warmup=0):
+        """warmup: eager steps before the capture - REAL optimiser steps on the batch in the static buffers (the construction's
+        `warmup`, documented there: lazy streams / workspaces / weight planes get created).  A re-capture (range event) runs none:
+        everything lazy exists already, and extra steps would apply extra AdamW updates, advance the step count and the dropout
+        seed behind the caller's back - the trajectory of a replayed run must be the eager one's."""
         with ops.use(self.opt.ctx):
-            self._capture_in_ctx()
+            self._capture_in_ctx(warmup)
 
-    def _capture_in_ctx(self):
+    def _capture_in_ctx(self, warmup):
         dev = self.past.device
         two_streams = ops.WgradStream.enabled
         if self.single_stream:
             ops.WgradStream.join()
             ops.WgradStream.enabled = False
+        gs = self.grad_sync
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):               # eager warm-up on a side stream (lazy streams / workspaces get created)
-                for _ in range(self.warmup):
-                    predictor_train_step(*self._args, sync=False)
+                if gs is not None and warmup:
+                    gs.relearn()                        # (the contribution counts of THIS schedule: the first warm-up step learns them)
+                for _ in range(warmup):
+                    predictor_train_step(*self._args, sync=False, grad_sync=gs)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
+            # the eager steps' cached blocks go back to the device: the capture allocates the step's whole working set again, from its
+            # private pool (c2: 104 GiB beside an eager pool that an un-synchronised warm-up grows to 200 GiB would not fit in 288)
+            torch.cuda.empty_cache()
+            # a live probe (bench.py) brackets launches with library events that the capture carries (sched.ProbeEvent): the records
+            # of the warm-up's eager launches are dropped, the capture's are re-stamped by every replay
+            if ops.GemmProbe.armed:
+                ops.GemmProbe.records = []
+            if ops.HbmProbe.armed:
+                ops.HbmProbe.records = []
             # amax slots (f16x3 GEMMs) must be zero when their tensor is produced: the captured step cuts its slots from chunks
             # created INSIDE the capture, so their zero fill is a node of the graph and every replay starts from clean slots
             ops.AmaxSlot.reset_chunks()
             n0 = lib().npvp_launch_count()
-            with torch.cuda.graph(self.graph):
-                self.out = predictor_train_step(*self._args, sync=False)
+            if gs is None:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = predictor_train_step(*self._args, sync=False)
+            else:
+                self._record_segments(dev, gs)
             self.launches = lib().npvp_launch_count() - n0          # library launches of one step (what a replay enqueues on the device)
         finally:
             ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code - also after a failed capture)
             ops.WgradStream.enabled = two_streams
+
+    def _record_segments(self, dev, gs):
+        """the data-parallel step as a StepTape (see the class docstring): dp routes every collective to the tape while it records"""
+        from . import dp
+        if gs.expected is None:
+            raise RuntimeError("GraphedTrainStep(grad_sync=...): GradSync has not learned its contribution counts - run at least two "
+                               "eager steps (warmup >= 2) before the capture")
+        tape = StepTape(dev)
+        cs = torch.cuda.Stream(device=dev)
+        cs.wait_stream(torch.cuda.current_stream(dev))
+        prev = dp.set_tape(tape)
+        try:
+            with torch.cuda.stream(cs):
+                tape.begin()
+                self.out = predictor_train_step(*self._args, sync=False, grad_sync=gs)
+                tape.end()
+        except BaseException:
+            tape.abort()
+            raise
+        finally:
+            dp.set_tape(prev)
+        torch.cuda.current_stream(dev).wait_stream(cs)
+        self.tape, self.graph = tape, None
 
     def _poll_range(self):
         """non-blocking: look at the copy issued `poll_every` replays ago; issue the next one"""
@@ -521,7 +651,7 @@ class GraphedTrainStep:
                 if not ops.RangeGuard.fallback:
                     ops.RangeGuard.fallback = True      # the new capture bakes the bf16x6 weight gradients in
                     self.recaptures += 1
-                    self._capture()
+                    self._capture(0)
         if self._flag_event is None and self.replays % self.poll_every == 0:
             flag = ops.RangeGuard._flags.get(dev)
             if flag is not None:
@@ -530,6 +660,8 @@ class GraphedTrainStep:
                 self._flag_event.record()
 
     def __call__(self, past_feats=None, future_feats=None, lr=None):
+        # (asked before anything of this call is enqueued: has the device drained since the last replay?)
+        drained = self.prime and torch.cuda.current_stream(self.past.device).query()
         if lr is not None:
             self.opt.set_lr(lr)
         if past_feats is not None:
@@ -537,7 +669,14 @@ class GraphedTrainStep:
         if future_feats is not None:
             self.fut.copy_(future_feats)
         self._poll_range()                  # (before the replay: a re-capture replaces self.out)
+        if drained:
+            from .sched import prime_clocks
+            if prime_clocks(self.past.device):
+                self.primed += 1
         ops.WeightPlanes.refresh_if_stale()
-        self.graph.replay()
+        if self.tape is not None:
+            self.tape.replay()
+        else:
+            self.graph.replay()
         self.replays += 1
         return self.out

@@ -21,6 +21,7 @@ def pytest_sessionstart(session):
     import tempfile
     config = session.config
     config._npvp_dp_job = None
+    config._npvp_larger_oracle = None
     mark = config.getoption("-m") or ""
     if "gpu" not in mark or "not gpu" in mark or os.environ.get("NPVP_SKIP_DP_TEST"):
         return
@@ -30,11 +31,25 @@ def pytest_sessionstart(session):
             return
     except Exception:
         return
+    # the CPU-oracle side of test_against_oracle_larger (230 s of CPU work) runs BESIDE the GPU tests in a CPU-only child: it imports
+    # torch and the oracle, never touches the GPU, and leaves one .pt per case for the test to pick up (tests/larger_oracle.py)
+    if not os.environ.get("NPVP_SKIP_LARGER_WORKER"):
+        odir = tempfile.mkdtemp(prefix="npvp_larger_oracle_")
+        olog = open(os.path.join(odir, "worker.log"), "w")
+        oproc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "larger_oracle.py"), odir], stdout=olog,
+                                 stderr=subprocess.STDOUT, cwd=ROOT)
+        config._npvp_larger_oracle = (oproc, odir)
     log = tempfile.NamedTemporaryFile(prefix="npvp_dp_jobs_", suffix=".log", delete=False)
     # tools/dp_jobs.py runs the 2-rank jobs one after the other (dp_check, then bench.py --gpus 2): at most 2 + 1 GPU processes
     proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dp_jobs.py"), log.name], stdout=log,
                             stderr=subprocess.STDOUT, cwd=ROOT)
     config._npvp_dp_job = (proc, log.name)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    job = getattr(session.config, "_npvp_larger_oracle", None)
+    if job is not None and job[0].poll() is None:
+        job[0].kill()              # (the exact child this session started)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -52,8 +52,9 @@ def test_c_api_wrappers_cover_the_abi_and_agree_with_ctypes(built):
     L = _lib.lib()
     raw = L._cdll
     missing = [n for n in _lib.SIGNATURES if not hasattr(F, n)]
-    assert missing == ["npvp_last_error", "npvp_stream_create_low_priority"], missing       # (char* / pointer returns stay with ctypes)
-    assert L._fast == len(_lib.SIGNATURES) - 2 and L.npvp_gemm_f32 is F.npvp_gemm_f32
+    # (char* / pointer / float returns stay with ctypes)
+    assert missing == ["npvp_last_error", "npvp_stream_create_low_priority", "npvp_event_create", "npvp_event_elapsed_ms"], missing
+    assert L._fast == len(_lib.SIGNATURES) - 4 and L.npvp_gemm_f32 is F.npvp_gemm_f32
     calls = [("npvp_gemm_f32", (1, 1, 128, 128, 33, None, 36, None, 36, None, 128, None, 0, None, None, None, 0, 0.0, 0, 1, 1, None, 0,
                                 1.0, 0, None, None, 0, None, None, None, None, None, 0.0, 1, 1, 0, None, 0, None)),
              ("npvp_layernorm_fwd", (None, None, None, None, None, None, 4, 500, 1e-5, 0, None, None)),

@@ -39,7 +39,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+class _ImmediateTape:
+    """stands in for trainer.StepTape on CPU (no stream capture there): `cut(action)` runs the action at once and logs it - the step
+    then takes dp's RECORDING code paths (GradSync._launch -> cut -> _launch_now, finish -> one closing action, SyncBatchNorm's
+    statistics as actions) and must give the results of the direct path"""
+
+    def __init__(self):
+        self.log = []
+
+    def cut(self, action):
+        self.log.append(action)
+        action()
+
+
+def _worker(rank, world, port, out, taped=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from npvp_amd import dp
@@ -61,11 +74,18 @@ def _worker(rank, world, port, out):
     x, img = dp.shard_batch(X, rank, world), dp.shard_batch(IMG, rank, world)
     m.train()
     for it in range(2):
+        tape = _ImmediateTape() if (taped and it == 1) else None        # (step 0 teaches GradSync its counts, as the recording's warm-up does)
+        prev = dp.set_tape(tape)
         buf.zero_grad()
         y = m(x, img)
         # loss = mean over the GLOBAL batch -> per-rank mean, gradients averaged by GradSync
         (y ** 2).mean().backward()
         sync.finish()
+        dp.set_tape(prev)
+        if tape is not None:
+            # one SyncBatchNorm forward + one backward collective, every contributing bucket from a hook, ONE closing action
+            assert len(tape.log) >= 2 + 3 + 1, len(tape.log)
+            assert all(b["work"] is None and b["ready"] == 0 for b in sync.buckets)
     if rank == 0:
         torch.save({"flat_g": buf.flat_g.clone(), "rm": m.head[1].running_mean.clone(), "rv": m.head[1].running_var.clone(),
                     "tail": (buf.tail_begin, buf.tail_end), "launched": sync.launched}, out)
@@ -74,13 +94,13 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
-def test_two_rank_gloo_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,taped", [(2, False), (4, False), (2, True)])
+def test_two_rank_gloo_matches_single_process(tmp_path, world, taped):
     """(2 ranks, and 4: the shards of the 8-sample batch are then 2 samples each - SyncBatchNorm's statistics and the bucket means
-    must still be those of the whole batch)"""
+    must still be those of the whole batch; taped: the second step through the recording code paths of a segmented replay)"""
     out = str(tmp_path / "r0.pt")
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, taped), nprocs=world, join=True)
     got = torch.load(out)
     # single process, whole batch
     sys.path.insert(0, ROOT)

@@ -52,6 +52,18 @@ def test_bench_two_ranks(request):
     assert r["config"]["global_batch"] == 16 and "c4" not in r["config"]["parallelism"] and r["config"]["parallelism"] == "dp2"
     assert r["roofline"] is not None and r["roofline"]["achieved"] > 0
     assert abs(r["value"] - 2 * 8 * 20 / (r["ms_per_step"] * 1e-3)) < 1e-2 * r["value"]
+    # the N > 1 record says how many ranks really reduce together, how much of the all-reduce is exposed, and - beside
+    # the weak-scaling `value` - the strong-scaling figure of BASELINE's data-parallel configuration for this GPU count, measured in the
+    # same run against the same global batch on ONE GPU
+    d = r["dp"]
+    assert d["world_size"] == 2 and d["ranks_in_allreduce"] == 2.0 and d["exposed_allreduce_ms_per_step"] >= 0.0
+    ss = r["strong_scaling"]
+    assert ss["n_gpus"] == 2 and ss["ideal"] == 2 and "16 clips over 2 GPUs" in ss["config"]
+    assert ss["frames_per_s"] > 0 and ss["whole_batch_on_1_gpu_frames_per_s"] > 0
+    assert abs(ss["speedup_vs_1_gpu"] - ss["frames_per_s"] / ss["whole_batch_on_1_gpu_frames_per_s"]) < 2e-3
+    assert r["scaling_dp"]["strong_ratio"] == ss["speedup_vs_1_gpu"]
+    # the step of this job was recorded as graph segments (--dp-graph always): the mode trial timed all three candidates
+    assert "'segments'" in log and "'eager_fused'" in log and "graph_segments" in r["config"]["workload"] or "HIP-graph segments" in r["config"]["workload"]
 
 
 def test_rccl_one_rank(request):
@@ -68,9 +80,30 @@ def test_rccl_one_rank(request):
     d = r["dp"]
     assert d["backend"] == "nccl" and d["buckets"] >= 6 and d["last_bucket_mb"] <= 16.0
     # step 1 learns the contribution counts and reduces everything in finish(); from step 2 on every bucket is launched from a hook
-    # (2 warm-up + 3 timed steps + the 2 extra steps of the HBM probe)
+    # (eager trial, the recording's warm-up, then replays: every bucket once per step whoever launches it)
     assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
-    assert d["exposed_allreduce_ms_per_step"] >= 0.0
+    assert d["exposed_allreduce_ms_per_step"] >= 0.0 and d["world_size"] == 1 and d["ranks_in_allreduce"] == 1.0
+    # round 6: the timed steps of this job replay the data-parallel step as graph segments with the collectives (real RCCL calls)
+    # issued eagerly between them - the host's share of a step is a few graph launches (<= 5 ms)
+    assert "HIP-graph segments" in r["config"]["workload"], r["config"]["workload"]
+    assert r["config"]["host_enqueue_ms_per_step"] <= 5.0, r["config"]["host_enqueue_ms_per_step"]
+
+
+def test_segmented_step_equals_eager_bit_for_bit(request):
+    """tools/dp_segments_check.py: the data-parallel step recorded as a chain of HIP-graph segments cut at every collective
+    (trainer.StepTape; bucket all-reduces on the side stream, SyncBatchNorm's statistics forward and backward, the closing wait) and
+    replayed for K - 2 steps == K eager data-parallel steps: parameters, Adam moments, the last gradient, the loss and the step count
+    are EQUAL (torch.equal) - on one real RCCL rank, and on two gloo ranks that share the card (there the collectives really
+    exchange data between the segments)."""
+    rc, read = _jobs(request)
+    for name, ranks in (("seg1", 1), ("seg2", 2)):
+        log = read(name)
+        assert "[dp_segments_check] OK" in log, f"tools/dp_segments_check.py ({name}) failed (rc={rc}):\n{log[-3000:]}"
+        assert log.count("'params': True, 'adam_m': True, 'adam_v': True, 'grad': True, 'loss': True, 'step_count': True") == ranks, log[-2000:]
+    one = read("seg1")
+    assert "backend=nccl" in one
+    host = float(one.split("host_ms_min=")[1].split()[0])
+    assert host <= 5.0, f"a replayed data-parallel step costs the host {host} ms"
 
 
 def test_library_exchange_one_rank(request):

@@ -53,7 +53,7 @@ def steps(m, batches, gsync, eval_between=False):
     lr > 0 AdamW's first updates are ~lr*sign(g) and amplify rounding-level gradient differences.  The first step teaches
     GradSync the per-parameter contribution counts (everything reduced in finish()), the next ones take the overlapped path."""
     opt = npvp_amd.FlatAdamW(m, lr=0.0, clip_module=m.transformer)
-    gs = dp.GradSync(opt.buf, bucket_bytes=8 << 20) if gsync else None
+    gs = dp.GradSync(opt, bucket_bytes=8 << 20) if gsync else None
     out = None
     for i, (p, f, e, split) in enumerate(batches):
         m.evt_prior.eps_fn = m.evt_posterior.eps_fn = (lambda shape, e=e: e)

@@ -6,6 +6,9 @@ tests/conftest.py before the test process touches the GPU; this wrapper itself n
   3. bench.py --gpus 1 on RCCL - one rank, backend nccl, NPVP_DP_FORCE=1: the data-parallel path on real RCCL (see below)
   4. the same with NPVP_DP_COMM=c - the gradient buckets through the library's own npvp_dp_* exchange
   5. tools/dp_check.py with 4 ranks on the card
+  6. tools/dp_segments_check.py - the data-parallel step replayed as HIP-graph segments with the collectives issued eagerly between
+                                them (trainer.StepTape) against the eager data-parallel step, bit for bit: on one RCCL rank and on two
+                                gloo ranks sharing the card
 Each job's output goes to <log>.<name>; the wrapper's exit code is the first failure's."""
 import os, subprocess, sys
 
@@ -15,23 +18,28 @@ env = dict(os.environ, NPVP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
 run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
 jobs = [("dp_check", run + ["--master-port", "29531", os.path.join(ROOT, "tools", "dp_check.py")]),
         ("bench2", run + ["--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "3",
-                          "--warmup", "1", "--no-secondary", "--dp-fused-trial", "always"])]
+                          "--warmup", "1", "--dp-fused-trial", "always", "--dp-graph", "always", "--trial-steps", "2", "--no-cpu-baseline"])]
 # 3. RCCL itself, as far as one GPU allows: ONE rank, backend nccl, NPVP_DP_FORCE=1 = the whole data-parallel code path on a group
 #    of one (ProcessGroupNCCL init, model broadcast, SyncBatchNorm2d's all-reduces on their own communicator, GradSync's bucket
 #    all_reduce(async_op=True) on the side stream + work.wait() + finish()) inside the benchmark's own step
 run1 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
 jobs.append(("rccl1", run1 + ["--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
-                              "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]))
+                              "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--dp-graph", "always", "--trial-steps", "3"]))
 # 4. the same one-rank RCCL step with the gradient buckets on the LIBRARY's exchange (NPVP_DP_COMM=c: npvp_dp_unique_id / npvp_dp_init /
 #    npvp_dp_allreduce_async / npvp_dp_wait of include/npvp_hip.h) instead of ProcessGroupNCCL's all_reduce
 #    (and with the mode trial's second leg forced - one launch per layer backward beside the gradient stream: GradSync must see the
 #    same per-parameter contribution counts in both legs)
 jobs.append(("rccl1c", run1 + ["--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "3",
-                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--dp-fused-trial", "always"]))
+                               "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--dp-fused-trial", "always", "--dp-graph", "never",
+                               "--trial-steps", "3"]))
 # 5. tools/dp_check.py once more with FOUR ranks on the card (gloo on device tensors; 8-sample global batch, 2 per rank)
 run4 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1"]
 jobs.append(("dp_check4", run4 + ["--master-port", "29535", os.path.join(ROOT, "tools", "dp_check.py")]))
-envs = {"dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts an activation of the 8-clip batch on a ReLU kink: tools/dp_check.py)
+# 6. the segmented replay of the data-parallel step == the eager data-parallel step, bit for bit (parameters, Adam state, gradients, loss)
+jobs.append(("seg1", run1 + ["--master-port", "29536", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
+jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
+envs = {"seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"), "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
+        "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts an activation of the 8-clip batch on a ReLU kink: tools/dp_check.py)
         "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
 rc = 0
