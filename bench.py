@@ -42,6 +42,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# --graph-packets fast keeps the ROCm runtime's packet-capture replay path (NPVP_GRAPH_PACKET_CAPTURE=1; npvp_amd/__init__.py switches it off
+# by default because it computes wrong steps - `replay_check` in this benchmark's record shows it: profiles/r06_graph_alloc_hazard.txt).
+# The choice has to be in the environment before the HIP runtime initialises, hence here.
+if "--graph-packets" in sys.argv and sys.argv[sys.argv.index("--graph-packets") + 1:][:1] == ["fast"]:
+    os.environ["NPVP_GRAPH_PACKET_CAPTURE"] = "1"
+
 import torch
 import torch.distributed as dist
 
@@ -152,7 +158,7 @@ def run_workload(key, *a, **kw):
         return _run_workload(key, *a, **kw)
 
 
-def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None, mode="eager"):
+def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=None, clips=None, mode="eager", check=False):
     """Build the workload's model / optimiser / synthetic batch, run `warmup` untimed and `steps` timed steps
     (barrier + synchronize on both sides, MAX over ranks), free everything.  -> result dict.  world = 1 inside a multi-rank job =
     a SOLO run of the calling rank (no collectives, no barrier): the one-GPU denominators of `scaling_dp`.
@@ -219,8 +225,18 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         # weight-gradient launch); --probe-all also brackets the weight-gradient and small-shape launches (their event pairs cost ~1 %)
         ops.GemmProbe.arm(None if args.probe_all else {2, 4, 5, 7, 8})
 
+    check_state = {}
+    fence_t = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def state_tensors():
+        return [opt.flat_p, opt.m, opt.v, opt.hyper, opt.ctx.rng.seed_tensor(dev)] + [b for b in model.buffers() if b.is_cuda]
+
     def graphed():
         opt.set_lr(P["predictor_lr"])
+        if check and not check_state:
+            # buffers of `replay_check` (below), allocated BEFORE the capture: nothing may be allocated between replays
+            check_state["snap"] = [torch.empty_like(t) for t in state_tensors()]
+            check_state["result"] = torch.empty_like(opt.flat_p)
         if probe:
             # the capture carries the probes: library events recorded inside it are external event-record nodes that every replay
             # stamps again (sched.ProbeEvent), so the roofline figures of a replayed step are measured IN the timed replays - read after
@@ -359,7 +375,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     def fence():
         torch.cuda.synchronize()
         if dp_on:
-            dist.barrier()
+            dist.all_reduce(fence_t)        # (a barrier on a tensor that exists since before any capture: dist.barrier() allocates one)
         torch.cuda.synchronize()
 
     # Warm-up WITHOUT a synchronisation per step: the host must run ahead of the GPU here as it does in the timed region.  Blocks that
@@ -375,7 +391,10 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     #  and retry - the pool that the warm-up had just grown: the timed steps then grew it again with fresh allocations, each of
     #  which can block for seconds on a box whose memory an earlier process has just released; profiles/r05_back_to_back.txt)
     free_b, _ = torch.cuda.mem_get_info(dev)
-    slack = torch.empty(max(1, min(int(0.2 * torch.cuda.memory_reserved(dev)), free_b - (8 << 30))), dtype=torch.uint8, device=dev)
+    # (an eager step's business only: a replayed step allocates nothing - and must not find freshly mapped memory being written
+    #  between its replays, npvp_amd/__init__.py)
+    slack_n = 1 if used in ("graph", "graph_segments") else max(1, min(int(0.2 * torch.cuda.memory_reserved(dev)), free_b - (8 << 30)))
+    slack = torch.empty(slack_n, dtype=torch.uint8, device=dev) if slack_n > 1 else torch.empty(0, dtype=torch.uint8, device=dev)
     # ... and touched before it goes back to the cache (its first use happens here, not in a timed step)
     t_sl = time.perf_counter()
     slack.zero_()
@@ -389,6 +408,9 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     replayed = used in ("graph", "graph_segments")
     if probe and not replayed:              # (a replayed step carries its probes since its capture)
         arm_probes()
+    if check and replayed and check_state:
+        for a_, b_ in zip(check_state["snap"], state_tensors()):      # (`replay_check`: the state the timed replays start from)
+            a_.copy_(b_)
     fence()
     L0 = npvp_amd._lib.lib().npvp_launch_count()
     t0 = time.perf_counter()
@@ -407,6 +429,8 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         launches = gstep.launches
     fence()
     dt = time.perf_counter() - t0
+    if check and replayed and check_state:
+        check_state["result"].copy_(opt.flat_p)
     log(f"[{key}] after the timed steps: reserved {torch.cuda.memory_reserved(dev) / 2 ** 30:.1f} GiB, allocator retries "
         f"{torch.cuda.memory_stats(dev).get('num_alloc_retries', 0)}")
     ops.GemmProbe.disarm()
@@ -492,13 +516,38 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
                     roof[tag] = {"value": u["mfma_util_step"], "vs_unprofiled_step": u.get("util_vs_unprofiled_step"),
                                  "clock_ghz": u["effective_clock_ghz"], "source": f"profiles/r05_mfma_util_{wk}.md"}
 
+    replay_check = None
+    if check and replayed and check_state:
+        # Did the TIMED replays compute what eager steps compute?  The state the timed region started from (saved above) is put
+        # back and the same K steps are taken eagerly (two streams, every launch enqueued by the host): same batch, same learning
+        # rates, same dropout stream (the seed lives in device memory and is part of the state).
+        st, snap, pa = state_tensors(), check_state["snap"], check_state["result"]
+        for a_, b_ in zip(snap, st):
+            b_.copy_(a_)
+        ops.WeightPlanes.refresh_all(opt.flat_p)          # (the planes mirror the parameters that were just put back)
+        if gsync is not None:
+            gsync.relearn()
+        for i in range(steps):
+            out_e = eager_step(warmup + i)
+        fence()
+        loss_e = float(out_e["loss"])
+        rel = float((opt.flat_p - pa).norm() / pa.norm())
+        upd = float((pa - snap[0]).norm() / pa.norm())
+        replay_check = {"steps": steps, "params_rel_l2_replay_vs_eager": rel, "update_rel_l2_over_the_steps": upd,
+                        "loss_replay": loss, "loss_eager": loss_e, "ok": bool(rel < 5e-5 and abs(loss - loss_e) <= 2e-4 * abs(loss_e)),
+                        "packet_capture": npvp_amd.graph_packet_capture(),
+                        "what": "the timed replays against the same steps taken eagerly from the same saved state (NPVP-D: equal to the "
+                                "bit; NPVP-S: the two runs draw their reparameterisation noise from different positions of torch's generator)"}
+        log(f"[{key}] replay check: " + json.dumps(replay_check))
+        check_state.clear()
+
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30
     log(f"[{key}] peak device memory {peak_gb:.1f} GiB")
     torch.cuda.reset_peak_memory_stats(dev)
     events = ops.RangeGuard.poll(dev)           # weight-gradient launches that met a feature 2^18 below its tensor's bound (0 expected)
     res = {"key": key, "name": name, "B": B, "To": To, "Tp": Tp, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "peak_gb": peak_gb,
            "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "roof_hbm": roof_hbm, "steps": steps,
-           "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms}
+           "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms, "replay_check": replay_check}
     if gsync is not None:
         # how many ranks REALLY reduce together: the mean over the ranks of (rank + 1), through the very exchange the gradient buckets
         # take (ProcessGroup or the library's npvp_dp_*), must be (world + 1) / 2 - one number the driver can check against --gpus
@@ -554,6 +603,10 @@ def main():
                     help="data parallel: when to record the step as HIP-graph segments with the collectives issued eagerly between them "
                          "(trainer.StepTape): auto = time it against the eager step and take the replay unless eager is faster (by > 5 %% "
                          "when host bound); always = take it; never = eager only")
+    ap.add_argument("--graph-packets", default="safe", choices=["fast", "safe"],
+                    help="how the ROCm runtime replays a HIP graph: safe (default) = DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the package's default; "
+                         "fast = the runtime's packet-capture path - quicker replays that compute WRONG steps on ROCm 7.2 (measurement "
+                         "only: `replay_check` in the record says so)")
     ap.add_argument("--graph-streams", type=int, default=1, choices=[1, 2],
                     help="streams inside a captured step: 1 (default: one chain of nodes, what replays fast) or 2 (measurement only)")
     ap.add_argument("--mode", default="auto", choices=["eager", "graph", "auto"],
@@ -567,6 +620,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
     args = ap.parse_args()
 
+    import npvp_amd
     from npvp_amd import dp, ops
 
     ops.set_gemm_precision(args.gemm)
@@ -577,7 +631,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    main_res = run_workload(args.workload, args.steps, args.warmup, args, rank, world, dev, probe=not args.no_probe, mode=args.mode)
+    main_res = run_workload(args.workload, args.steps, args.warmup, args, rank, world, dev, probe=not args.no_probe, mode=args.mode, check=True)
 
     secondary, detail, scaling_dp, modes, strong = {}, {}, None, {}, None
     sec_ok = not args.no_secondary and not args.graph and args.flavour == "predictor"
@@ -589,7 +643,7 @@ def main():
             secondary[name] = [round(r["ms"], 2), round(r["frames_per_s"], 1), round(r["host_ms"], 1), round(r["launches"]),
                                round(r["flops_step"] / (r["ms"] * 1e-3) / 1e12, 1)]
             if r["mode"] != "eager":
-                modes[name] = r["mode"]
+                modes[name] = r["mode"] + ("" if r.get("replay_check") is None else (" (replay_check ok)" if r["replay_check"]["ok"] else " (replay_check FAILED)"))
             detail[name] = {"workload": r["name"] + (" - FULL step from pixels through the frozen autoencoder" if flav == "full" else
                                                      " - predictor-only step") + (" [rank 0 alone]" if solo else ""),
                             "clips_per_gpu": r["B"], "To": r["To"], "Tp": r["Tp"], "frames_per_s": round(r["frames_per_s"], 2),
@@ -604,7 +658,7 @@ def main():
             for name, k, flav in [("c2p", "c2p", None), ("c1", "c1", None), ("c0", "c0", None), ("c3s", "c3", None), ("c4s", "c4", None),
                                   ("c3full", "c3full", None), ("c4full", "c4full", None), ("full64", "c1", "full"), ("full128", "c4", "full")]:
                 note(name, run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False, flavour=flav,
-                                        mode="eager" if flav == "full" else "auto"), flav)
+                                        mode="eager" if flav == "full" else "auto", check=True), flav)
             # what N GPUs can at best make of these shards: N x shard / whole batch on one GPU (the step is not linear in the clip
             # count - an 8-clip shard is bound by kernel count)
             scaling_dp = {"c3_on_4_upper_bound": round(4 * secondary["c3s"][1] / secondary["c3full"][1], 2),
@@ -616,7 +670,7 @@ def main():
             # barrier below - the same configuration's whole global batch and its 8-clip shard on ONE GPU
             k = {4: "c3"}.get(world, "c4")
             # (the primary run IS that configuration when the caller asked for it - the 2-rank rehearsal does: not run twice)
-            rd = main_res if args.workload == k else run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False)
+            rd = main_res if args.workload == k else run_workload(k, sec_steps, sec_warm, args, rank, world, dev, probe=False, check=True)
             note(k, rd)
             if rank == 0:
                 rs = run_workload(k, sec_steps, sec_warm, args, 0, 1, dev, probe=False)
@@ -662,6 +716,7 @@ def main():
                "roofline": r["roof"], "roofline_hbm": r["roof_hbm"], "secondary": secondary or None,
                "secondary_fields": ["ms_per_step", "frames_per_s", "host_enqueue_ms", "library_launches_per_step", "whole_step_tflops"] if secondary else None,
                "secondary_mode": modes or None, "scaling_dp": scaling_dp, "strong_scaling": strong, "dp": r.get("dp"),
+               "replay_check": r.get("replay_check"), "graph_packet_capture": npvp_amd.graph_packet_capture(),
                "host": dict(zip(("cpu", "cores"), host_cpu()))}
         if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")

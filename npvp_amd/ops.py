@@ -157,6 +157,7 @@ class WeightPlanes:
     enabled = True
     _owners = []            # weak references to tensors that carry a `_npvp_planes` store
     _tables = None          # [(fmt, device table, amax table or None, [entries])] - rebuilt when `_dirty`
+    _group_tensors = {}     # (storage address, fmt, device) -> (entry identities, device table, amax table): see refresh_all
     _dirty = True
     _gen = object()         # identity token of the current generation of entries
 
@@ -272,19 +273,34 @@ class WeightPlanes:
                 if ent.w.is_cuda:       # (grouped by STORAGE: the weights of one trainer are views of its flat parameter buffer)
                     groups.setdefault((ent.w.untyped_storage().data_ptr(), ent.fmt, ent.w.device), []).append(ent)
             cls._tables = []
-            for (own_id, fmt, dev), ents in groups.items():
-                amax_t = None
-                if fmt == 6:             # one contiguous slot table per device: zeroed by ONE memset in the batched call
-                    amax_t = torch.zeros(len(ents), AmaxSlot.FLOATS, dtype=torch.float32, device=dev)
-                    for i, ent in enumerate(ents):
-                        ent.amax_t = amax_t
-                        ent.amax.ptr, ent.amax.chunk = amax_t.data_ptr() + AmaxSlot.BYTES * i, amax_t
-                rows = []
-                for ent in ents:
-                    N, K = ent.w.shape
-                    r = [ent.w.data_ptr(), ent.w.stride(0), N, K, ent.planes[0].data_ptr(), ent.planes[1].data_ptr()]
-                    rows.append(r + [ent.amax.ptr, 0] if fmt == 6 else r)
-                cls._tables.append((fmt, torch.tensor(rows, dtype=torch.int64).to(dev), amax_t, ents, own_id))
+            kept = {}
+            for gkey, ents in groups.items():
+                own_id, fmt, dev = gkey
+                # A group whose entries are the ones it had at the last rebuild KEEPS its device table and its amax slots: the rebuild
+                # was caused by something else (another model's weights registered or garbage collected), and a captured HIP graph of
+                # this trainer's step has the addresses of both baked in - a fresh pair would leave the graph re-splitting into, and
+                # its GEMMs reading scales from, memory that the allocator hands to the next caller (round 6: a replayed step went
+                # wrong as soon as anything was allocated and written between two replays).
+                ids = tuple(id(e) for e in ents)
+                old = cls._group_tensors.get(gkey)
+                if old is not None and old[0] == ids and (fmt != 6 or all(e.amax_t is old[2] for e in ents)):
+                    table, amax_t = old[1], old[2]
+                else:
+                    amax_t = None
+                    if fmt == 6:             # one contiguous slot table per device: zeroed by ONE memset in the batched call
+                        amax_t = torch.zeros(len(ents), AmaxSlot.FLOATS, dtype=torch.float32, device=dev)
+                        for i, ent in enumerate(ents):
+                            ent.amax_t = amax_t
+                            ent.amax.ptr, ent.amax.chunk = amax_t.data_ptr() + AmaxSlot.BYTES * i, amax_t
+                    rows = []
+                    for ent in ents:
+                        N, K = ent.w.shape
+                        r = [ent.w.data_ptr(), ent.w.stride(0), N, K, ent.planes[0].data_ptr(), ent.planes[1].data_ptr()]
+                        rows.append(r + [ent.amax.ptr, 0] if fmt == 6 else r)
+                    table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                kept[gkey] = (ids, table, amax_t)
+                cls._tables.append((fmt, table, amax_t, ents, own_id))
+            cls._group_tensors = kept
             cls._dirty = False
         only = None if owner is None else owner.untyped_storage().data_ptr()
         for fmt, table, amax_t, ents, own_id in cls._tables:

@@ -247,21 +247,29 @@ def prime_clocks(dev, gib=None):
     firmware's clock decision for the busy period that follows a long pure-memory phase, not a cache or allocator effect.  The
     memset is ~5 ms of device time once per busy period; the buffer comes from (and returns to) the caching allocator.
     -> bytes zeroed (0: not enough free memory, nothing done)"""
+    buf = prime_buffer(dev, gib)
+    if buf is None:
+        return 0
+    buf.zero_()                             # (a tensor that owns its whole storage: ONE hipMemsetAsync)
+    return buf.numel()
+
+
+def prime_buffer(dev, gib=None):
+    """the buffer prime_clocks zeroes (None: priming switched off, or not enough free memory - it is optional).  trainer.GraphedTrainStep
+    allocates it BEFORE its capture and keeps it: device memory mapped after a graph's instantiation must not be touched between
+    its replays (trainer.GraphedTrainStep._device_allocs)."""
     gib = PRIME_GIB if gib is None else gib
     if gib <= 0:
-        return 0
+        return None
     free_b, _ = torch.cuda.mem_get_info(dev)
     cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
     n = int(min(gib * (1 << 30), max(free_b - (8 << 30), cached // 2)))
-    if n < (8 << 30):
-        return 0
+    if n < (12 << 30):                      # (below ~12 GiB the memset does not move the clock: profiles/r06_clock_priming.txt)
+        return None
     try:
-        buf = torch.empty(n, dtype=torch.uint8, device=dev)
-    except RuntimeError:                    # (out of memory after all: priming is optional)
-        return 0
-    buf.zero_()                             # (a tensor that owns its whole storage: ONE hipMemsetAsync)
-    del buf
-    return n
+        return torch.empty(n, dtype=torch.uint8, device=dev)
+    except RuntimeError:
+        return None
 
 
 # --------------------------------------------------------------------------- per-trainer state

@@ -9,6 +9,7 @@ npvp_adamw_step); the flat gradient buffer is also what the data-parallel all-re
 (npvp_amd.dp) slice, so gradients are never copied.
 """
 import math
+import os
 
 import torch
 import yaml
@@ -539,7 +540,7 @@ class GraphedTrainStep:
     (at least two eager steps, in the single-stream schedule the capture uses) teaches GradSync the contribution counts."""
 
     def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3,
-                 single_stream=True, poll_every=32, grad_sync=None, prime=True):
+                 single_stream=True, poll_every=32, grad_sync=None, prime=None):
         """warmup: eager optimiser steps taken on (past_feats, future_feats) BEFORE the capture - they are real steps (parameters,
         Adam state, step count and dropout seed advance `warmup` times); pass warmup=0 when the caller has already stepped the model
         eagerly on this device (then nothing but the capture itself happens, and the capture executes nothing)."""
@@ -554,7 +555,12 @@ class GraphedTrainStep:
         # prime: a replay that finds the stream DRAINED (the first one, or the first after the caller synchronised) is preceded by
         # sched.prime_clocks - one long memset after which the device runs the busy period that follows at its higher engine clock
         # (c2: 237 -> 214 ms per replayed step).  A loop that keeps the queue fed is primed once.
+        if prime is None:                   # (measured only on the packet-capture replay path, which the package switches off by default)
+            prime = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"
         self.prime, self.primed = bool(prime), 0
+        self._prime_buf = None
+        self.remapped = 0                   # re-captures because the allocator mapped new device memory (see _device_allocs)
+        self._watch_allocs = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"      # (only the packet-capture path needs it)
         self.single_stream, self.poll_every, self.warmup = single_stream, max(1, int(poll_every)), warmup
         self.replays = self.recaptures = self.range_events = 0
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -589,6 +595,11 @@ class GraphedTrainStep:
             # the eager steps' cached blocks go back to the device: the capture allocates the step's whole working set again, from its
             # private pool (c2: 104 GiB beside an eager pool that an un-synchronised warm-up grows to 200 GiB would not fit in 288)
             torch.cuda.empty_cache()
+            if self.prime and self._prime_buf is None:
+                # the buffer of sched.prime_clocks, allocated BEFORE the capture and kept: memory mapped after the graph's
+                # instantiation would force a re-capture (see _device_allocs)
+                from .sched import prime_buffer
+                self._prime_buf = prime_buffer(dev)
             # a live probe (bench.py) brackets launches with library events that the capture carries (sched.ProbeEvent): the records
             # of the warm-up's eager launches are dropped, the capture's are re-stamped by every replay
             if ops.GemmProbe.armed:
@@ -606,9 +617,24 @@ class GraphedTrainStep:
             else:
                 self._record_segments(dev, gs)
             self.launches = lib().npvp_launch_count() - n0          # library launches of one step (what a replay enqueues on the device)
+            # the graph has the addresses of the weight-plane tables and amax slots baked in: they live as long as the graph does
+            self._plane_tables = list(ops.WeightPlanes._tables or [])
+            # ... and so do the probe events whose record nodes the capture carries (a destroyed event under a replay is a crash)
+            self._probe_events = (list(ops.GemmProbe.records) if ops.GemmProbe.armed else []) + (list(ops.HbmProbe.records) if ops.HbmProbe.armed else [])
+            self._allocs_at_capture = self._device_allocs(dev)
         finally:
             ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code - also after a failed capture)
             ops.WgradStream.enabled = two_streams
+
+    @staticmethod
+    def _device_allocs(dev):
+        """how many device segments the caching allocator has mapped so far (a monotonic counter).  Why it is watched (round 6,
+        profiles/r06_graph_remap.txt): on ROCm 7.2 a graph that replays through the runtime's packet-capture path - the fast one -
+        computes ONE wrong step if, since it was instantiated, new device memory was mapped (hipMalloc) and a kernel touched it:
+        content-independent, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (slower replays), gone when the step is captured again
+        after the mapping.  So a replay that finds the counter moved captures the step again first (`remapped` counts them) - in a
+        steady training loop the allocator serves everything from its cache and the counter stands still."""
+        return torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
 
     def _record_segments(self, dev, gs):
         """the data-parallel step as a StepTape (see the class docstring): dp routes every collective to the tape while it records"""
@@ -669,10 +695,13 @@ class GraphedTrainStep:
         if future_feats is not None:
             self.fut.copy_(future_feats)
         self._poll_range()                  # (before the replay: a re-capture replaces self.out)
-        if drained:
-            from .sched import prime_clocks
-            if prime_clocks(self.past.device):
-                self.primed += 1
+        if self._watch_allocs and self._device_allocs(self.past.device) != self._allocs_at_capture:
+            torch.cuda.synchronize(self.past.device)
+            self.remapped += 1
+            self._capture(0)
+        if drained and self._prime_buf is not None:
+            self._prime_buf.zero_()         # (sched.prime_clocks: ONE long memset in front of a busy period that starts from idle)
+            self.primed += 1
         ops.WeightPlanes.refresh_if_stale()
         if self.tape is not None:
             self.tape.replay()

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import npvp_amd  # noqa: E402,F401  (before anything initialises the HIP runtime: the package picks the runtime's graph-replay mode at import)
 
 
 def pytest_configure(config):
@@ -53,7 +54,12 @@ def pytest_sessionfinish(session, exitstatus):
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for."""
+    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for.  The tests that only COLLECT the
+    multi-process jobs started at session start (tests/test_dp_gpu.py) run last: the jobs share the card with the session's own
+    tests, and a collector that runs early just waits for them."""
+    late = [it for it in items if it.fspath.basename == "test_dp_gpu.py"]
+    if late:
+        items[:] = [it for it in items if it.fspath.basename != "test_dp_gpu.py"] + late
     try:
         import torch
         has_gpu = torch.cuda.is_available()

@@ -84,9 +84,9 @@ def test_rccl_one_rank(request):
     assert d["allreduces_launched"] % d["buckets"] == 0 and d["allreduces_launched"] >= d["buckets"] * 5, d
     assert d["exposed_allreduce_ms_per_step"] >= 0.0 and d["world_size"] == 1 and d["ranks_in_allreduce"] == 1.0
     # round 6: the timed steps of this job replay the data-parallel step as graph segments with the collectives (real RCCL calls)
-    # issued eagerly between them - the host's share of a step is a few graph launches (<= 5 ms)
+    # issued eagerly between them - the host's share of a step is a few graph launches (a quarter of the step, not all of it)
     assert "HIP-graph segments" in r["config"]["workload"], r["config"]["workload"]
-    assert r["config"]["host_enqueue_ms_per_step"] <= 5.0, r["config"]["host_enqueue_ms_per_step"]
+    assert r["config"]["host_enqueue_ms_per_step"] <= 12.0, r["config"]["host_enqueue_ms_per_step"]     # (eager: 25 - 35 ms)
 
 
 def test_segmented_step_equals_eager_bit_for_bit(request):
@@ -103,7 +103,20 @@ def test_segmented_step_equals_eager_bit_for_bit(request):
     one = read("seg1")
     assert "backend=nccl" in one
     host = float(one.split("host_ms_min=")[1].split()[0])
-    assert host <= 5.0, f"a replayed data-parallel step costs the host {host} ms"
+    # (the runtime's safe replay mode enqueues a graph's ~1 000 packets from the host: ~3 ms per step + ~0.15 ms per segment; with the
+    #  packet-capture path this was 3 ms in all - and wrong results.  Either way a fraction of the 31 ms the device needs)
+    assert host <= 10.0, f"a replayed data-parallel step costs the host {host} ms"
+
+
+def test_replayed_step_survives_caller_allocations(request):
+    """tools/graph_alloc_hazard.py in the package's default runtime mode: a caller that allocates device memory after the capture and
+    writes it between two replays (a 16-float tensor, a fresh 1 MiB buffer, `loss.clone()` per step) leaves the replayed run ON the
+    eager trajectory.  (With the ROCm runtime's packet-capture path - NPVP_GRAPH_PACKET_CAPTURE=1 - the same program computes one
+    wrong step: DESIGN 7, profiles/r06_graph_alloc_hazard.txt; the package switches that path off at import.)"""
+    rc, read = _jobs(request)
+    for i in range(3):
+        log = read(f"hazard{i}")
+        assert "[graph_alloc_hazard] packet capture off" in log and log.rstrip().endswith("OK"), log[-1500:]
 
 
 def test_library_exchange_one_rank(request):

@@ -38,7 +38,13 @@ jobs.append(("dp_check4", run4 + ["--master-port", "29535", os.path.join(ROOT, "
 # 6. the segmented replay of the data-parallel step == the eager data-parallel step, bit for bit (parameters, Adam state, gradients, loss)
 jobs.append(("seg1", run1 + ["--master-port", "29536", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
-envs = {"seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"), "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
+# 7. the runtime's graph packet-capture hazard (npvp_amd/__init__.py): in the package's default mode a caller that allocates and writes
+#    device memory between two replays must NOT disturb the replayed trajectory (tools/graph_alloc_hazard.py, three variants)
+for i, b in enumerate(("tiny", "fill:0.001", "clone")):
+    jobs.append((f"hazard{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
+envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill:0.001"), "hazard2": dict(env, BETWEEN="clone"),
+        "seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
+        "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
         "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts an activation of the 8-clip batch on a ReLU kink: tools/dp_check.py)
         "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
