@@ -145,6 +145,13 @@ def cpu_baseline(primary):
                              f"({dt0:.2f} s/step)"}}
 
 
+def library_hash():
+    """sha256 of the loaded libnpvp_hip.so (what the committed counter passes of profiles/ are tied to)"""
+    import hashlib
+    from npvp_amd._lib import LIB_PATH
+    return hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -486,20 +493,38 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
             n, pms, pfl, pby = crit[kid]
             kname = ops.GemmProbe.KERNELS[kid]
             ach = pfl / (pms * 1e-3) / 1e12
-            traffic = None
-            tj = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r_}_hbm_traffic_{key}.json") for r_ in (5, 4, 3)) if os.path.exists(q)), "")
-            if os.path.exists(tj) and not full:
-                # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command (separate
-                # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 rule): profiles/r0N_hbm_traffic_<key>.* (newest round)
-                ent = json.load(open(tj)).get("pooled", {}).get(kname)
-                traffic = round(ent["hbm_bytes_per_dispatch"]) if ent else None
+            # Figures that cannot be measured inside the timed process (PMC passes serialise the dispatches): read from the committed
+            # counter passes of this very command - and ONLY when those passes ran on the library that is loaded now (the profile
+            # records its sha256).  A kernel change without new passes shows as null + "stale".
+            lib_hash = library_hash()
+            traffic, traffic_src = None, None
+
+            def committed(pattern):
+                """-> (record, file) of the newest round's profile whose library hash is the loaded library's, else (None, newest file)"""
+                newest = None
+                for r_ in range(9, 2, -1):
+                    q = os.path.join(ROOT, "profiles", pattern.format(r=r_))
+                    if os.path.exists(q):
+                        newest = newest or q
+                        rec = json.load(open(q))
+                        if rec.get("lib_sha256") == lib_hash:
+                            return rec, q
+                return None, newest
+
+            if not full:
+                rec, q = committed("r0{r}_hbm_traffic_" + key + ".json")
+                if rec is not None:
+                    ent = rec.get("pooled", {}).get(kname)
+                    traffic, traffic_src = (round(ent["hbm_bytes_per_dispatch"]) if ent else None), os.path.relpath(q, ROOT)
+                elif q is not None:
+                    traffic_src = {"stale": True, "file": os.path.relpath(q, ROOT), "why": "measured on another build of libnpvp_hip.so"}
             f16 = kid in (5, 6, 7, 8)
             mfmas = 1 if kid == 0 else (3 if f16 else 6)
             roof = {"bound": "mfma", "kernel": kname + " (forward + dgrad launches)",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "mfma_per_product": mfmas,
                     "mfma_pipe_busy_frac": round(mfmas * ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(pby / n), "launches": n,
                     "avg_launch_us": round(1000.0 * pms / n, 2), "by_layout_and_kernel_id": groups,
                     "note": f"achieved = algorithmic 2MNK flops / event-pair time of every launch; {mfmas} MFMAs per fp32-grade product, "
                             f"so frac <= 1/{mfmas} by construction",
@@ -510,11 +535,14 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
             # steps / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8), from a committed rocprofv3 --pmc pass over this very command
             # (tools/profile_r05.sh, tools/rocpd_mfma_util.py; counter passes cannot run inside the timed process - like `traffic`)
             for tag, wk in (("mfma_util_step", key), ("mfma_util_step_c2p", "c2p")):
-                uj = os.path.join(ROOT, "profiles", f"r05_mfma_util_{wk}.json")
-                if os.path.exists(uj) and not full and (tag == "mfma_util_step" or key == "c2"):
-                    u = json.load(open(uj))
+                if full or not (tag == "mfma_util_step" or key == "c2"):
+                    continue
+                u, q = committed("r0{r}_mfma_util_" + wk + ".json")
+                if u is not None:
                     roof[tag] = {"value": u["mfma_util_step"], "vs_unprofiled_step": u.get("util_vs_unprofiled_step"),
-                                 "clock_ghz": u["effective_clock_ghz"], "source": f"profiles/r05_mfma_util_{wk}.md"}
+                                 "clock_ghz": u["effective_clock_ghz"], "source": os.path.relpath(q, ROOT).replace(".json", ".md")}
+                elif q is not None:
+                    roof[tag] = {"value": None, "stale": True, "file": os.path.relpath(q, ROOT), "why": "measured on another build of libnpvp_hip.so"}
 
     replay_check = None
     if check and replayed and check_state:

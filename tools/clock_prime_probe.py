@@ -4,7 +4,10 @@ sclk ~2 270 MHz instead of ~1 970 MHz, the MFMA GEMMs run 19 % faster, and the s
 (60 replays = 13 s checked).  This tool replays a workload's graph in event-timed loops after different primers and samples the
 clocks beside it (tools/clock_watch.sh), so that the effect and its trigger are on record:
 
-    bash tools/clock_watch.sh gpurun_out/r06/clocks.txt -- python tools/clock_prime_probe.py [workload] [eager]
+    NPVP_GRAPH_PACKET_CAPTURE=1 bash tools/clock_watch.sh gpurun_out/r06/clocks.txt -- python tools/clock_prime_probe.py [workload] [eager]
+
+(the effect was measured on the runtime's packet-capture replay path, which `import npvp_amd` switches off by default because its
+arithmetic is broken - profiles/r06_graph_alloc_hazard.txt; with the safe path the primer does nothing)
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -14,8 +14,10 @@ reductions off).  Round 5, what they were written for: with 8 clips, clip seed 1
 differs from the single-process one by 2.9e-4 in nearly EVERY parameter - identically for 2 and 4 ranks, identically whichever way
 the reference is scheduled, and not at all (8e-7) for clip seeds 12, 13, 21, 31 on the same shapes: one activation of that batch
 sits within rounding distance of a ReLU kink and lands on different sides in the two summation orders of the BatchNorm statistics
-(the parity tests search their seeds for a margin for the same reason, tests/test_hip_golden.py _evt_relu_margin).  The 4-rank job
-of `pytest -m gpu` therefore runs with DP_CHECK_SEED=12.
+(the parity tests search their seeds for a margin for the same reason, tests/larger_oracle.py evt_relu_margin).  Round 6 DEMONSTRATED it
+(DP_CHECK_MARGIN=1, profiles/r06_dp_check_relu_kink.txt): with seed 11 exactly one unit of rank 0's shard (|pre-activation| 2.4e-07) is
+rectified in the data-parallel run and not in the single-process run; with seeds 12, 13, 21 no ReLU decision differs and the gradients
+agree to 8e-07.  The 4-rank job of `pytest -m gpu` therefore runs with DP_CHECK_SEED=12.
 
 Also run by `pytest -m gpu` (tests/conftest.py starts it before the test process touches the GPU, tests/test_dp_gpu.py
 waits for it): two ranks share the one card of the GPU box over gloo-on-device tensors.
@@ -27,6 +29,21 @@ import torch.distributed as dist
 import npvp_amd
 from npvp_amd import dp, ops
 from oracle import ops as O
+
+# DP_CHECK_MARGIN=1: record the smallest |BatchNorm output| in front of the EventEncoder's ReLUs - how close the batch sits
+# to a ReLU kink - for every training forward; printed per case below (the single-process reference and this rank's shard)
+MARGINS = []
+if os.environ.get("DP_CHECK_MARGIN"):
+    from npvp_amd.models import submodules as _sub
+    _bn_rows0 = _sub._bn_rows
+
+    def _bn_rows_watched(x2, bn):
+        y = _bn_rows0(x2, bn)
+        if bn.training:
+            a = y.detach().abs()
+            MARGINS.append((float(a.min()), float((a < 1e-5).sum()), y.numel(), (y.detach() > 0).cpu(), y.detach().cpu()))
+        return y
+    _sub._bn_rows = _bn_rows_watched
 
 rank, world, local = dp.init_distributed()
 dev = torch.device("cuda", local % torch.cuda.device_count())
@@ -151,6 +168,24 @@ if rank == 0:
                       f"vs data parallel {float((o3.flat_g - opt2.flat_g).norm() / base.norm()):.3e}", flush=True)
             finally:
                 setter(True)
+    if MARGINS:
+        # which side of the kink does every unit fall on - in this rank's data-parallel forwards and in the single-process reference's?
+        # MARGINS holds, in order: case-1 DP (3 steps + the eval forward does not record), case-1 reference, case-2 DP, case-2 reference
+        per_step = len(MARGINS) // 12       # BatchNorm calls per training forward
+        dp2, ref2_ = MARGINS[6 * per_step:9 * per_step], MARGINS[9 * per_step:12 * per_step]
+        flips, worst = 0, 0.0
+        for (_, _, _, md, yd), (_, _, _, mr, yr) in zip(dp2, ref2_):
+            C = md.shape[1]
+            mr_s, yr_s = mr.view(B, -1, C)[rank::world].reshape(-1, C), yr.view(B, -1, C)[rank::world].reshape(-1, C)
+            dis = md != mr_s
+            flips += int(dis.sum())
+            if dis.any():
+                worst = max(worst, float(torch.maximum(yd.abs(), yr_s.abs())[dis].max()))
+        print(f"[dp_check] random context: units of rank 0's shard whose ReLU decision DIFFERS between the data-parallel run and the single "
+              f"process: {flips} (largest |pre-activation| among them {worst:.2e})", flush=True)
+        print(f"[dp_check] ReLU margin (min |BatchNorm output| over all training forwards): {min(m_[0] for m_ in MARGINS):.3e}; "
+              f"units within 1e-5 of the kink: {int(sum(m_[1] for m_ in MARGINS))} of {sum(m_[2] for m_ in MARGINS)} "
+              f"(clip seed {os.environ.get('DP_CHECK_SEED', 11)})", flush=True)
     compare("random context", opt2, ml2, gs2, ropt2, rout2, m2, ref2)
     print("[dp_check] OK", flush=True)
 dist.barrier()

@@ -45,7 +45,7 @@ for i, b in enumerate(("tiny", "fill:0.001", "clone")):
 envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill:0.001"), "hazard2": dict(env, BETWEEN="clone"),
         "seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
-        "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts an activation of the 8-clip batch on a ReLU kink: tools/dp_check.py)
+        "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts ONE unit of the 8-clip batch on a ReLU kink, counted: profiles/r06_dp_check_relu_kink.txt)
         "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
 rc = 0

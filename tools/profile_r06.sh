@@ -26,6 +26,27 @@ dptrace)    # the data-parallel c4 shard step on ONE RCCL rank: eager (two strea
     head -8 "$OUT/streams_c4_dp_$M.md"
   done
   unset RANK WORLD_SIZE LOCAL_RANK NPVP_DP_FORCE NPVP_DIST_BACKEND ;;
+c2trace)    # kernel trace + stream view of the primary workload as the default command runs it (rocprofv3 --kernel-trace --stats)
+  rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o c2 -- python3 $ROOT/bench.py --steps 3 --warmup 2 --mode eager $QUIET > "$OUT/bench_c2_profiled.json" 2> "$OUT/kt.err"
+  python3 $ROOT/tools/rocpd_stats.py $(ls "$OUT"/kt/*.db | head -1) "$OUT/kernel_stats_c2.csv" > /dev/null
+  python3 $ROOT/tools/rocpd_streams.py $(ls "$OUT"/kt/*.db | head -1) 2 "$OUT/streams_c2.md" > /dev/null
+  rm -rf "$OUT/kt"
+  head -12 "$OUT/kernel_stats_c2.csv" ;;
+traffic)    # HBM-side traffic of the primary workload (separate FETCH_SIZE / WRITE_SIZE passes); the JSON records the library's sha256
+  BENCH="python3 $ROOT/bench.py --steps 3 --warmup 2 --mode eager $QUIET"
+  rocprofv3 --pmc FETCH_SIZE -d "$OUT/pf" -o c2 -- $BENCH > /dev/null 2> "$OUT/pf.err"
+  rocprofv3 --pmc WRITE_SIZE -d "$OUT/pw" -o c2 -- $BENCH > /dev/null 2> "$OUT/pw.err"
+  python3 $ROOT/tools/rocpd_traffic.py $(ls "$OUT"/pf/*.db | head -1) $(ls "$OUT"/pw/*.db | head -1) "$OUT/hbm_traffic_c2.md" "$OUT/hbm_traffic_c2.json" > /dev/null
+  rm -rf "$OUT/pf" "$OUT/pw"
+  tail -8 "$OUT/hbm_traffic_c2.md" ;;
+mfma)       # BASELINE's "MFMA util %": one --pmc pass per workload, the bench record beside it for the unprofiled step time
+  for W in c2p c2; do
+    python3 $ROOT/bench.py --workload $W --steps 6 --warmup 3 --mode eager $QUIET > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err" || exit 1
+    MS=$(python3 -c "import json,sys; print(json.load(open('$OUT/bench_$W.json'))['ms_per_step'])")
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/mu_$W" -o $W -- python3 $ROOT/bench.py --workload $W --steps 3 --warmup 2 --mode eager $QUIET > /dev/null 2> "$OUT/mu_$W.err" || exit 1
+    python3 $ROOT/tools/rocpd_mfma_util.py $(ls "$OUT"/mu_$W/*.db | head -1) --steps 3 --ms $MS --workload $W --out "$OUT/mfma_util_$W.md" --json "$OUT/mfma_util_$W.json" | head -12
+    rm -rf "$OUT/mu_$W"
+  done ;;
 *) echo "unknown step $STEP" ;;
 esac
 done

@@ -76,5 +76,8 @@ txt = "\n".join(out) + "\n"
 if arg("--out"):
     open(arg("--out"), "w").write(txt)
 if arg("--json"):
+    import hashlib, os
+    _lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "npvp_amd", "libnpvp_hip.so")
+    res["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest() if os.path.exists(_lib) else None  # bench.py emits the figure only beside THIS build
     json.dump(res, open(arg("--json"), "w"), indent=1)
 print(txt)

@@ -41,5 +41,8 @@ out += ["", "## pooled over template instantiations (what `roofline.traffic` of 
 for k, v in sorted(js["pooled"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_dispatch"] * kv[1]["dispatches"]):
     out.append(f"| `{k}` | {v['dispatches']} | {v['hbm_bytes_per_dispatch']/1e6:.1f} |")
 open(sys.argv[3], "w").write("\n".join(out) + "\n")
+import hashlib, os
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "npvp_amd", "libnpvp_hip.so")
+js["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest() if os.path.exists(_lib) else None      # bench.py emits these figures only beside THIS build
 json.dump(js, open(sys.argv[4], "w"), indent=1)
 print("\n".join(out[:40]))
