@@ -298,7 +298,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         # decision from the MAX over the ranks so that all ranks take the same one:
         #   eager        two streams, two launches per layer backward
         #   eager_fused  (if the eager step is host bound) dgrad + weight gradient of a layer as ONE launch beside the gradient stream
-        #   segments     the segmented replay (--dp-graph never skips it, always forces it)
+        #   segments     (host-bound or short steps; --dp-graph never skips it, always forces it) the segmented replay
         for i in range(warmup):
             eager_step(i)
 
@@ -318,7 +318,8 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
                 used, e_ms, e_host = "eager_fused", f_ms, f_host
             else:
                 ops.FusedLinearBwd.with_gradient_stream = False
-        if mode == "graph" or args.dp_graph != "never":           # (auto: always tried - c2's replay beats its eager step too)
+        if mode == "graph" or args.dp_graph == "always" or (args.dp_graph == "auto" and (host_bound or e_ms < 60.0)):
+            # (auto: host-bound or short steps - the shards; c2's segmented replay loses to its eager step in the safe replay mode, 238 vs 231 ms)
             fused_was = ops.FusedLinearBwd.with_gradient_stream
             try:
                 gstep, gfn = graphed()
@@ -356,9 +357,10 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
             eager_step(i)
         e_ms, e_host = trial(eager_step)
         trial_ms = {"eager": round(e_ms, 2), "eager_host": round(e_host, 2)}
-        if True:
-            # (round 6: the replay is tried for EVERY workload, not only the host-bound ones - c2's single-stream replay runs at
-            #  213 ms where the eager two-stream step takes 230: every kernel has the device to itself and there are no dispatch gaps)
+        if e_host >= 0.6 * e_ms or e_ms < 60.0 or args.graph_packets == "fast":
+            # the replay is tried for every step that is host bound or short (the 8-clip shards, c0: a few seconds of trial); the large
+            # workloads' replays lose to their eager two-stream steps in the safe replay mode (c2 236 - 242 against 229 - 236 ms, c1 92 - 96
+            # against 84 - 86: DESIGN section 5), and a capture of c2 next to its eager pool is 130 GiB of allocator churn for nothing
             try:
                 gstep, gfn = graphed()
                 g_ms, g_host = trial(gfn)
@@ -629,8 +631,8 @@ def main():
     ap.add_argument("--trial-steps", type=int, default=10, help="timed steps per candidate of a mode trial (the rehearsals on a shared card use fewer)")
     ap.add_argument("--dp-graph", default="auto", choices=["auto", "always", "never"],
                     help="data parallel: when to record the step as HIP-graph segments with the collectives issued eagerly between them "
-                         "(trainer.StepTape): auto = time it against the eager step and take the replay unless eager is faster (by > 5 %% "
-                         "when host bound); always = take it; never = eager only")
+                         "(trainer.StepTape): auto = for host-bound or short steps, time it against the eager step and take the replay unless "
+                         "eager is faster (by > 5 %% when host bound); always = take it; never = eager only")
     ap.add_argument("--graph-packets", default="safe", choices=["fast", "safe"],
                     help="how the ROCm runtime replays a HIP graph: safe (default) = DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the package's default; "
                          "fast = the runtime's packet-capture path - quicker replays that compute WRONG steps on ROCm 7.2 (measurement "
