@@ -22,6 +22,9 @@ def _jobs(request):
         proc.kill()
         raise
     read = lambda name: open(f"{log_path}.{name}").read() if os.path.exists(f"{log_path}.{name}") else ""
+    if not getattr(request.config, "_npvp_dp_times_shown", False):
+        request.config._npvp_dp_times_shown = True
+        print("\n[dp jobs] " + read("times").replace("\n", "; "))
     return rc, read
 
 

@@ -48,10 +48,14 @@ envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill
         "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts ONE unit of the 8-clip batch on a ReLU kink, counted: profiles/r06_dp_check_relu_kink.txt)
         "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "rccl1c": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_DP_COMM="c")}
+import time
 rc = 0
-for name, cmd in jobs:
-    with open(f"{log}.{name}", "w") as f:
-        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, env=envs.get(name, env), cwd=ROOT)
-    if r.returncode != 0 and rc == 0:
-        rc = r.returncode
+with open(f"{log}.times", "w") as tf:
+    for name, cmd in jobs:
+        t0 = time.time()
+        with open(f"{log}.{name}", "w") as f:
+            r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, env=envs.get(name, env), cwd=ROOT)
+        tf.write(f"{name} {time.time() - t0:.1f} s rc={r.returncode}\n"); tf.flush()
+        if r.returncode != 0 and rc == 0:
+            rc = r.returncode
 sys.exit(rc)
