@@ -305,3 +305,33 @@ def test_range_guard_fallback_is_retried_and_backs_off():
     assert g._probation == 0 and g.retry_after == 4 and not g.fallback
     g.reset()
     assert g.events == 0 and g.retry_after == g.RETRY_AFTER
+
+
+def test_import_selects_the_safe_graph_replay_mode():
+    """`import npvp_amd` puts DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 into the environment (the ROCm 7.2 packet-capture replay path computes
+    wrong steps for this workload: DESIGN 7) unless NPVP_GRAPH_PACKET_CAPTURE=1 asks for the runtime's default, and never overrides a
+    value the caller set.  Run in fresh interpreters: the variable only matters before the HIP runtime initialises."""
+    import subprocess, sys
+    code = "import os, npvp_amd; print(os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), npvp_amd.graph_packet_capture())"
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "NPVP_GRAPH_PACKET_CAPTURE")}
+        e.update(env)
+        return subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300).stdout.split()
+    assert run() == ["0", "False"]
+    assert run(NPVP_GRAPH_PACKET_CAPTURE="1") == ["None", "True"]
+    assert run(DEBUG_CLR_GRAPH_PACKET_CAPTURE="1") == ["1", "True"]
+
+
+def test_bench_takes_the_replay_of_a_host_bound_step_unless_eager_clearly_wins():
+    """bench.py's mode rule restated on its numbers: the driver record of round 5 (eager trial 30.2 ms with 33 ms of
+    host per step, replay 31.7 ms) must come out as the REPLAY; a GPU-bound step keeps whichever is faster."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "prefer_replay")
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "bench.py", "exec"), ns)
+    prefer = ns["prefer_replay"]
+    assert prefer(30.23, 33.5, 31.68) is True             # round 5's driver box: host bound, eager only 4.6 % ahead in the trial
+    assert prefer(29.0, 28.0, 31.0) is False              # host bound, but eager wins by more than 5 %
+    assert prefer(230.0, 34.0, 236.0) is False            # not host bound: the rule does not apply (the caller compares the times)
+    assert prefer(30.0, 29.0, None) is False              # the capture failed
