@@ -47,6 +47,14 @@ mfma)       # BASELINE's "MFMA util %": one --pmc pass per workload, the bench r
     python3 $ROOT/tools/rocpd_mfma_util.py $(ls "$OUT"/mu_$W/*.db | head -1) --steps 3 --ms $MS --workload $W --out "$OUT/mfma_util_$W.md" --json "$OUT/mfma_util_$W.json" | head -12
     rm -rf "$OUT/mu_$W"
   done ;;
+gemmpmc)    # SQ counter passes over the stand-alone GEMMs at the c2 decoder shapes (two passes of 8 counters, no other tracing domain)
+  rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+    -d "$OUT/g1" -o gemm -- python3 $ROOT/tools/gemm_pmc.py > /dev/null 2> "$OUT/g1.err"
+  rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES \
+    -d "$OUT/g2" -o gemm -- python3 $ROOT/tools/gemm_pmc.py > /dev/null 2> "$OUT/g2.err"
+  python3 $ROOT/tools/rocpd_pmc.py $(ls "$OUT"/g1/*.db | head -1) $(ls "$OUT"/g2/*.db | head -1) --filter npvp::gemm --out "$OUT/pmc_gemm_table.md" > /dev/null
+  rm -rf "$OUT/g1" "$OUT/g2"
+  cat "$OUT/pmc_gemm_table.md" | cut -c1-400 ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
