@@ -137,7 +137,8 @@ def cpu_baseline(primary):
     v, dt = cpu_baseline_one(cfg_file, To, Tp, 2, 3, cores)
     f0, _, B0, To0, Tp0 = WORKLOADS["c0"]
     v0, dt0 = cpu_baseline_one(f0, To0, Tp0, B0, 3, cores)
-    return {"value": round(v, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(v, 2), "unit": "frames/s", "cores": cores, "kind": "port", "extrapolated_from_sample": True,
+            "host_logical_cpus": host_cpu()[1],
             "sample": f"2 clips x (To={To},Tp={Tp}) of the primary workload, full-depth predictor train step, 1 warm-up + 3 "
                       f"timed steps of the CPU oracle (torch {torch.__version__}, {dt:.2f} s/step)",
             "c0": {"value": round(v0, 2), "unit": "frames/s",

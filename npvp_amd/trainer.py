@@ -522,9 +522,15 @@ class GraphedTrainStep:
     replay must see differently lives in device memory: the input batch (copied into static buffers), the dropout seed (bumped by a
     kernel inside the graph), lr / step count / clip coefficient.
 
-    single_stream (default): the step is captured WITHOUT the gradient stream - a graph with one chain of nodes replays through the
-    runtime's batched-packet path, a graph with cross-stream edges does not (measured: 62 - 77 ms against 34 ms for an 8-clip
-    step).  The overlap the second stream gives the eager step comes from inside the launches instead (grouped GEMM launches).
+    single_stream (default): the step is captured WITHOUT the gradient stream - a graph with cross-stream edges replays at twice the
+    time of a single chain of nodes on ROCm 7.2 (56 against 31 ms for an 8-clip step, in either replay mode of the runtime).  The
+    overlap the second stream gives the eager step comes from inside the launches instead (grouped GEMM launches).
+
+    Replay mode of the runtime (round 6): `import npvp_amd` selects DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - the runtime then marshals every
+    node at launch (2.5 - 4 ms of host per replay of ~1 000 kernels) instead of replaying packets it prepared at instantiation
+    (0.3 ms), because the prepared-packet path computes wrong steps for this workload (npvp_amd/__init__.py).  With that
+    path switched on (NPVP_GRAPH_PACKET_CAPTURE=1) this class re-captures whenever the allocator has mapped new device segments since the
+    instantiation and primes the clock in front of a busy period (`prime`); neither makes the path trustworthy.
 
     Range of the fp16 arithmetic (ops.RangeGuard): the weight-gradient kernels baked into the graph raise the device counter like the
     eager ones; every `poll_every` replays the counter is copied to pinned host memory WITHOUT blocking and looked at on the next call.
@@ -629,7 +635,7 @@ class GraphedTrainStep:
     @staticmethod
     def _device_allocs(dev):
         """how many device segments the caching allocator has mapped so far (a monotonic counter).  Why it is watched (round 6,
-        profiles/r06_graph_remap.txt): on ROCm 7.2 a graph that replays through the runtime's packet-capture path - the fast one -
+        profiles/r06_graph_alloc_hazard.txt): on ROCm 7.2 a graph that replays through the runtime's packet-capture path - the fast one -
         computes ONE wrong step if, since it was instantiated, new device memory was mapped (hipMalloc) and a kernel touched it:
         content-independent, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (slower replays), gone when the step is captured again
         after the mapping.  So a replay that finds the counter moved captures the step again first (`remapped` counts them) - in a
