@@ -42,9 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# --graph-packets fast keeps the ROCm runtime's packet-capture replay path (NPVP_GRAPH_PACKET_CAPTURE=1; npvp_amd/__init__.py switches it off
-# by default because it computes wrong steps - `replay_check` in this benchmark's record shows it: profiles/r06_graph_alloc_hazard.txt).
-# The choice has to be in the environment before the HIP runtime initialises, hence here.
+# --graph-packets fast keeps the ROCm runtime's prepared-packet replay path (NPVP_GRAPH_PACKET_CAPTURE=1).  npvp_amd/__init__.py switches it
+# off by default: on ROCm 7.2 it does not order a graph's memset nodes against its kernels (profiles/r06_graph_alloc_hazard.txt).  The
+# package's own step contains no memset node (`graph_nodes` in the record) and `replay_check` compares the timed replays with the same
+# steps taken eagerly - equal to the bit in both modes.  The choice has to be in the environment before the HIP runtime initialises, hence here.
 if "--graph-packets" in sys.argv and sys.argv[sys.argv.index("--graph-packets") + 1:][:1] == ["fast"]:
     os.environ["NPVP_GRAPH_PACKET_CAPTURE"] = "1"
 
@@ -435,8 +436,10 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     # launches ahead, i.e. they converge to the GPU's step time and say nothing about the host.
     t_host = host_min * steps
     launches = (npvp_amd._lib.lib().npvp_launch_count() - L0) / steps       # (library launches; a replayed graph enqueues none: taken from its capture)
+    graph_nodes = None
     if used in ("graph", "graph_segments"):
         launches = gstep.launches
+        graph_nodes = {k: v for k, v in gstep.census.items() if k != "memset_bytes"}        # (node census of the replayed step: no "memset")
     fence()
     dt = time.perf_counter() - t0
     if check and replayed and check_state:
@@ -578,7 +581,8 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     events = ops.RangeGuard.poll(dev)           # weight-gradient launches that met a feature 2^18 below its tensor's bound (0 expected)
     res = {"key": key, "name": name, "B": B, "To": To, "Tp": Tp, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "peak_gb": peak_gb,
            "loss": loss, "host_ms": 1000.0 * t_host / steps, "flops_step": flops_step, "roof": roof, "roof_hbm": roof_hbm, "steps": steps,
-           "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms, "replay_check": replay_check}
+           "warmup": warmup, "range_events": events, "launches": launches, "mode": used, "mode_trial": trial_ms, "replay_check": replay_check,
+           "graph_nodes": graph_nodes}
     if gsync is not None:
         # how many ranks REALLY reduce together: the mean over the ranks of (rank + 1), through the very exchange the gradient buckets
         # take (ProcessGroup or the library's npvp_dp_*), must be (world + 1) / 2 - one number the driver can check against --gpus
@@ -636,8 +640,8 @@ def main():
                          "eager is faster (by > 5 %% when host bound); always = take it; never = eager only")
     ap.add_argument("--graph-packets", default="safe", choices=["fast", "safe"],
                     help="how the ROCm runtime replays a HIP graph: safe (default) = DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the package's default; "
-                         "fast = the runtime's packet-capture path - quicker replays that compute WRONG steps on ROCm 7.2 (measurement "
-                         "only: `replay_check` in the record says so)")
+                         "fast = the runtime's prepared-packet path (less host time per replay; refuses a step with memset nodes, which "
+                         "that path mis-orders on ROCm 7.2).  `replay_check` in the record compares the replays with eager steps either way")
     ap.add_argument("--graph-streams", type=int, default=1, choices=[1, 2],
                     help="streams inside a captured step: 1 (default: one chain of nodes, what replays fast) or 2 (measurement only)")
     ap.add_argument("--mode", default="auto", choices=["eager", "graph", "auto"],
@@ -747,7 +751,7 @@ def main():
                "roofline": r["roof"], "roofline_hbm": r["roof_hbm"], "secondary": secondary or None,
                "secondary_fields": ["ms_per_step", "frames_per_s", "host_enqueue_ms", "library_launches_per_step", "whole_step_tflops"] if secondary else None,
                "secondary_mode": modes or None, "scaling_dp": scaling_dp, "strong_scaling": strong, "dp": r.get("dp"),
-               "replay_check": r.get("replay_check"), "graph_packet_capture": npvp_amd.graph_packet_capture(),
+               "replay_check": r.get("replay_check"), "graph_nodes": r.get("graph_nodes"), "graph_packet_capture": npvp_amd.graph_packet_capture(),
                "host": dict(zip(("cpu", "cores"), host_cpu()))}
         if world == 1 and not args.no_cpu_baseline and args.flavour == "predictor":
             log("timing the CPU oracle on a bounded sample ...")

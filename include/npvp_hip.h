@@ -54,6 +54,13 @@ int npvp_event_record(void* event, void* stream);
 float npvp_event_elapsed_ms(void* event0, void* event1);
 int npvp_event_destroy(void* event);
 
+/* Node census of a captured step (a hipGraph_t, e.g. torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()): counts[16] indexed by
+ * hipGraphNodeType (0 kernel, 1 memcpy, 2 memset, ...), memset_bytes[0 .. max_memsets) the sizes of the first memset nodes; returns
+ * the number of nodes or a negative error.  The training step of this library contains no memset node, and the host layer checks
+ * it: on ROCm 7.2 a graph replayed from prepared packets (the runtime's default) does not order its memset nodes against the
+ * neighbouring kernels (profiles/r06_graph_alloc_hazard.txt). */
+long long npvp_graph_node_counts(void* graph, long long* counts, long long* memset_bytes, int max_memsets);
+
 /* ---- GEMM (every nn.Linear / 1x1 Conv2d / MHA in- and out-projection and their backward:
  * ref/models/VidHRFormer.py:71-72,111,184-185,225 (token FFN), :345,364,380,387 (MlpDWBN fc1/fc2),
  * torch.nn.MultiheadAttention in_proj/out_proj at :70,180,192,270; NRMLP linears
@@ -369,6 +376,15 @@ int npvp_broadcast_mid(const float* in, float* out, int A, int B, long long Cc, 
 long long npvp_colsum_workspace_bytes(long long rows, int N);
 int npvp_colsum(const float* x, long long rows, int N, long long ld, float* out, int accumulate /* out += */,
                 void* workspace, long long ws_bytes, npvp_stream_t stream);
+
+/* ---- scalar losses of shared_step (ref/models/Predictor.py:172-194): L1Loss = lam * mean|a - b| (ref/models/criterion.py:99-121)
+ * and the sum under Div_KL (ref/models/criterion.py:341-354).  Two-stage sums in a fixed order: deterministic, and - unlike a
+ * multi-block torch reduction - without a semaphore that a memset node of a captured graph has to clear.  out / gout are device
+ * scalars; l1_mean_bwd writes da = sgn(a - b) * ((gout * lam) / n).  workspace >= 1024 floats. */
+int npvp_l1_mean(const float* a, const float* b, long long n, float lam, float* out, void* workspace, long long ws_bytes,
+                 npvp_stream_t stream);
+int npvp_l1_mean_bwd(const float* a, const float* b, long long n, const float* gout, float lam, float* da, npvp_stream_t stream);
+int npvp_sum_all(const float* x, long long n, float* out, void* workspace, long long ws_bytes, npvp_stream_t stream);
 
 /* ---- optimiser step of training_step_no_gan (ref/models/Predictor.py:135-136,197): clip_grad_norm_
  * over a flat gradient range, then torch.optim.AdamW semantics on flat buffers.  hyper = {lr, step}

@@ -27,6 +27,7 @@ SIGNATURES = {
     "npvp_event_record": (c_int, [c_p, c_p]),
     "npvp_event_elapsed_ms": (c_f, [c_p, c_p]),
     "npvp_event_destroy": (c_int, [c_p]),
+    "npvp_graph_node_counts": (c_ll, [c_p, c_p, c_p, c_int]),
     "npvp_gemm_workspace_bytes": (c_ll, [c_int, c_int, c_int]),
     "npvp_gemm_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "npvp_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_int, c_p, c_p,
@@ -100,6 +101,9 @@ SIGNATURES = {
     "npvp_colsum_workspace_bytes": (c_ll, [c_ll, c_int]),
     "npvp_colsum": (c_int, [c_p, c_ll, c_int, c_ll, c_p, c_int, c_p, c_ll, c_p]),
     "npvp_grad_norm_clip": (c_int, [c_p, c_ll, c_f, c_p, c_p, c_ll, c_p]),
+    "npvp_l1_mean": (c_int, [c_p, c_p, c_ll, c_f, c_p, c_p, c_ll, c_p]),
+    "npvp_l1_mean_bwd": (c_int, [c_p, c_p, c_ll, c_p, c_f, c_p, c_p]),
+    "npvp_sum_all": (c_int, [c_p, c_ll, c_p, c_p, c_ll, c_p]),
     "npvp_adamw_step": (c_int, [c_p, c_p, c_p, c_p, c_ll, c_p, c_f, c_f, c_f, c_f, c_p, c_ll, c_ll, c_int, c_p]),
     "npvp_sqdiff_workspace_bytes": (c_ll, [c_int, c_ll]),
     "npvp_sqdiff_per_image": (c_int, [c_p, c_p, c_int, c_ll, c_f, c_f, c_p, c_p, c_ll, c_p]),

@@ -1,6 +1,7 @@
 // Library-wide entry points: version, last-error string.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -79,3 +80,33 @@ extern "C" float npvp_event_elapsed_ms(void* e0, void* e1) {
   return ms;
 }
 extern "C" int npvp_event_destroy(void* ev) { return ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess ? NPVP_OK : NPVP_ERR_ARG; }
+
+// What a captured step consists of.  counts[16] by hipGraphNodeType (0 kernel, 1 memcpy, 2 memset, 3 host, 4 child graph, 5 empty,
+// 6 wait-event, 7 event-record, ...); memset_bytes[0 .. max_memsets) = the sizes of the first memset nodes.  Returns the number
+// of nodes, or a negative error.  Why it exists: memset nodes are what the ROCm 7.2 packet-capture replay mishandles
+// (profiles/r06_graph_alloc_hazard.txt) - trainer.GraphedTrainStep counts them and refuses that replay mode when it finds any.
+extern "C" long long npvp_graph_node_counts(void* graph, long long* counts, long long* memset_bytes, int max_memsets) {
+  if (!graph || !counts) { npvp_set_error("graph_node_counts: null argument"); return NPVP_ERR_ARG; }
+  size_t n = 0;
+  if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) { npvp_set_error("graph_node_counts: hipGraphGetNodes failed"); return NPVP_ERR_LAUNCH; }
+  for (int i = 0; i < 16; ++i) counts[i] = 0;
+  if (n == 0) return 0;
+  hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+  if (!nodes) { npvp_set_error("graph_node_counts: out of host memory"); return NPVP_ERR_ARG; }
+  if (hipGraphGetNodes((hipGraph_t)graph, nodes, &n) != hipSuccess) { free(nodes); npvp_set_error("graph_node_counts: hipGraphGetNodes failed"); return NPVP_ERR_LAUNCH; }
+  int sets = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) continue;
+    const int ti = (int)t;
+    counts[ti >= 0 && ti < 15 ? ti : 15] += 1;
+    if (t == hipGraphNodeTypeMemset && memset_bytes && sets < max_memsets) {
+      hipMemsetParams mp;
+      memset_bytes[sets++] = hipGraphMemsetNodeGetParams(nodes[i], &mp) == hipSuccess
+                                 ? (long long)mp.elementSize * (long long)mp.width * (long long)(mp.height ? mp.height : 1) : -1;
+    }
+  }
+  free(nodes);
+  return (long long)n;
+}
+

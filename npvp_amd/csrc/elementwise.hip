@@ -279,6 +279,94 @@ extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, 
   return NPVP_OK;
 }
 
+// ---- scalar losses of the step (ref/models/criterion.py:99-121 L1Loss, :341-354 Div_KL): deterministic two-stage sums, fixed
+// order, no atomics and no semaphore.  torch's multi-block reductions zero a 4-byte semaphore with a memset NODE when they are
+// captured; memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt), so
+// the captured step contains none.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 u = ld4(a + i), v = ld4(b + i);
+    s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n & ~3ll; i < n; ++i) s += fabsf(a[i] - b[i]);
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 v = ld4(x + i);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n & ~3ll; i < n; ++i) s += x[i];
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = (sum of the partials / div) * mul
+__global__ void sum_finish_kernel(const float* __restrict__ part, int nb, float div, float mul, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) out[0] = (s / div) * mul;
+}
+
+// da = sgn(a - b) * ((gout * lam) / n): the gradient torch's abs -> mean -> mul chain hands to `a`, in its order of operations
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                     const float* __restrict__ gout, float lam, float* __restrict__ da) {
+  const float c = (gout[0] * lam) / (float)n;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 u = ld4(a + i), v = ld4(b + i);
+    float4 r;
+    r.x = c * (float)((u.x > v.x) - (u.x < v.x)); r.y = c * (float)((u.y > v.y) - (u.y < v.y));
+    r.z = c * (float)((u.z > v.z) - (u.z < v.z)); r.w = c * (float)((u.w > v.w) - (u.w < v.w));
+    st4(da + i, r);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n & ~3ll; i < n; ++i) da[i] = c * (float)((a[i] > b[i]) - (a[i] < b[i]));
+}
+
+static long long loss_blocks(long long n) { long long nb = (n / 4 + 255) / 256; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb; }
+
+// out[0] = lam * mean |a - b|; workspace >= 1024 floats
+extern "C" int npvp_l1_mean(const float* a, const float* b, long long n, float lam, float* out, void* workspace, long long ws_bytes,
+                            hipStream_t stream) {
+  NPVP_CHECK_ARG(a && b && out && n > 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0, "l1_mean: bad buffers");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= 1024 * 4, "l1_mean: workspace too small");
+  const long long nb = loss_blocks(n);
+  NPVP_LAUNCH(l1_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, b, n, (float*)workspace);
+  NPVP_CHECK_LAUNCH();
+  NPVP_LAUNCH(sum_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, (int)nb, (float)n, lam, out);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+extern "C" int npvp_l1_mean_bwd(const float* a, const float* b, long long n, const float* gout, float lam, float* da, hipStream_t stream) {
+  NPVP_CHECK_ARG(a && b && gout && da && n > 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)da % 16) == 0,
+                 "l1_mean_bwd: bad buffers");
+  long long nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+  NPVP_LAUNCH(l1_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, b, n, gout, lam, da);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
+// out[0] = sum x; workspace >= 1024 floats
+extern "C" int npvp_sum_all(const float* x, long long n, float* out, void* workspace, long long ws_bytes, hipStream_t stream) {
+  NPVP_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x % 16) == 0, "sum_all: bad buffer");
+  NPVP_CHECK_ARG(workspace && ws_bytes >= 1024 * 4, "sum_all: workspace too small");
+  const long long nb = loss_blocks(n);
+  NPVP_LAUNCH(sum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, n, (float*)workspace);
+  NPVP_CHECK_LAUNCH();
+  NPVP_LAUNCH(sum_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, (int)nb, 1.f, 1.f, out);
+  NPVP_CHECK_LAUNCH();
+  return NPVP_OK;
+}
+
 // out2 = {norm, clip coefficient}; workspace >= 1024 floats
 extern "C" int npvp_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, void* workspace,
                                    long long ws_bytes, hipStream_t stream) {

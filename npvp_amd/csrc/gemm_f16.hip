@@ -777,10 +777,22 @@ extern "C" int npvp_amax(const float* x, long long rows, long long cols, long lo
   return NPVP_OK;
 }
 
+// The amax tables are zeroed by a KERNEL, not by hipMemsetAsync: inside a captured step a memset becomes a memset node, and
+// memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt).
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+static hipError_t zero_fill(void* p, size_t bytes, hipStream_t stream) {
+  const long long n = (long long)(bytes / 4);
+  long long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  NPVP_LAUNCH(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)p, n);
+  return hipGetLastError();
+}
+
 extern "C" int npvp_split_weights_f16(const void* desc, int count, void* amax_table, long long amax_bytes, hipStream_t stream) {
   NPVP_CHECK_ARG(desc && count > 0, "split_weights_f16: empty table");
   if (amax_table && amax_bytes > 0) {
-    if (hipMemsetAsync(amax_table, 0, (size_t)amax_bytes, stream) != hipSuccess) { npvp_set_error("split_weights_f16: memset failed"); return NPVP_ERR_LAUNCH; }
+    if (zero_fill(amax_table, (size_t)amax_bytes, stream) != hipSuccess) { npvp_set_error("split_weights_f16: zero fill failed"); return NPVP_ERR_LAUNCH; }
   }
   SplitDescH none = {};
   NPVP_LAUNCH(weights_amax_kernel, dim3(16, count), dim3(256), 0, stream, (const SplitDescH*)desc, none);
@@ -793,7 +805,7 @@ extern "C" int npvp_split_weights_f16(const void* desc, int count, void* amax_ta
 extern "C" int npvp_split_weight_f16(const float* w, long long ld, int N, int K, void* F, void* D, float* amax_slot, hipStream_t stream) {
   NPVP_CHECK_ARG(N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ld % 4 == 0, "split_weight_f16: N, K must be multiples of 8");
   NPVP_CHECK_ARG(((uintptr_t)w % 16) == 0 && amax_slot, "split_weight_f16: w must be 16-byte aligned, amax_slot non-null");
-  if (hipMemsetAsync(amax_slot, 0, AMAX_WORDS * AMAX_STRIDE * 4, stream) != hipSuccess) { npvp_set_error("split_weight_f16: memset failed"); return NPVP_ERR_LAUNCH; }
+  if (zero_fill(amax_slot, AMAX_WORDS * AMAX_STRIDE * 4, stream) != hipSuccess) { npvp_set_error("split_weight_f16: zero fill failed"); return NPVP_ERR_LAUNCH; }
   SplitDescH one = {w, ld, N, K, (_Float16*)F, (_Float16*)D, amax_slot, 0};
   NPVP_LAUNCH(weights_amax_kernel, dim3(16, 1), dim3(256), 0, stream, (const SplitDescH*)nullptr, one);
   NPVP_CHECK_LAUNCH();

@@ -713,6 +713,62 @@ class _MeanMid(torch.autograd.Function):
         return broadcast_mid(g, ctx.B, 1.0 / ctx.B)
 
 
+class _L1Mean(torch.autograd.Function):
+    """lam * mean|a - b| (ref/models/criterion.py:99-121 with norm_dim None); the gradient goes to `a` only - the second operand of
+    the Stage-2 losses is the ground truth.  One fused pass forward, one backward, and no torch reduction: a captured step must not
+    contain memset nodes (npvp_hip.h npvp_l1_mean)."""
+
+    @staticmethod
+    def forward(ctx, a, b, lam):
+        remember(ctx)
+        _chk(a, b)
+        if a.shape != b.shape:
+            raise RuntimeError(f"l1_mean: shapes differ: {tuple(a.shape)} / {tuple(b.shape)}")
+        a, b = _c(a), _c(b)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws, wsn = _ws(4096, a.device)
+        check(lib().npvp_l1_mean(_ptr(a), _ptr(b), a.numel(), float(lam), _ptr(out), _ptr(ws), wsn, _stream()), "npvp_l1_mean")
+        ctx.save_for_backward(a, b)
+        ctx.lam = float(lam)
+        return out
+
+    @scoped
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        _chk(g)
+        da = torch.empty_like(a)
+        check(lib().npvp_l1_mean_bwd(_ptr(a), _ptr(b), a.numel(), _ptr(_c(g)), ctx.lam, _ptr(da), _stream()), "npvp_l1_mean_bwd")
+        return da, None, None
+
+
+def l1_mean(a, b, lam=1.0):
+    if b.requires_grad:
+        raise RuntimeError("l1_mean: only the first operand takes a gradient (the Stage-2 losses compare against ground truth)")
+    return _L1Mean.apply(a, b, lam)
+
+
+class _SumAll(torch.autograd.Function):
+    """sum of every element -> device scalar, in a fixed order (npvp_hip.h npvp_sum_all)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        ctx.shape = x.shape
+        x = _c(x)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws, wsn = _ws(4096, x.device)
+        check(lib().npvp_sum_all(_ptr(x), x.numel(), _ptr(out), _ptr(ws), wsn, _stream()), "npvp_sum_all")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape)
+
+
+def sum_all(x):
+    return _SumAll.apply(x)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, relu):

@@ -86,7 +86,9 @@ class AmaxSlot:
         st = cls._cur.get(key)
         if st is None or st[1] >= cls.CHUNK:
             cur = torch.cuda.current_stream(dev)
-            ch = torch.zeros(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev)
+            # (zeroed by a fill KERNEL, explicitly: a hipMemsetAsync would be a memset node of a captured step, and memset nodes are
+            #  what the ROCm 7.2 prepared-packet replay mis-orders - profiles/r06_graph_alloc_hazard.txt)
+            ch = torch.empty(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev).fill_(0.0)
             others = [torch.cuda.default_stream(dev)]
             if WgradStreamState.enabled:
                 others.append(WgradStreamState.stream(dev))      # weight-gradient GEMMs read slots on the gradient stream
@@ -233,43 +235,6 @@ class AuxStream:
             if quiet is not None:
                 quiet(False)
         return cls._streams[key]
-
-
-PRIME_GIB = float(os.environ.get("NPVP_PRIME_GIB", "24"))
-
-
-def prime_clocks(dev, gib=None):
-    """One long hipMemsetAsync before a busy period that starts from an idle device (round 6, profiles/r06_clock_priming.txt).
-    Measured on MI355X with the c2 step replayed from its graph: started cold, the replays run at sclk ~1.97 GHz (237 ms per step);
-    started right behind ONE memset over a >= 16 GiB buffer they run at ~2.27 GHz (214 ms; the MFMA GEMMs 19 % faster, the HBM-bound
-    kernels unchanged) and stay there for as long as the queue never drains (60 replays = 13 s checked; the next idle moment drops the
-    state again).  A fill KERNEL over the same bytes, several shorter memsets, or a device-to-device copy do nothing - it is the
-    firmware's clock decision for the busy period that follows a long pure-memory phase, not a cache or allocator effect.  The
-    memset is ~5 ms of device time once per busy period; the buffer comes from (and returns to) the caching allocator.
-    -> bytes zeroed (0: not enough free memory, nothing done)"""
-    buf = prime_buffer(dev, gib)
-    if buf is None:
-        return 0
-    buf.zero_()                             # (a tensor that owns its whole storage: ONE hipMemsetAsync)
-    return buf.numel()
-
-
-def prime_buffer(dev, gib=None):
-    """the buffer prime_clocks zeroes (None: priming switched off, or not enough free memory - it is optional).  trainer.GraphedTrainStep
-    allocates it BEFORE its capture and keeps it: device memory mapped after a graph's instantiation must not be touched between
-    its replays (trainer.GraphedTrainStep._device_allocs)."""
-    gib = PRIME_GIB if gib is None else gib
-    if gib <= 0:
-        return None
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    n = int(min(gib * (1 << 30), max(free_b - (8 << 30), cached // 2)))
-    if n < (12 << 30):                      # (below ~12 GiB the memset does not move the clock: profiles/r06_clock_priming.txt)
-        return None
-    try:
-        return torch.empty(n, dtype=torch.uint8, device=dev)
-    except RuntimeError:
-        return None
 
 
 # --------------------------------------------------------------------------- per-trainer state

@@ -450,6 +450,52 @@ def load_lightning_checkpoint(path, predictor, enc=None, dec=None, opt=None, str
     return ck.get("epoch", 0), ck.get("global_step", 0)
 
 
+
+_NODE_NAMES = ("kernel", "memcpy", "memset", "host", "child_graph", "empty", "wait_event", "event_record", "ext_sem_signal", "ext_sem_wait",
+               "mem_alloc", "mem_free", "memcpy_from_symbol", "memcpy_to_symbol", "14", "other")
+
+
+def _new_graph():
+    """a torch graph object that KEEPS its hipGraph_t after the capture, so that the nodes can be counted (graph_census) before the
+    explicit instantiation"""
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def graph_census(graph):
+    """{node type: count} of a captured torch.cuda.CUDAGraph(keep_graph=True) plus "memset_bytes" (sizes of its memset nodes) -
+    include/npvp_hip.h npvp_graph_node_counts"""
+    import ctypes
+    counts, sets = (ctypes.c_longlong * 16)(), (ctypes.c_longlong * 64)()
+    n = lib().npvp_graph_node_counts(graph.raw_cuda_graph(), ctypes.cast(counts, ctypes.c_void_p), ctypes.cast(sets, ctypes.c_void_p), 64)
+    if n < 0:
+        check(int(n), "npvp_graph_node_counts")
+    out = {name: int(c) for name, c in zip(_NODE_NAMES, counts) if c}
+    out["memset_bytes"] = [int(b) for b in sets[:min(64, int(counts[2]))]]
+    return out
+
+
+def _merge_census(total, one):
+    for k, v in one.items():
+        total[k] = total.get(k, []) + v if k == "memset_bytes" else total.get(k, 0) + v
+    return total
+
+
+def _require_memset_free(census, what):
+    """Memset nodes and the runtime's replay modes (round 6, profiles/r06_graph_alloc_hazard.txt): a graph that ROCm 7.2 replays from
+    the AQL packets it prepared at instantiation (the runtime's default, DEBUG_CLR_GRAPH_PACKET_CAPTURE=1) does not order its memset
+    nodes against the neighbouring kernels - the zero fill of the amax slots raced with their producers, the 4-byte semaphore of a
+    torch reduction was cleared late and the loss scalar never written.  The step of this package therefore zero-fills with
+    kernels and reduces with its own fixed-order sums, and a captured step that still contains a memset node (a caller's own ops
+    inside the step, MIOpen) is refused in that replay mode instead of computing silently different numbers."""
+    from . import graph_packet_capture
+    n = census.get("memset", 0)
+    if n and graph_packet_capture() and os.environ.get("NPVP_ALLOW_GRAPH_MEMSETS") != "1":      # (the switch: tools/graph_alloc_hazard.py)
+        raise RuntimeError(f"{what}: the captured step contains {n} memset node(s) (bytes: {census['memset_bytes'][:8]}) and the HIP runtime "
+                           "replays graphs from prepared packets (DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0): on ROCm 7.2 such a replay does "
+                           "not order memset nodes against kernels.  Import npvp_amd before the first CUDA call without "
+                           "NPVP_GRAPH_PACKET_CAPTURE=1 (it then selects the node-by-node replay mode), or remove the memsets from the step")
+
+
 class StepTape:
     """A training step as a CHAIN of HIP-graph segments with host actions between them - how a step with collectives in it is
     replayed without the host enqueueing its ~1 000 launches: the kernels live in graphs, the collectives stay ordinary eager calls
@@ -468,6 +514,7 @@ class StepTape:
         self.pool = torch.cuda.graph_pool_handle()
         self._g = None
         self._tick = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.census = {}                 # node counts over all segments (graph_census)
 
     @property
     def recording(self):
@@ -478,23 +525,31 @@ class StepTape:
         return sum(1 for it in self.items if isinstance(it, torch.cuda.CUDAGraph))
 
     def begin(self):
-        g = torch.cuda.CUDAGraph()
+        g = _new_graph()
         g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
         self._g = g
         self._tick.add_(1.0)
 
+    def _close(self, g):
+        g.capture_end()
+        _merge_census(self.census, graph_census(g))
+        self.items.append(g)
+
     def cut(self, action):
         g, self._g = self._g, None
-        g.capture_end()
-        self.items.append(g)
+        self._close(g)
         self.items.append(action)
         self.begin()
 
     def end(self):
+        """closes the last segment, checks the census (_require_memset_free) and instantiates every segment"""
         g, self._g = self._g, None
         if g is not None:
-            g.capture_end()
-            self.items.append(g)
+            self._close(g)
+        _require_memset_free(self.census, "StepTape")
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.instantiate()
 
     def abort(self):
         """after an exception inside a recording: close the open capture (its graph is dropped)"""
@@ -526,11 +581,14 @@ class GraphedTrainStep:
     time of a single chain of nodes on ROCm 7.2 (56 against 31 ms for an 8-clip step, in either replay mode of the runtime).  The
     overlap the second stream gives the eager step comes from inside the launches instead (grouped GEMM launches).
 
-    Replay mode of the runtime (round 6): `import npvp_amd` selects DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - the runtime then marshals every
-    node at launch (2.5 - 4 ms of host per replay of ~1 000 kernels) instead of replaying packets it prepared at instantiation
-    (0.3 ms), because the prepared-packet path computes wrong steps for this workload (npvp_amd/__init__.py).  With that
-    path switched on (NPVP_GRAPH_PACKET_CAPTURE=1) this class re-captures whenever the allocator has mapped new device segments since the
-    instantiation and primes the clock in front of a busy period (`prime`); neither makes the path trustworthy.
+    Replay mode of the runtime and memset nodes (round 6, profiles/r06_graph_alloc_hazard.txt): ROCm 7.2 replays a graph from AQL
+    packets it prepared at instantiation (0.3 - 1.5 ms of host per replay of ~1 000 kernels) and in that mode does NOT order the
+    graph's memset nodes against the neighbouring kernels; `import npvp_amd` therefore selects DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - the
+    runtime marshals every node at launch (2.5 - 8 ms of host per replay), which is exact with any step.  The step of this package
+    contains no memset node (zero fills are kernels, the losses are the library's fixed-order sums), `census` says so for every
+    capture, and with the prepared-packet mode switched on (NPVP_GRAPH_PACKET_CAPTURE=1) a capture that does contain one - a caller's
+    own ops, MIOpen - is refused (_require_memset_free).  A memset-free step is equal to the bit in both modes and, being bound by
+    its kernels, equally fast (c4 shard 34.0 / 34.1 ms, c2 239.0 / 238.6 ms on one box).
 
     Range of the fp16 arithmetic (ops.RangeGuard): the weight-gradient kernels baked into the graph raise the device counter like the
     eager ones; every `poll_every` replays the counter is copied to pinned host memory WITHOUT blocking and looked at on the next call.
@@ -546,7 +604,7 @@ class GraphedTrainStep:
     (at least two eager steps, in the single-stream schedule the capture uses) teaches GradSync the contribution counts."""
 
     def __init__(self, predictor, opt, past_feats, future_feats, lam_PF_L1=0.01, KL_beta=1e-8, max_grad_norm=1.0, warmup=3,
-                 single_stream=True, poll_every=32, grad_sync=None, prime=None):
+                 single_stream=True, poll_every=32, grad_sync=None):
         """warmup: eager optimiser steps taken on (past_feats, future_feats) BEFORE the capture - they are real steps (parameters,
         Adam state, step count and dropout seed advance `warmup` times); pass warmup=0 when the caller has already stepped the model
         eagerly on this device (then nothing but the capture itself happens, and the capture executes nothing)."""
@@ -558,15 +616,7 @@ class GraphedTrainStep:
             assert single_stream, "a data-parallel step is recorded single-stream (graph segments are chains)"
             warmup = max(2, warmup)
         self.tape = None
-        # prime: a replay that finds the stream DRAINED (the first one, or the first after the caller synchronised) is preceded by
-        # sched.prime_clocks - one long memset after which the device runs the busy period that follows at its higher engine clock
-        # (c2: 237 -> 214 ms per replayed step).  A loop that keeps the queue fed is primed once.
-        if prime is None:                   # (measured only on the packet-capture replay path, which the package switches off by default)
-            prime = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"
-        self.prime, self.primed = bool(prime), 0
-        self._prime_buf = None
-        self.remapped = 0                   # re-captures because the allocator mapped new device memory (see _device_allocs)
-        self._watch_allocs = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"      # (only the packet-capture path needs it)
+        self.census = {}                    # node counts of the captured step (graph_census); census.get("memset", 0) == 0 for this package's step
         self.single_stream, self.poll_every, self.warmup = single_stream, max(1, int(poll_every)), warmup
         self.replays = self.recaptures = self.range_events = 0
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -601,11 +651,6 @@ class GraphedTrainStep:
             # the eager steps' cached blocks go back to the device: the capture allocates the step's whole working set again, from its
             # private pool (c2: 104 GiB beside an eager pool that an un-synchronised warm-up grows to 200 GiB would not fit in 288)
             torch.cuda.empty_cache()
-            if self.prime and self._prime_buf is None:
-                # the buffer of sched.prime_clocks, allocated BEFORE the capture and kept: memory mapped after the graph's
-                # instantiation would force a re-capture (see _device_allocs)
-                from .sched import prime_buffer
-                self._prime_buf = prime_buffer(dev)
             # a live probe (bench.py) brackets launches with library events that the capture carries (sched.ProbeEvent): the records
             # of the warm-up's eager launches are dropped, the capture's are re-stamped by every replay
             if ops.GemmProbe.armed:
@@ -617,30 +662,25 @@ class GraphedTrainStep:
             ops.AmaxSlot.reset_chunks()
             n0 = lib().npvp_launch_count()
             if gs is None:
-                self.graph = torch.cuda.CUDAGraph()
+                self.graph = _new_graph()
                 with torch.cuda.graph(self.graph):
                     self.out = predictor_train_step(*self._args, sync=False)
+                self.census = graph_census(self.graph)
+                _require_memset_free(self.census, "GraphedTrainStep")
+                self.graph.instantiate()
             else:
                 self._record_segments(dev, gs)
+                self.census = dict(self.tape.census)
+            if os.environ.get("NPVP_GRAPH_NODES") == "1":       # (diagnosis)
+                print(f"[GraphedTrainStep] nodes of the captured step: {self.census}", flush=True)
             self.launches = lib().npvp_launch_count() - n0          # library launches of one step (what a replay enqueues on the device)
             # the graph has the addresses of the weight-plane tables and amax slots baked in: they live as long as the graph does
             self._plane_tables = list(ops.WeightPlanes._tables or [])
             # ... and so do the probe events whose record nodes the capture carries (a destroyed event under a replay is a crash)
             self._probe_events = (list(ops.GemmProbe.records) if ops.GemmProbe.armed else []) + (list(ops.HbmProbe.records) if ops.HbmProbe.armed else [])
-            self._allocs_at_capture = self._device_allocs(dev)
         finally:
             ops.AmaxSlot.reset_chunks()         # (the graph's private-pool chunk is not for eager code - also after a failed capture)
             ops.WgradStream.enabled = two_streams
-
-    @staticmethod
-    def _device_allocs(dev):
-        """how many device segments the caching allocator has mapped so far (a monotonic counter).  Why it is watched (round 6,
-        profiles/r06_graph_alloc_hazard.txt): on ROCm 7.2 a graph that replays through the runtime's packet-capture path - the fast one -
-        computes ONE wrong step if, since it was instantiated, new device memory was mapped (hipMalloc) and a kernel touched it:
-        content-independent, gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (slower replays), gone when the step is captured again
-        after the mapping.  So a replay that finds the counter moved captures the step again first (`remapped` counts them) - in a
-        steady training loop the allocator serves everything from its cache and the counter stands still."""
-        return torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
 
     def _record_segments(self, dev, gs):
         """the data-parallel step as a StepTape (see the class docstring): dp routes every collective to the tape while it records"""
@@ -692,8 +732,6 @@ class GraphedTrainStep:
                 self._flag_event.record()
 
     def __call__(self, past_feats=None, future_feats=None, lr=None):
-        # (asked before anything of this call is enqueued: has the device drained since the last replay?)
-        drained = self.prime and torch.cuda.current_stream(self.past.device).query()
         if lr is not None:
             self.opt.set_lr(lr)
         if past_feats is not None:
@@ -701,13 +739,6 @@ class GraphedTrainStep:
         if future_feats is not None:
             self.fut.copy_(future_feats)
         self._poll_range()                  # (before the replay: a re-capture replaces self.out)
-        if self._watch_allocs and self._device_allocs(self.past.device) != self._allocs_at_capture:
-            torch.cuda.synchronize(self.past.device)
-            self.remapped += 1
-            self._capture(0)
-        if drained and self._prime_buf is not None:
-            self._prime_buf.zero_()         # (sched.prime_clocks: ONE long memset in front of a busy period that starts from idle)
-            self.primed += 1
         ops.WeightPlanes.refresh_if_stale()
         if self.tape is not None:
             self.tape.replay()

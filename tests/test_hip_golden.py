@@ -678,6 +678,8 @@ def test_graphed_step_recapture_stays_on_the_eager_trajectory(impl):
                 torch.cuda.synchronize()
                 assert step.recaptures == 1
                 step(); out = step()
+                # (a captured step has no memset node: the ROCm 7.2 prepared-packet replay mis-orders them, trainer._require_memset_free)
+                assert step.census["kernel"] > 100 and step.census.get("memset", 0) == 0, step.census
             else:
                 for i in range(6):
                     if i == 3:
@@ -692,6 +694,25 @@ def test_graphed_step_recapture_stays_on_the_eager_trajectory(impl):
     assert abs(le - lg) <= 1e-5 * abs(le), (le, lg)
     err = float((pe - pg).norm() / pe.norm())
     assert err < 1e-6, f"six calls with a re-capture in the middle vs six eager steps: parameters rel-L2 {err:.3e}"
+
+
+def test_captured_steps_have_no_memset_nodes(impl):
+    """On ROCm 7.2 a graph replayed from prepared packets (the runtime's default mode) does not order its memset nodes against the
+    neighbouring kernels (profiles/r06_graph_alloc_hazard.txt), so the captured step contains none: zero fills are kernels and the
+    loss reductions are the library's fixed-order sums - also with a stochastic predictor (NPVP-S: Div_KL's sum, the
+    reparameterisation noise).  `census` is the node count of the capture (npvp_graph_node_counts); the replays in that runtime mode
+    are checked by tests/test_dp_gpu.py::test_replayed_step_survives_caller_allocations in processes of their own."""
+    if MODE != "f16x3":
+        pytest.skip("one arithmetic mode is enough for a property of the captured graph")
+    past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
+    for stochastic in (False, True):
+        m = GC._small_predictor(impl, stochastic, 181, DEV, evt_layers=1, dec_layers=1, dropout=0.1, drop_path=0.1)
+        m.train()
+        opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
+        step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1)
+        assert step.census["kernel"] > 100 and step.census.get("memset", 0) == 0, (stochastic, step.census)
+        step()
+        torch.cuda.synchronize()
 
 
 def test_predictor_full_depth(impl):

@@ -317,6 +317,38 @@ def test_transpose_and_mean(K):
     close(yg.grad, y.grad, tol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 512, 8, 8), (1, 1, 37), (64, 28, 512, 8, 8)])
+def test_scalar_losses_against_the_oracle(shape):
+    """L1Loss and Div_KL (oracle/model.py, ref/models/criterion.py:99-121,341-354) through the library's fixed-order sums
+    (npvp_l1_mean / npvp_l1_mean_bwd / npvp_sum_all): values to 1e-6, the L1 gradient EQUAL to the one torch's abs -> mean -> mul
+    chain produces (sign * lam / n, same order of operations), two runs equal to the bit; a ragged length exercises the tails."""
+    import npvp_amd
+    from oracle import model as OM
+    a, b = O.seeded_randn(shape, 701), O.seeded_randn(shape, 702)
+    b.view(-1)[::7] = a.view(-1)[::7]                       # exact zeros of a - b: sgn(0) = 0
+    ao = a.clone().requires_grad_()
+    want = OM.L1Loss(lam=0.01)(ao, b)
+    (want * 3.0).backward()
+    ad = a.to(DEV).requires_grad_()
+    got = npvp_amd.L1Loss(lam=0.01)(ad, b.to(DEV))
+    (got * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    assert torch.equal(ad.grad.cpu(), ao.grad)
+    again = npvp_amd.L1Loss(lam=0.01)(ad.detach(), b.to(DEV))
+    assert torch.equal(again, got.detach())
+    if len(shape) == 5 and shape[0] <= 2:
+        mu1, lv1, mu2, lv2 = (O.seeded_randn(shape, 710 + i) * 0.3 for i in range(4))
+        lo = [t.clone().requires_grad_() for t in (mu1, lv1, mu2, lv2)]
+        ld = [t.to(DEV).requires_grad_() for t in (mu1, lv1, mu2, lv2)]
+        kw, kg = OM.Div_KL(1e-6)(*lo), npvp_amd.Div_KL(1e-6)(*ld)
+        kw.backward(); kg.backward()
+        assert abs(float(kg) - float(kw)) <= 2e-6 * abs(float(kw))
+        for x, y in zip(ld, lo):
+            close(x.grad, y.grad, tol=1e-6)
+    with pytest.raises(RuntimeError):
+        npvp_amd.ops.l1_mean(ad, b.to(DEV)[..., :-1])
+
+
 # ------------------------------------------------------------------------------- dropout (statistics + fwd/bwd replay)
 def test_dropout_statistics_and_replay(K):
     from npvp_amd.ops import Drop

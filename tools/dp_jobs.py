@@ -6,6 +6,8 @@ tests/conftest.py before the test process touches the GPU; this wrapper itself n
   3. bench.py --gpus 1 on RCCL - one rank, backend nccl, NPVP_DP_FORCE=1: the data-parallel path on real RCCL (see below)
   4. the same with NPVP_DP_COMM=c - the gradient buckets through the library's own npvp_dp_* exchange
   5. tools/dp_check.py with 4 ranks on the card
+  7. tools/graph_alloc_hazard.py - replayed steps with a caller allocating / copying batches between the replays, in both replay modes
+                                of the runtime
   6. tools/dp_segments_check.py - the data-parallel step replayed as HIP-graph segments with the collectives issued eagerly between
                                 them (trainer.StepTape) against the eager data-parallel step, bit for bit: on one RCCL rank and on two
                                 gloo ranks sharing the card
@@ -38,11 +40,16 @@ jobs.append(("dp_check4", run4 + ["--master-port", "29535", os.path.join(ROOT, "
 # 6. the segmented replay of the data-parallel step == the eager data-parallel step, bit for bit (parameters, Adam state, gradients, loss)
 jobs.append(("seg1", run1 + ["--master-port", "29536", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
-# 7. the runtime's graph packet-capture hazard (npvp_amd/__init__.py): in the package's default mode a caller that allocates and writes
-#    device memory between two replays must NOT disturb the replayed trajectory (tools/graph_alloc_hazard.py, three variants)
-for i, b in enumerate(("tiny", "fill:0.001", "clone")):
+# 7. replayed steps and what a caller does between replays (tools/graph_alloc_hazard.py): in the package's default runtime mode
+#    (hazard0-2) and with the runtime's prepared-packet replay switched on (fast0-1: the step has no memset node, which that mode
+#    mis-orders on ROCm 7.2 - npvp_amd/__init__.py) losses and parameters must stay on the eager trajectory, bit for bit
+for i in range(3):
     jobs.append((f"hazard{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
+for i in range(2):
+    jobs.append((f"fast{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
+fast = {k: v for k, v in env.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}         # (inherited from a parent that imported npvp_amd)
 envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill:0.001"), "hazard2": dict(env, BETWEEN="clone"),
+        "fast0": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="inputs"), "fast1": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="tiny"),
         "seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
         "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts ONE unit of the 8-clip batch on a ReLU kink, counted: profiles/r06_dp_check_relu_kink.txt)

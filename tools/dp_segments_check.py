@@ -84,7 +84,7 @@ relg = float((oA.flat_g - oB.flat_g).norm() / oA.flat_g.norm().clamp_min(1e-30))
 print(f"[dp_segments_check] rank {rank}/{world} backend={dist.get_backend()} comm={gB.comm}: {n_seg} graph segments + {n_act} eager actions, "
       f"{step.launches} library launches inside; buckets={len(gB.buckets)} launched={gB.launched}; host ms per replayed step: "
       + " ".join(f"{h:.2f}" for h in host) + "; host ms per EAGER step: " + " ".join(f"{h:.2f}" for h in tA) + f"; loss eager {lossA:.9g} / segments {lossB:.9g}; params rel diff {rel:.3e}, grad rel diff {relg:.3e}; "
-      f"bitwise equal: {res}", flush=True)
+      f"bitwise equal: {res}; nodes of the segments: {step.census}", flush=True)
 ok = all(res.values())
 t = torch.tensor([1.0 if ok else 0.0], device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)

@@ -1,19 +1,30 @@
-"""Reproducer of the ROCm 7.2 graph packet-capture hazard (round 6) and check of the package's safe default.
+"""Reproducer of the ROCm 7.2 graph hazard of round 6 - memset NODES in a graph that the runtime replays from prepared AQL packets -
+and check that the package's captured step is free of it.
 
 A small predictor is trained for six steps twice: eagerly, and by replaying the step's HIP graph (trainer.GraphedTrainStep) with
 something harmless done between the replays, chosen by BETWEEN:
+    none        nothing
     tiny        a 16-float tensor is allocated after the capture; ONE float of it is filled before every replay
+    tiny_sync   the same, and the device is synchronised between the fill and the replay
     fill:<GiB>  a fresh buffer of that size is allocated, filled and freed before every replay
     pre         a buffer allocated BEFORE the capture is filled before every replay
     clone       the caller keeps `out["loss"].clone()` of every step (allocates 512 bytes per step)
-    none        nothing
-With the runtime's packet-capture path (NPVP_GRAPH_PACKET_CAPTURE=1; the ROCm default) `tiny`, `fill` and `clone` make ONE replay
-compute a wrong update - whatever the bytes written are - and the losses leave the eager trajectory; `pre` and `none` are exact.
-With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (what `import npvp_amd` selects unless told otherwise) every variant is exact.
-Prints the two loss sequences and "[graph_alloc_hazard] OK" when they agree to 1e-6.
+    inputs      the real caller: a NEW batch tensor every step, copied into the step's static inputs (step(past, fut))
+Losses AND parameters of the two runs must be equal.
 
-    python tools/graph_alloc_hazard.py                      # package default: must print OK for every BETWEEN
-    NPVP_GRAPH_PACKET_CAPTURE=1 BETWEEN=tiny python tools/graph_alloc_hazard.py     # shows the wrong step
+STEP_MEMSET=loss puts a memset node back into the captured step, as it had them until round 6: the feature loss as
+torch.abs(a - b).mean() - torch's multi-block reduction clears a 4-byte semaphore with a memset.  With the runtime's prepared-packet
+replay (NPVP_GRAPH_PACKET_CAPTURE=1; the ROCm default) that node is not ordered against its neighbours: with BETWEEN=tiny the loss
+scalar of every replay after the first is never written (the parameters stay exact).  The other memset the step had - the 2 KB-per-
+weight amax table that npvp_split_weights_f16 cleared with hipMemsetAsync, now a kernel - raced with the kernels that raise the
+amaxes: the operand scales of the f16x3 GEMMs were cleared late and the PARAMETERS left the eager trajectory (bench.py replay_check
+of the round's earlier tree, profiles/r06_graph_alloc_hazard.txt).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (what `import npvp_amd` selects
+unless told otherwise) every variant is exact, and so is the memset-free step in both modes.  (GraphedTrainStep refuses a step with
+memset nodes under the prepared-packet mode; NPVP_ALLOW_GRAPH_MEMSETS=1 - set by this tool with STEP_MEMSET - lets the reproducer through.)
+
+    python tools/graph_alloc_hazard.py                                              # package default: OK
+    NPVP_GRAPH_PACKET_CAPTURE=1 BETWEEN=tiny python tools/graph_alloc_hazard.py     # memset-free step on the fast replay path: OK
+    NPVP_GRAPH_PACKET_CAPTURE=1 BETWEEN=tiny STEP_MEMSET=loss python tools/graph_alloc_hazard.py    # shows the unwritten loss
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +36,17 @@ from oracle import ops as O
 
 DEV = "cuda:0"
 between = os.environ.get("BETWEEN", "tiny")
+step_memset = os.environ.get("STEP_MEMSET", "")
+if step_memset:
+    os.environ["NPVP_ALLOW_GRAPH_MEMSETS"] = "1"
+    if "loss" in step_memset:
+        class TorchL1:
+            def __init__(self, norm_dim=None, lam=1.0):
+                self.lam = lam
+
+            def __call__(self, a, b):
+                return torch.abs(b - a).mean() * self.lam
+        impl.trainer.L1Loss = TorchL1
 past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
 runs = {}
 for graphed in (False, True):
@@ -35,23 +57,28 @@ for graphed in (False, True):
     losses, kept = [], []
     if graphed:
         pre = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
-        step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1, prime=False)
+        step = impl.GraphedTrainStep(m, opt, past, fut, 0.01, 1e-6, 1.0, warmup=1)
         O.key_hashed_fill(m, 181)                   # (rewind: the constructor's warm-up step was a real one)
         opt.m.zero_(); opt.v.zero_(); opt.hyper[1:2].zero_()
         impl.ops.rng.manual_seed(77, torch.device(DEV))
         for i in range(6):
             torch.cuda.synchronize()
-            if between == "tiny":
+            if between in ("tiny", "tiny_sync"):
                 if i == 0:
                     keep = torch.empty(16, dtype=torch.float32, device=DEV)
                 keep[0:1].fill_(1.0)
+                if between == "tiny_sync":
+                    torch.cuda.synchronize()
             elif between.startswith("fill"):
                 b = torch.empty(int(float(between.split(":")[1]) * (1 << 30)), dtype=torch.uint8, device=DEV)
                 b.fill_(7)
                 del b
             elif between == "pre":
                 pre.fill_(7)
-            out = step()
+            if between == "inputs":
+                out = step(past.clone(), fut.clone())
+            else:
+                out = step()
             torch.cuda.synchronize()
             losses.append(float(out["loss"]))
             if between == "clone":
@@ -62,7 +89,14 @@ for graphed in (False, True):
             torch.cuda.synchronize()
             losses.append(float(out["loss"]))
     runs[graphed] = losses
+    torch.cuda.synchronize()
+    runs[(graphed, 'p')] = opt.flat_p.clone()
+    if graphed:
+        print(f"nodes of the captured step: {step.census}", flush=True)
     print(("replayed" if graphed else "eager   "), " ".join(f"{l:.6f}" for l in losses), flush=True)
-ok = all(abs(a - b) <= 1e-6 * abs(a) + 1e-9 for a, b in zip(runs[False], runs[True]))
-print(f"[graph_alloc_hazard] packet capture {'ON' if impl.graph_packet_capture() else 'off'}, BETWEEN={between}: " + ("OK" if ok else "the replayed run LEFT the eager trajectory"), flush=True)
+same_p = bool(torch.equal(runs[(True, 'p')], runs[(False, 'p')]))
+rel_p = float((runs[(True, 'p')] - runs[(False, 'p')]).norm() / runs[(False, 'p')].norm())
+print(f"parameters after the six steps, replayed against eager: rel l2 diff {rel_p:.3e}, bit-equal {same_p}", flush=True)
+ok = same_p and all(abs(a - b) <= 1e-6 * abs(a) + 1e-9 for a, b in zip(runs[False], runs[True]))
+print(f"[graph_alloc_hazard] packet capture {'ON' if impl.graph_packet_capture() else 'off'}, BETWEEN={between}{' STEP_MEMSET=' + step_memset if step_memset else ''}: " + ("OK" if ok else "the replayed run LEFT the eager trajectory"), flush=True)
 sys.exit(0 if ok else 1)
