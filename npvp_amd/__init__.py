@@ -7,21 +7,25 @@ anywhere, but calling an op without the built library or without a GPU raises - 
 """
 import os as _os
 
-# HIP-graph replays (trainer.GraphedTrainStep) and the ROCm runtime's packet-capture path (round 6, profiles/r06_graph_alloc_hazard.txt).
-# By default the runtime replays a graph from AQL packets it prepared at instantiation - the fast path (c2: 214 ms per replayed step
-# against 236 without it).  On ROCm 7.2 that path computes ONE WRONG STEP, silently and independently of what the bytes are, when
-# device memory that was free when the graph was instantiated is allocated and written by any kernel between two replays (a caller's
-# `loss.clone()`, a new batch tensor, a metrics buffer: tools/graph_alloc_hazard.py reproduces it with a 4-byte fill); with
-# DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 every variant of the reproducer is exact.  A library cannot know what its caller allocates, so
-# the package takes the safe runtime mode unless told otherwise - the variable has to be in the environment before the HIP runtime
-# initialises, i.e. import npvp_amd before the first CUDA call.  NPVP_GRAPH_PACKET_CAPTURE=1 keeps the fast path for loops that
-# allocate nothing between replays (bench.py's timed loops do not, and say so in their record).
+# HIP-graph replays (trainer.GraphedTrainStep) and the ROCm runtime's two replay modes (round 6, profiles/r06_graph_alloc_hazard.txt).
+# By default the runtime replays a graph from AQL packets it prepared at instantiation (0.3 - 1.5 ms of host per replay of ~1 000
+# kernels instead of 2.5 - 8 ms).  On ROCm 7.2 that mode does NOT order a graph's MEMSET NODES against the neighbouring kernels: a
+# hipMemsetAsync captured into the step (the amax table npvp_split_weights_f16 used to clear that way, the 4-byte semaphore of a
+# multi-block torch reduction such as mean()) runs early or late, silently - wrong operand scales and wrong parameters in the first
+# case, a loss scalar that is never written in the second; whether it shows depends on unrelated things (a caller's allocation
+# between two replays, a large memset in front of the loop).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the runtime marshals every node at
+# launch and is exact.  The package's own step has no memset node any more (zero fills are kernels, the losses are the library's
+# fixed-order sums; GraphedTrainStep counts the nodes of every capture and refuses a step with memset nodes in the prepared-packet
+# mode), and it is equal to the bit in both modes - but a caller may capture ops of its own (the frozen decoder's MIOpen
+# convolutions, torch reductions), so the package still takes the mode that is exact with ANY graph unless told otherwise.  The
+# variable has to be in the environment before the HIP runtime initialises, i.e. import npvp_amd before the first CUDA call.
+# NPVP_GRAPH_PACKET_CAPTURE=1 keeps the runtime's default (and the refusal above).
 if _os.environ.get("NPVP_GRAPH_PACKET_CAPTURE", "0") != "1":
     _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 def graph_packet_capture():
-    """True when graph replays go through the runtime's packet-capture path (fast; see the hazard above)"""
+    """True when graph replays go through the runtime's prepared-packet path (less host time; see above for what it does to memset nodes)"""
     return _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"
 
 

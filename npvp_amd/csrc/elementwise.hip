@@ -279,6 +279,7 @@ extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, 
   return NPVP_OK;
 }
 
+namespace npvp {
 // ---- scalar losses of the step (ref/models/criterion.py:99-121 L1Loss, :341-354 Div_KL): deterministic two-stage sums, fixed
 // order, no atomics and no semaphore.  torch's multi-block reductions zero a 4-byte semaphore with a memset NODE when they are
 // captured; memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt), so
@@ -330,6 +331,8 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n & ~3ll; i < n; ++i) da[i] = c * (float)((a[i] > b[i]) - (a[i] < b[i]));
 }
+
+}  // namespace npvp
 
 static long long loss_blocks(long long n) { long long nb = (n / 4 + 255) / 256; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb; }
 

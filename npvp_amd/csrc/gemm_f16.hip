@@ -777,11 +777,14 @@ extern "C" int npvp_amax(const float* x, long long rows, long long cols, long lo
   return NPVP_OK;
 }
 
+namespace npvp {
 // The amax tables are zeroed by a KERNEL, not by hipMemsetAsync: inside a captured step a memset becomes a memset node, and
 // memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt).
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
 }
+}  // namespace npvp
+
 static hipError_t zero_fill(void* p, size_t bytes, hipStream_t stream) {
   const long long n = (long long)(bytes / 4);
   long long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
