@@ -16,7 +16,7 @@ import os as _os
 # between two replays, a large memset in front of the loop).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the runtime marshals every node at
 # launch and is exact.  The package's own step has no memset node any more (zero fills are kernels, the losses are the library's
 # fixed-order sums; GraphedTrainStep counts the nodes of every capture and refuses a step with memset nodes in the prepared-packet
-# mode), and it is equal to the bit in both modes - but a caller may capture ops of its own (the frozen decoder's MIOpen
+# mode), plain or data-parallel, and it is equal to the bit in both modes - but a caller may capture ops of its own (the frozen decoder's MIOpen
 # convolutions, torch reductions), so the package still takes the mode that is exact with ANY graph unless told otherwise.  The
 # variable has to be in the environment before the HIP runtime initialises, i.e. import npvp_amd before the first CUDA call.
 # NPVP_GRAPH_PACKET_CAPTURE=1 keeps the runtime's default (and the refusal above).

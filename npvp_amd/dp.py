@@ -347,6 +347,17 @@ def syncbn_group():
     return _SYNCBN_GROUP
 
 
+def _chan_sum(t, dims):
+    """per-channel sum of a SyncBatchNorm operand.  The predictor hands channels-last ROWS [R, C] on the device: those go through the
+    library's fixed-order column sum (ops.colsum) - deterministic, and without the 4 - 8 byte semaphore memset a multi-block torch
+    reduction brings into a captured graph segment (trainer._require_memset_free).  Anything else (host tensors of the gloo tests,
+    NCHW callers) takes torch's sum."""
+    if t.is_cuda and t.dim() == 2 and t.dtype == torch.float32 and t.shape[1] % 4 == 0:
+        from . import ops
+        return ops.colsum(t if t.is_contiguous() else t.contiguous())
+    return t.sum(dims)
+
+
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, training, group):
@@ -354,7 +365,7 @@ class _SyncBNFn(torch.autograd.Function):
         dims = [0] + list(range(2, x.dim()))
         if training:
             cnt = x.new_full((1,), x.numel() / C)             # (a fill kernel, not a host-to-device copy: capturable)
-            stat = torch.cat([x.sum(dims), (x * x).sum(dims), cnt])
+            stat = torch.cat([_chan_sum(x, dims), _chan_sum(x * x, dims), cnt])
             _collective(lambda: dist.all_reduce(stat, group=group))
             n = stat[-1]
             mean = stat[:C] / n
@@ -376,10 +387,10 @@ class _SyncBNFn(torch.autograd.Function):
         xhat, weight, rstd = ctx.saved_tensors
         dims, shape, training, group, n = ctx.cfg
         C = weight.shape[0]
-        dw, db = (dy * xhat).sum(dims), dy.sum(dims)
+        dw, db = _chan_sum(dy * xhat, dims), _chan_sum(dy, dims)
         g = dy * weight.view(shape)
         if training:
-            s = torch.cat([g.sum(dims), (g * xhat).sum(dims)])
+            s = torch.cat([_chan_sum(g, dims), _chan_sum(g * xhat, dims)])
             _collective(lambda: dist.all_reduce(s, group=group))
             dx = rstd.view(shape) * (g - (s[:C] / n).view(shape) - xhat * (s[C:] / n).view(shape))
         else:

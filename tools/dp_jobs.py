@@ -40,6 +40,9 @@ jobs.append(("dp_check4", run4 + ["--master-port", "29535", os.path.join(ROOT, "
 # 6. the segmented replay of the data-parallel step == the eager data-parallel step, bit for bit (parameters, Adam state, gradients, loss)
 jobs.append(("seg1", run1 + ["--master-port", "29536", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
+#    ... and once more on the RCCL rank with the runtime's prepared-packet replay switched on: the segments carry no memset node
+#    (SyncBatchNorm's statistics are the library's column sums), so that mode is exact too and the host pays less per replay
+jobs.append(("seg1f", run1 + ["--master-port", "29538", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 # 7. replayed steps and what a caller does between replays (tools/graph_alloc_hazard.py): in the package's default runtime mode
 #    (hazard0-2) and with the runtime's prepared-packet replay switched on (fast0-1: the step has no memset node, which that mode
 #    mis-orders on ROCm 7.2 - npvp_amd/__init__.py) losses and parameters must stay on the eager trajectory, bit for bit
@@ -51,6 +54,7 @@ fast = {k: v for k, v in env.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}  
 envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill:0.001"), "hazard2": dict(env, BETWEEN="clone"),
         "fast0": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="inputs"), "fast1": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="tiny"),
         "seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
+        "seg1f": dict(fast, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_GRAPH_PACKET_CAPTURE="1"),
         "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),
         "dp_check4": dict(env, DP_CHECK_SEED="12"),      # (clip seed 11 puts ONE unit of the 8-clip batch on a ReLU kink, counted: profiles/r06_dp_check_relu_kink.txt)
         "rccl1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
