@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B on ONE box: the committed tree (_old/) against the working tree, c4 shard replayed
+# A/B on ONE box: an older tree against the working tree, c4 shard replayed in both replay modes of the runtime, with replay_check.
+# Prepare the older tree in the container first (it travels to the box with the snapshot; _old/ is git-ignored):
+#   mkdir _old && git archive <rev> | tar -x -C _old && (cd _old && python -c 'import __graft_entry__ as g; g.build()')
+# Used for profiles/r06_graph_alloc_hazard.txt 5b (<rev> = 2946ba8, the last tree with memset nodes in the captured step).
 mkdir -p gpurun_out/r06
 out=$PWD/gpurun_out/r06/ab_c4.txt
 : > $out
