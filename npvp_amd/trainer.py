@@ -483,8 +483,9 @@ def _merge_census(total, one):
 def _require_memset_free(census, what):
     """Memset nodes and the runtime's replay modes (round 6, profiles/r06_graph_alloc_hazard.txt): a graph that ROCm 7.2 replays from
     the AQL packets it prepared at instantiation (the runtime's default, DEBUG_CLR_GRAPH_PACKET_CAPTURE=1) does not order its memset
-    nodes against the neighbouring kernels - the zero fill of the amax slots raced with their producers, the 4-byte semaphore of a
-    torch reduction was cleared late and the loss scalar never written.  The step of this package therefore zero-fills with
+    nodes against the neighbouring kernels - the hipMemsetAsync of the weight groups' amax table raced with the kernel that raises the
+    amaxes (wrong operand scales, wrong parameters), the 4-byte semaphore of a torch reduction was cleared at the wrong time and the
+    loss scalar never written.  The step of this package therefore zero-fills with
     kernels and reduces with its own fixed-order sums, and a captured step that still contains a memset node (a caller's own ops
     inside the step, MIOpen) is refused in that replay mode instead of computing silently different numbers."""
     from . import graph_packet_capture
