@@ -40,6 +40,11 @@ def test_argument_errors_do_not_need_a_gpu(built):
     assert L.npvp_attn_fwd(None, 512, None, 512, None, 512, None, 512, 1, 1, 64, 8, 0, 200, 200, 8, 64, 0, 0.0, None, 0, None, None) == -1
     assert b"[1,128]" in L.npvp_last_error()            # (sequence lengths 33 .. 128 are legal since round 5: the generic kernels)
     assert L.npvp_gemm_workspace_bytes(2048, 512, 20480) > 0 and L.npvp_gemm_workspace_bytes(20480, 512, 512) == 0
+    # round 6: the scalar losses and the graph node census
+    assert L.npvp_l1_mean(None, None, 16, 1.0, None, None, 0, None) == -1 and b"l1_mean" in L.npvp_last_error()
+    assert L.npvp_l1_mean_bwd(None, None, 16, None, 1.0, None, None) == -1
+    assert L.npvp_sum_all(None, 0, None, None, 0, None) == -1 and b"sum_all" in L.npvp_last_error()
+    assert L.npvp_graph_node_counts(None, None, None, 0) == -1 and b"graph_node_counts" in L.npvp_last_error()
 
 
 def test_c_api_wrappers_cover_the_abi_and_agree_with_ctypes(built):
