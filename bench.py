@@ -422,6 +422,7 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     if check and replayed and check_state:
         for a_, b_ in zip(check_state["snap"], state_tensors()):      # (`replay_check`: the state the timed replays start from)
             a_.copy_(b_)
+        check_state["rng"] = torch.cuda.get_rng_state(dev)            # (NPVP-S: the position of torch's generator - host state, no device work)
     fence()
     L0 = npvp_amd._lib.lib().npvp_launch_count()
     t0 = time.perf_counter()
@@ -554,10 +555,12 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
     if check and replayed and check_state:
         # Did the TIMED replays compute what eager steps compute?  The state the timed region started from (saved above) is put
         # back and the same K steps are taken eagerly (two streams, every launch enqueued by the host): same batch, same learning
-        # rates, same dropout stream (the seed lives in device memory and is part of the state).
+        # rates, same dropout stream (the seed lives in device memory and is part of the state), same reparameterisation noise
+        # (NPVP-S: torch's generator is put back to where the timed region found it).
         st, snap, pa = state_tensors(), check_state["snap"], check_state["result"]
         for a_, b_ in zip(snap, st):
             b_.copy_(a_)
+        torch.cuda.set_rng_state(check_state["rng"], dev)             # (a replay advances the generator exactly as the eager step does)
         ops.WeightPlanes.refresh_all(opt.flat_p)          # (the planes mirror the parameters that were just put back)
         if gsync is not None:
             gsync.relearn()
@@ -568,10 +571,11 @@ def _run_workload(key, steps, warmup, args, rank, world, dev, probe, flavour=Non
         rel = float((opt.flat_p - pa).norm() / pa.norm())
         upd = float((pa - snap[0]).norm() / pa.norm())
         replay_check = {"steps": steps, "params_rel_l2_replay_vs_eager": rel, "update_rel_l2_over_the_steps": upd,
-                        "loss_replay": loss, "loss_eager": loss_e, "ok": bool(rel < 5e-5 and abs(loss - loss_e) <= 2e-4 * abs(loss_e)),
+                        "loss_replay": loss, "loss_eager": loss_e, "bit_equal": bool(rel == 0.0 and loss == loss_e),
+                        "ok": bool(rel < 5e-5 and abs(loss - loss_e) <= 2e-4 * abs(loss_e)),
                         "packet_capture": npvp_amd.graph_packet_capture(),
-                        "what": "the timed replays against the same steps taken eagerly from the same saved state (NPVP-D: equal to the "
-                                "bit; NPVP-S: the two runs draw their reparameterisation noise from different positions of torch's generator)"}
+                        "what": "the timed replays against the same steps taken eagerly from the same saved state, dropout seed and "
+                                "generator position (expected: 0.0 = equal to the bit)"}
         log(f"[{key}] replay check: " + json.dumps(replay_check))
         check_state.clear()
 

@@ -121,14 +121,14 @@ def test_replayed_step_survives_caller_allocations(request):
     """tools/graph_alloc_hazard.py: a caller that allocates device memory after the capture and writes it between two replays (a
     16-float tensor, a fresh 1 MiB buffer, `loss.clone()` per step, a new batch tensor copied into the static inputs) leaves the
     replayed run ON the eager trajectory - losses and parameters, bit for bit - in the package's default runtime mode (hazard0-2) and
-    with the runtime's prepared-packet replay switched on (fast0-1: NPVP_GRAPH_PACKET_CAPTURE=1).  The second holds because the step
+    with the runtime's prepared-packet replay switched on (fast0-2: NPVP_GRAPH_PACKET_CAPTURE=1; fast2 = the stochastic NPVP-S predictor).  The second holds because the step
     has no memset node: on ROCm 7.2 that replay mode does not order memset nodes against kernels (until round 6 the step had two
     kinds of them and computed wrong steps there: DESIGN 7, profiles/r06_graph_alloc_hazard.txt)."""
     rc, read = _jobs(request)
     for i in range(3):
         log = read(f"hazard{i}")
         assert "[graph_alloc_hazard] packet capture off" in log and "bit-equal True" in log and log.rstrip().endswith("OK"), log[-1500:]
-    for i in range(2):
+    for i in range(3):
         log = read(f"fast{i}")
         assert "[graph_alloc_hazard] packet capture ON" in log and "bit-equal True" in log and log.rstrip().endswith("OK"), log[-1500:]
         assert "'memset'" not in log.split("nodes of the captured step:")[1].split("\n")[0], log[-1500:]

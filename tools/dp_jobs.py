@@ -44,15 +44,16 @@ jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools"
 #    (SyncBatchNorm's statistics are the library's column sums), so that mode is exact too and the host pays less per replay
 jobs.append(("seg1f", run1 + ["--master-port", "29538", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 # 7. replayed steps and what a caller does between replays (tools/graph_alloc_hazard.py): in the package's default runtime mode
-#    (hazard0-2) and with the runtime's prepared-packet replay switched on (fast0-1: the step has no memset node, which that mode
+#    (hazard0-2) and with the runtime's prepared-packet replay switched on (fast0-2: the step has no memset node, which that mode
 #    mis-orders on ROCm 7.2 - npvp_amd/__init__.py) losses and parameters must stay on the eager trajectory, bit for bit
 for i in range(3):
     jobs.append((f"hazard{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
-for i in range(2):
+for i in range(3):
     jobs.append((f"fast{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
 fast = {k: v for k, v in env.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}         # (inherited from a parent that imported npvp_amd)
 envs = {"hazard0": dict(env, BETWEEN="tiny"), "hazard1": dict(env, BETWEEN="fill:0.001"), "hazard2": dict(env, BETWEEN="clone"),
         "fast0": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="inputs"), "fast1": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="tiny"),
+        "fast2": dict(fast, NPVP_GRAPH_PACKET_CAPTURE="1", BETWEEN="inputs", STOCHASTIC="1"),     # (NPVP-S: one memcpy node, same noise in both runs)
         "seg1": dict(env, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1"),
         "seg1f": dict(fast, NPVP_DIST_BACKEND="nccl", NPVP_DP_FORCE="1", NPVP_GRAPH_PACKET_CAPTURE="1"),
         "seg2": dict(env, SEG_CHECK_STEPS="4", SEG_CHECK_LAYERS="4"),

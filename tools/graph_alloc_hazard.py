@@ -10,7 +10,8 @@ something harmless done between the replays, chosen by BETWEEN:
     pre         a buffer allocated BEFORE the capture is filled before every replay
     clone       the caller keeps `out["loss"].clone()` of every step (allocates 512 bytes per step)
     inputs      the real caller: a NEW batch tensor every step, copied into the step's static inputs (step(past, fut))
-Losses AND parameters of the two runs must be equal.
+Losses AND parameters of the two runs must be equal.  STOCHASTIC=1 takes the NPVP-S predictor (both runs draw the same noise: the
+generator is re-seeded in front of the six steps, and a replay advances it exactly as the eager step does).
 
 STEP_MEMSET=loss puts a memset node back into the captured step, as it had them until round 6: the feature loss as
 torch.abs(a - b).mean() - torch's multi-block reduction clears a 4-byte semaphore with a memset.  With the runtime's prepared-packet
@@ -37,6 +38,7 @@ from oracle import ops as O
 DEV = "cuda:0"
 between = os.environ.get("BETWEEN", "tiny")
 step_memset = os.environ.get("STEP_MEMSET", "")
+stochastic = os.environ.get("STOCHASTIC", "0") == "1"        # NPVP-S: both event encoders, KL term, one memcpy node in the graph
 if step_memset:
     os.environ["NPVP_ALLOW_GRAPH_MEMSETS"] = "1"
     if "loss" in step_memset:
@@ -50,10 +52,11 @@ if step_memset:
 past = O.synth_features((2, 3, 512, 8, 8), 182).to(DEV); fut = O.synth_features((2, 4, 512, 8, 8), 183).to(DEV)
 runs = {}
 for graphed in (False, True):
-    m = GC._small_predictor(impl, False, 181, DEV, evt_layers=1, dec_layers=1, dropout=0.1, drop_path=0.1)
+    m = GC._small_predictor(impl, stochastic, 181, DEV, evt_layers=1, dec_layers=1, dropout=0.1, drop_path=0.1)
     m.train()
     opt = impl.FlatAdamW(m, lr=1e-4, clip_module=m.transformer, max_grad_norm=1.0)
     impl.ops.rng.manual_seed(77, torch.device(DEV))
+    torch.cuda.manual_seed(4321)            # (NPVP-S: the reparameterisation noise comes from torch's generator)
     losses, kept = [], []
     if graphed:
         pre = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
@@ -61,6 +64,7 @@ for graphed in (False, True):
         O.key_hashed_fill(m, 181)                   # (rewind: the constructor's warm-up step was a real one)
         opt.m.zero_(); opt.v.zero_(); opt.hyper[1:2].zero_()
         impl.ops.rng.manual_seed(77, torch.device(DEV))
+        torch.cuda.manual_seed(4321)
         for i in range(6):
             torch.cuda.synchronize()
             if between in ("tiny", "tiny_sync"):
@@ -98,5 +102,5 @@ same_p = bool(torch.equal(runs[(True, 'p')], runs[(False, 'p')]))
 rel_p = float((runs[(True, 'p')] - runs[(False, 'p')]).norm() / runs[(False, 'p')].norm())
 print(f"parameters after the six steps, replayed against eager: rel l2 diff {rel_p:.3e}, bit-equal {same_p}", flush=True)
 ok = same_p and all(abs(a - b) <= 1e-6 * abs(a) + 1e-9 for a, b in zip(runs[False], runs[True]))
-print(f"[graph_alloc_hazard] packet capture {'ON' if impl.graph_packet_capture() else 'off'}, BETWEEN={between}{' STEP_MEMSET=' + step_memset if step_memset else ''}: " + ("OK" if ok else "the replayed run LEFT the eager trajectory"), flush=True)
+print(f"[graph_alloc_hazard] packet capture {'ON' if impl.graph_packet_capture() else 'off'}, BETWEEN={between}{' STEP_MEMSET=' + step_memset if step_memset else ''}{' STOCHASTIC' if stochastic else ''}: " + ("OK" if ok else "the replayed run LEFT the eager trajectory"), flush=True)
 sys.exit(0 if ok else 1)
