@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # --graph-packets fast keeps the ROCm runtime's prepared-packet replay path (NPVP_GRAPH_PACKET_CAPTURE=1).  npvp_amd/__init__.py switches it
-# off by default: on ROCm 7.2 it does not order a graph's memset nodes against its kernels (profiles/r06_graph_alloc_hazard.txt).  The
+# off by default: on ROCm 7.2 it does not execute a graph's memset nodes reliably (profiles/r06_graph_alloc_hazard.txt).  The
 # package's own step contains no memset node (`graph_nodes` in the record) and `replay_check` compares the timed replays with the same
 # steps taken eagerly - equal to the bit in both modes.  The choice has to be in the environment before the HIP runtime initialises, hence here.
 if "--graph-packets" in sys.argv and sys.argv[sys.argv.index("--graph-packets") + 1:][:1] == ["fast"]:
@@ -645,7 +645,7 @@ def main():
     ap.add_argument("--graph-packets", default="safe", choices=["fast", "safe"],
                     help="how the ROCm runtime replays a HIP graph: safe (default) = DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the package's default; "
                          "fast = the runtime's prepared-packet path (less host time per replay; refuses a step with memset nodes, which "
-                         "that path mis-orders on ROCm 7.2).  `replay_check` in the record compares the replays with eager steps either way")
+                         "that path does not execute reliably on ROCm 7.2).  `replay_check` in the record compares the replays with eager steps either way")
     ap.add_argument("--graph-streams", type=int, default=1, choices=[1, 2],
                     help="streams inside a captured step: 1 (default: one chain of nodes, what replays fast) or 2 (measurement only)")
     ap.add_argument("--mode", default="auto", choices=["eager", "graph", "auto"],

@@ -57,8 +57,8 @@ int npvp_event_destroy(void* event);
 /* Node census of a captured step (a hipGraph_t, e.g. torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()): counts[16] indexed by
  * hipGraphNodeType (0 kernel, 1 memcpy, 2 memset, ...), memset_bytes[0 .. max_memsets) the sizes of the first memset nodes; returns
  * the number of nodes or a negative error.  The training step of this library contains no memset node, and the host layer checks
- * it: on ROCm 7.2 a graph replayed from prepared packets (the runtime's default) does not order its memset nodes against the
- * neighbouring kernels (profiles/r06_graph_alloc_hazard.txt). */
+ * it: on ROCm 7.2 a graph replayed from prepared packets (the runtime's default) does not execute its memset nodes reliably - stale fill
+ * patterns once the process has issued other memsets (tools/graph_memset_node_repro.py, profiles/r06_graph_alloc_hazard.txt). */
 long long npvp_graph_node_counts(void* graph, long long* counts, long long* memset_bytes, int max_memsets);
 
 /* ---- GEMM (every nn.Linear / 1x1 Conv2d / MHA in- and out-projection and their backward:

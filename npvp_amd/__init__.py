@@ -9,11 +9,11 @@ import os as _os
 
 # HIP-graph replays (trainer.GraphedTrainStep) and the ROCm runtime's two replay modes (round 6, profiles/r06_graph_alloc_hazard.txt).
 # By default the runtime replays a graph from AQL packets it prepared at instantiation (0.3 - 1.5 ms of host per replay of ~1 000
-# kernels instead of 2.5 - 8 ms).  On ROCm 7.2 that mode does NOT order a graph's MEMSET NODES against the neighbouring kernels: a
-# hipMemsetAsync captured into the step (the amax table npvp_split_weights_f16 used to clear that way, the 4-byte semaphore of a
-# multi-block torch reduction such as mean()) runs early or late, silently - wrong operand scales and wrong parameters in the first
-# case, a loss scalar that is never written in the second; whether it shows depends on unrelated things (a caller's allocation
-# between two replays, a large memset in front of the loop).  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the runtime marshals every node at
+# kernels instead of 2.5 - 8 ms).  On ROCm 7.2 that mode does NOT replay a graph's MEMSET NODES reliably: once the process has issued
+# other work after the instantiation - an eager hipMemsetAsync of 1 MiB is enough, tools/graph_memset_node_repro.py shows it with
+# torch alone - a memset node fills part of its buffer with a stale pattern or does nothing, silently.  The step had two of them
+# (the amax table npvp_split_weights_f16 cleared with hipMemsetAsync, the 4-byte semaphore of a multi-block torch reduction such as
+# mean()): wrong operand scales and wrong parameters from the first, a loss scalar that is never written from the second.  With DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the runtime marshals every node at
 # launch and is exact.  The package's own step has no memset node any more (zero fills are kernels, the losses are the library's
 # fixed-order sums; GraphedTrainStep counts the nodes of every capture and refuses a step with memset nodes in the prepared-packet
 # mode), plain or data-parallel, and it is equal to the bit in both modes - but a caller may capture ops of its own (the frozen decoder's MIOpen

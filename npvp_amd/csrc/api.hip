@@ -83,7 +83,7 @@ extern "C" int npvp_event_destroy(void* ev) { return ev && hipEventDestroy((hipE
 
 // What a captured step consists of.  counts[16] by hipGraphNodeType (0 kernel, 1 memcpy, 2 memset, 3 host, 4 child graph, 5 empty,
 // 6 wait-event, 7 event-record, ...); memset_bytes[0 .. max_memsets) = the sizes of the first memset nodes.  Returns the number
-// of nodes, or a negative error.  Why it exists: memset nodes are what the ROCm 7.2 packet-capture replay mishandles
+// of nodes, or a negative error.  Why it exists: memset nodes are what the ROCm 7.2 prepared-packet replay does not execute reliably
 // (profiles/r06_graph_alloc_hazard.txt) - trainer.GraphedTrainStep counts them and refuses that replay mode when it finds any.
 extern "C" long long npvp_graph_node_counts(void* graph, long long* counts, long long* memset_bytes, int max_memsets) {
   if (!graph || !counts) { npvp_set_error("graph_node_counts: null argument"); return NPVP_ERR_ARG; }

@@ -282,7 +282,7 @@ extern "C" int npvp_colsum(const float* x, long long rows, int N, long long ld, 
 namespace npvp {
 // ---- scalar losses of the step (ref/models/criterion.py:99-121 L1Loss, :341-354 Div_KL): deterministic two-stage sums, fixed
 // order, no atomics and no semaphore.  torch's multi-block reductions zero a 4-byte semaphore with a memset NODE when they are
-// captured; memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt), so
+// captured; memset nodes are what the ROCm 7.2 prepared-packet replay does not execute reliably (profiles/r06_graph_alloc_hazard.txt), so
 // the captured step contains none.
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
                                                          float* __restrict__ part) {

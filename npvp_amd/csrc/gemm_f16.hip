@@ -779,7 +779,7 @@ extern "C" int npvp_amax(const float* x, long long rows, long long cols, long lo
 
 namespace npvp {
 // The amax tables are zeroed by a KERNEL, not by hipMemsetAsync: inside a captured step a memset becomes a memset node, and
-// memset nodes are what the ROCm 7.2 packet-capture replay path mishandles (profiles/r06_graph_alloc_hazard.txt).
+// memset nodes are what the ROCm 7.2 prepared-packet replay does not execute reliably (profiles/r06_graph_alloc_hazard.txt).
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0u;
 }

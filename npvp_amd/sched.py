@@ -87,7 +87,7 @@ class AmaxSlot:
         if st is None or st[1] >= cls.CHUNK:
             cur = torch.cuda.current_stream(dev)
             # (zeroed by a fill KERNEL, explicitly: a hipMemsetAsync would be a memset node of a captured step, and memset nodes are
-            #  what the ROCm 7.2 prepared-packet replay mis-orders - profiles/r06_graph_alloc_hazard.txt)
+            #  what the ROCm 7.2 prepared-packet replay does not execute reliably - profiles/r06_graph_alloc_hazard.txt)
             ch = torch.empty(cls.CHUNK, cls.FLOATS, dtype=torch.float32, device=dev).fill_(0.0)
             others = [torch.cuda.default_stream(dev)]
             if WgradStreamState.enabled:

@@ -482,10 +482,11 @@ def _merge_census(total, one):
 
 def _require_memset_free(census, what):
     """Memset nodes and the runtime's replay modes (round 6, profiles/r06_graph_alloc_hazard.txt): a graph that ROCm 7.2 replays from
-    the AQL packets it prepared at instantiation (the runtime's default, DEBUG_CLR_GRAPH_PACKET_CAPTURE=1) does not order its memset
-    nodes against the neighbouring kernels - the hipMemsetAsync of the weight groups' amax table raced with the kernel that raises the
-    amaxes (wrong operand scales, wrong parameters), the 4-byte semaphore of a torch reduction was cleared at the wrong time and the
-    loss scalar never written.  The step of this package therefore zero-fills with
+    the AQL packets it prepared at instantiation (the runtime's default, DEBUG_CLR_GRAPH_PACKET_CAPTURE=1) does not execute its memset
+    nodes reliably: after other work of the process (an eager hipMemsetAsync of 1 MiB is enough: tools/graph_memset_node_repro.py) a
+    memset node fills part of its buffer with a stale pattern or does nothing.  In the training step the hipMemsetAsync of the weight
+    groups' amax table left garbage amaxes (wrong operand scales, wrong parameters) and the 4-byte semaphore of a torch reduction was
+    not cleared (the loss scalar never written).  The step of this package therefore zero-fills with
     kernels and reduces with its own fixed-order sums, and a captured step that still contains a memset node (a caller's own ops
     inside the step, MIOpen) is refused in that replay mode instead of computing silently different numbers."""
     from . import graph_packet_capture
@@ -493,7 +494,7 @@ def _require_memset_free(census, what):
     if n and graph_packet_capture() and os.environ.get("NPVP_ALLOW_GRAPH_MEMSETS") != "1":      # (the switch: tools/graph_alloc_hazard.py)
         raise RuntimeError(f"{what}: the captured step contains {n} memset node(s) (bytes: {census['memset_bytes'][:8]}) and the HIP runtime "
                            "replays graphs from prepared packets (DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0): on ROCm 7.2 such a replay does "
-                           "not order memset nodes against kernels.  Import npvp_amd before the first CUDA call without "
+                           "not execute memset nodes reliably (tools/graph_memset_node_repro.py).  Import npvp_amd before the first CUDA call without "
                            "NPVP_GRAPH_PACKET_CAPTURE=1 (it then selects the node-by-node replay mode), or remove the memsets from the step")
 
 
@@ -583,8 +584,8 @@ class GraphedTrainStep:
     overlap the second stream gives the eager step comes from inside the launches instead (grouped GEMM launches).
 
     Replay mode of the runtime and memset nodes (round 6, profiles/r06_graph_alloc_hazard.txt): ROCm 7.2 replays a graph from AQL
-    packets it prepared at instantiation (0.3 - 1.5 ms of host per replay of ~1 000 kernels) and in that mode does NOT order the
-    graph's memset nodes against the neighbouring kernels; `import npvp_amd` therefore selects DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - the
+    packets it prepared at instantiation (0.3 - 1.5 ms of host per replay of ~1 000 kernels) and in that mode does NOT execute the
+    graph's memset nodes reliably (stale fill patterns after other work of the process: tools/graph_memset_node_repro.py); `import npvp_amd` therefore selects DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - the
     runtime marshals every node at launch (2.5 - 8 ms of host per replay), which is exact with any step.  The step of this package
     contains no memset node (zero fills are kernels, the losses are the library's fixed-order sums), `census` says so for every
     capture, and with the prepared-packet mode switched on (NPVP_GRAPH_PACKET_CAPTURE=1) a capture that does contain one - a caller's

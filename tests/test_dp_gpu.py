@@ -110,7 +110,7 @@ def test_segmented_step_equals_eager_bit_for_bit(request):
     #  packet-capture path this was 3 ms in all - and wrong results.  Either way a fraction of the 31 ms the device needs)
     assert host <= 10.0, f"a replayed data-parallel step costs the host {host} ms"
     # the same job with the runtime's prepared-packet replay mode on (NPVP_GRAPH_PACKET_CAPTURE=1): the segments contain no memset node
-    # (which that mode mis-orders on ROCm 7.2), it is bit-identical too, and the host pays less per replay
+    # (which that mode does not execute reliably on ROCm 7.2), it is bit-identical too, and the host pays less per replay
     fastlog = read("seg1f")
     assert "[dp_segments_check] OK" in fastlog and "'memset'" not in fastlog.split("nodes of the segments:")[1].split("\n")[0], fastlog[-3000:]
     assert fastlog.count("'params': True, 'adam_m': True, 'adam_v': True, 'grad': True, 'loss': True, 'step_count': True") == 1, fastlog[-2000:]
@@ -122,7 +122,7 @@ def test_replayed_step_survives_caller_allocations(request):
     16-float tensor, a fresh 1 MiB buffer, `loss.clone()` per step, a new batch tensor copied into the static inputs) leaves the
     replayed run ON the eager trajectory - losses and parameters, bit for bit - in the package's default runtime mode (hazard0-2) and
     with the runtime's prepared-packet replay switched on (fast0-2: NPVP_GRAPH_PACKET_CAPTURE=1; fast2 = the stochastic NPVP-S predictor).  The second holds because the step
-    has no memset node: on ROCm 7.2 that replay mode does not order memset nodes against kernels (until round 6 the step had two
+    has no memset node: on ROCm 7.2 that replay mode does not execute memset nodes reliably (until round 6 the step had two
     kinds of them and computed wrong steps there: DESIGN 7, profiles/r06_graph_alloc_hazard.txt)."""
     rc, read = _jobs(request)
     for i in range(3):

@@ -678,7 +678,7 @@ def test_graphed_step_recapture_stays_on_the_eager_trajectory(impl):
                 torch.cuda.synchronize()
                 assert step.recaptures == 1
                 step(); out = step()
-                # (a captured step has no memset node: the ROCm 7.2 prepared-packet replay mis-orders them, trainer._require_memset_free)
+                # (a captured step has no memset node: the ROCm 7.2 prepared-packet replay does not execute them reliably, trainer._require_memset_free)
                 assert step.census["kernel"] > 100 and step.census.get("memset", 0) == 0, step.census
             else:
                 for i in range(6):
@@ -697,8 +697,8 @@ def test_graphed_step_recapture_stays_on_the_eager_trajectory(impl):
 
 
 def test_captured_steps_have_no_memset_nodes(impl):
-    """On ROCm 7.2 a graph replayed from prepared packets (the runtime's default mode) does not order its memset nodes against the
-    neighbouring kernels (profiles/r06_graph_alloc_hazard.txt), so the captured step contains none: zero fills are kernels and the
+    """On ROCm 7.2 a graph replayed from prepared packets (the runtime's default mode) does not execute its memset nodes reliably
+    (stale fill patterns or no effect: tools/graph_memset_node_repro.py, profiles/r06_graph_alloc_hazard.txt), so the captured step contains none: zero fills are kernels and the
     loss reductions are the library's fixed-order sums - also with a stochastic predictor (NPVP-S: Div_KL's sum, the
     reparameterisation noise).  `census` is the node count of the capture (npvp_graph_node_counts); the replays in that runtime mode
     are checked by tests/test_dp_gpu.py::test_replayed_step_survives_caller_allocations in processes of their own."""

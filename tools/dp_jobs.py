@@ -45,7 +45,7 @@ jobs.append(("seg2", run + ["--master-port", "29537", os.path.join(ROOT, "tools"
 jobs.append(("seg1f", run1 + ["--master-port", "29538", os.path.join(ROOT, "tools", "dp_segments_check.py")]))
 # 7. replayed steps and what a caller does between replays (tools/graph_alloc_hazard.py): in the package's default runtime mode
 #    (hazard0-2) and with the runtime's prepared-packet replay switched on (fast0-2: the step has no memset node, which that mode
-#    mis-orders on ROCm 7.2 - npvp_amd/__init__.py) losses and parameters must stay on the eager trajectory, bit for bit
+#    does not execute reliably on ROCm 7.2 - npvp_amd/__init__.py) losses and parameters must stay on the eager trajectory, bit for bit
 for i in range(3):
     jobs.append((f"hazard{i}", [sys.executable, os.path.join(ROOT, "tools", "graph_alloc_hazard.py")]))
 for i in range(3):

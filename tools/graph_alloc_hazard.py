@@ -15,7 +15,7 @@ generator is re-seeded in front of the six steps, and a replay advances it exact
 
 STEP_MEMSET=loss puts a memset node back into the captured step, as it had them until round 6: the feature loss as
 torch.abs(a - b).mean() - torch's multi-block reduction clears a 4-byte semaphore with a memset.  With the runtime's prepared-packet
-replay (NPVP_GRAPH_PACKET_CAPTURE=1; the ROCm default) that node is not ordered against its neighbours: with BETWEEN=tiny the loss
+replay (NPVP_GRAPH_PACKET_CAPTURE=1; the ROCm default) that node is not executed reliably: with BETWEEN=tiny the loss
 scalar of every replay after the first is never written (the parameters stay exact).  The other memset the step had - the 2 KB-per-
 weight amax table that npvp_split_weights_f16 cleared with hipMemsetAsync, now a kernel - raced with the kernels that raise the
 amaxes: the operand scales of the f16x3 GEMMs were cleared late and the PARAMETERS left the eager trajectory (bench.py replay_check
